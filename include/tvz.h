@@ -1,0 +1,166 @@
+/*
+ * tvz.h — C ABI of libtvz.so, the MI355X (gfx950) duplicate-detection core.
+ *
+ * The reference (infraheads/tvidz) has NO FFI / plugin boundary on this path.
+ * Its two seams are
+ *   (1) a child process:  ffmpeg -vf select=gt(scene\,0.3),showinfo   whose
+ *       stderr is text-parsed             inspector/app.py:202-232
+ *   (2) a Python function: db.find_duplicates(new_timestamps, min_match=5)
+ *       -> [(video_id, match_count)]       inspector/db.py:76-94,
+ *       driven per new cut by               inspector/app.py:234-255
+ * Each entry point below cites the seam it replaces.  Everything is plain C:
+ * pointers + sizes, no torch / C++ types.  `d_` = device (HBM) pointer,
+ * `h_` = host pointer.  `hip_stream` is a hipStream_t passed as void*
+ * (NULL = the default stream).  All functions are re-entrant; the only shared
+ * mutable object is a tvz_corpus handle, which is internally locked.
+ *
+ * Error convention: 0 on success, negative tvz_status otherwise; the message
+ * is in tvz_last_error() (thread-local).  The Python shim raises
+ * RuntimeError(msg) so failures land in the same `except Exception` as the
+ * reference's (inspector/app.py:303).
+ */
+#ifndef TVZ_H
+#define TVZ_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TVZ_VERSION 100 /* 0.1.0 */
+
+typedef enum tvz_status {
+    TVZ_OK = 0,
+    TVZ_ERR_INVALID = -1,     /* bad argument (null pointer, negative size, ...) */
+    TVZ_ERR_HIP = -2,         /* a HIP runtime call failed */
+    TVZ_ERR_NOMEM = -3,       /* device or host allocation failed */
+    TVZ_ERR_UNSUPPORTED = -4, /* shape outside what the kernels handle */
+    TVZ_ERR_WORKSPACE = -5    /* caller-provided workspace too small */
+} tvz_status;
+
+#define TVZ_KTH_NEVER 0x7fffffff /* kth_hit_idx of a candidate that never reaches min_match */
+
+int tvz_version(void);
+const char *tvz_last_error(void);
+
+/* ------------------------------------------------------------------------
+ * Scene-cut scoring   — replaces the arithmetic reached through
+ * inspector/app.py:202-209 (ffmpeg `select=gt(scene,0.3)`; upstream
+ * libavfilter/f_select.c get_scene_score + scene_sad.c).
+ * ------------------------------------------------------------------------ */
+
+/* Bytes of scratch tvz_luma_sad_u8 / tvz_scene_scores_u8 need for a batch. */
+size_t tvz_scene_workspace_bytes(int64_t T, int32_t H, int32_t W);
+
+/* Luma sum of absolute differences between consecutive frames of a batch.
+ *   d_luma : uint8 luma planes, frame t at d_luma + t*frame_stride_bytes,
+ *            row y at + y*row_stride_bytes, W bytes per row.
+ *   d_sad_out[T] : sad[0] = 0, sad[t] = sum |luma[t] - luma[t-1]|  (exact).
+ * Every luma byte is read from HBM once (+1 halo frame per 128-frame chunk).
+ * Fast path: row_stride == W, base and frame stride 16-byte aligned; anything
+ * else takes a slower generic kernel with identical results. */
+int tvz_luma_sad_u8(const uint8_t *d_luma, int64_t T, int32_t H, int32_t W,
+                    int64_t frame_stride_bytes, int64_t row_stride_bytes,
+                    uint64_t *d_sad_out, void *d_workspace, size_t workspace_bytes,
+                    void *hip_stream);
+
+/* get_scene_score epilogue over a SAD vector:
+ *   mafd  = sad / (W*H) / 2^(bitdepth-8);  diff = |mafd - prev_mafd|
+ *   score = clipf((float)(min(mafd, diff) / 100), 0, 1);  selected = score > threshold
+ * have_prev = 0: element 0 is the first frame of the stream (score 0, and
+ * element 1 uses prev_mafd_in as ffmpeg's zero-initialised prev_mafd would).
+ * have_prev = 1: the batch continues a stream; sad[0] is a real SAD against
+ * the previous batch's last frame and prev_mafd_in is that batch's last mafd.
+ * d_score / d_mafd may be NULL. */
+int tvz_scene_select(const uint64_t *d_sad, int64_t T, int32_t H, int32_t W,
+                     int32_t bitdepth, double threshold, double prev_mafd_in,
+                     int32_t have_prev, uint8_t *d_selected, double *d_score,
+                     double *d_mafd, void *hip_stream);
+
+/* Fused batch call: luma -> sad, mafd, score, selected in two launches.
+ * d_prev_frame (nullable): the last luma plane of the previous batch (tightly
+ * packed H*W bytes, 16-byte aligned); when given, have_prev semantics apply and
+ * element 0 gets a real score.  Any of d_sad_out/d_score/d_mafd may be NULL. */
+int tvz_scene_scores_u8(const uint8_t *d_luma, int64_t T, int32_t H, int32_t W,
+                        int64_t frame_stride_bytes, int64_t row_stride_bytes,
+                        const uint8_t *d_prev_frame, double prev_mafd_in,
+                        int32_t bitdepth, double threshold,
+                        uint64_t *d_sad_out, double *d_mafd, double *d_score,
+                        uint8_t *d_selected, void *d_workspace, size_t workspace_bytes,
+                        void *hip_stream);
+
+/* ------------------------------------------------------------------------
+ * Timestamp corpus   — device image of the `video_timestamps` table
+ * (inspector/db.py:21-27): one row = (video_id, float8[] timestamps).
+ * ------------------------------------------------------------------------ */
+typedef struct tvz_corpus tvz_corpus;
+
+int tvz_corpus_create(tvz_corpus **out, int device);
+int tvz_corpus_destroy(tvz_corpus *c);
+
+/* Replace the whole corpus (the `session.query(VideoTimestamps).all()` of
+ * db.py:83 done once instead of per call).  Row r owns
+ * h_keys[h_offsets[r] .. h_offsets[r+1]).  Rows need not be sorted or unique;
+ * NaN keys are dropped (NaN == x is false), -0.0 is folded into +0.0. */
+int tvz_corpus_upload(tvz_corpus *c, const int32_t *h_video_ids, const int64_t *h_offsets,
+                      const double *h_keys, int64_t n_rows, int64_t n_keys);
+
+/* add_timestamps (db.py:43-64): replace the first row of `video_id` with the
+ * new list, or append a row if the video has none. */
+int tvz_corpus_upsert(tvz_corpus *c, int32_t video_id, const double *h_keys, int64_t n);
+
+/* `/admin/clear-db` (app.py:325-333). */
+int tvz_corpus_clear(tvz_corpus *c);
+
+int tvz_corpus_stats(tvz_corpus *c, int64_t *n_rows, int64_t *n_keys, int64_t *arena_keys);
+
+/* ------------------------------------------------------------------------
+ * Corpus match   — replaces db.find_duplicates (inspector/db.py:76-94) and
+ * the per-prefix loop around it (inspector/app.py:231-255).
+ *
+ * For every (query q, corpus row r):
+ *   count = #{ i : query_q[i] in row_r }                (db.py:86-89; query
+ *           multiplicity counts, the row is a set, exact float64 ==)
+ *   kth   = index i of the min_match-th such hit        (TVZ_KTH_NEVER if
+ *           count < min_match, -1 if min_match <= 0)
+ * A pair is a HIT iff count >= min_match (db.py:90) and video_id !=
+ * exclude_id[q] (app.py:237).  Hits are appended per query as int32 triples
+ * (video_id, count, kth), in unspecified order (as db.py:83 has no ORDER BY).
+ * `kth` makes the streaming loop a single call: prefix k+1 is the first prefix
+ * on which find_duplicates returns row r  <=>  kth == k.
+ * ------------------------------------------------------------------------ */
+
+/* Batched, device-resident form (bench / sharded path).
+ *   d_queries   : float64 keys of all queries back to back
+ *   d_q_offsets : int64[Q+1]
+ *   d_exclude_ids : int32[Q] or NULL
+ *   d_hits      : int32[Q][cap][3] out;  d_hits_n : int32[Q] out = number of
+ *                 hits found (may exceed cap; only the first cap are stored)
+ *   max_query_len : upper bound on any query's length (sizes the LDS table) */
+int tvz_match(tvz_corpus *c, const double *d_queries, const int64_t *d_q_offsets,
+              int32_t Q, int32_t max_query_len, int32_t min_match,
+              const int32_t *d_exclude_ids, int32_t cap,
+              int32_t *d_hits, int32_t *d_hits_n, void *hip_stream);
+
+/* Host-in / host-out single query: the drop-in for db.find_duplicates.
+ * Results sorted by (video_id, count).  *n_out = number of hits (if > cap only
+ * cap are returned).  h_out_kth may be NULL. */
+int tvz_find_duplicates(tvz_corpus *c, const double *h_query, int64_t n, int32_t min_match,
+                        int32_t exclude_id, int64_t cap, int32_t *h_out_ids,
+                        int32_t *h_out_counts, int32_t *h_out_kth, int64_t *n_out);
+
+/* Per-query top-k of hit lists ordered by (kth asc, video_id asc, count asc).
+ *   d_lists : int32[n_lists][Q][cap][3]  (n_lists = 1 for a local tvz_match
+ *             result; = world size for an all-gathered set of per-shard top-k)
+ *   d_lists_n : int32[n_lists][Q] valid counts, or NULL = all cap entries
+ *             (entries with video_id < 0 are padding and sort last)
+ *   d_topk  : int32[Q][k][3] out, padded with (-1, 0, TVZ_KTH_NEVER). */
+int tvz_topk(const int32_t *d_lists, const int32_t *d_lists_n, int32_t n_lists, int32_t Q,
+             int32_t cap, int32_t k, int32_t *d_topk, void *hip_stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TVZ_H */

@@ -1,0 +1,279 @@
+/*
+ * tvz_oracle.c — CPU restatement of the tvidz inspector hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is part of the product:
+ * only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * load this file's shared object, and only as the checker / CPU baseline.
+ * The product path (tvidz_amd/) never imports it and has no CPU fallback.
+ *
+ * What is restated (all citations relative to /root/reference):
+ *
+ *  (1) corpus matcher  — inspector/db.py:76-94 `find_duplicates`, loop shape
+ *      of db.py:85-91 kept verbatim (for cand: for new_ts: `new_ts in
+ *      cand.timestamps` = linear scan with ==).
+ *      PARITY: PINNED.  Checked against the reference's only known-answer
+ *      test (inspector/test_app.py:66-83) and against tests/golden/match_*.json,
+ *      which were produced by executing the reference's own db.find_duplicates
+ *      in the build container (oracle/gen_golden.py).
+ *
+ *  (2) streaming verdict — inspector/app.py:228-255: consecutive-duplicate
+ *      drop (:231), per-prefix match with min_match (:235), self exclusion by
+ *      id (:237), stop at first non-empty result (:238-255).  Restated as the
+ *      batch-equivalent "index of the min_match-th hit" per candidate.
+ *      PARITY: PINNED through (1) (golden streaming cases replay app.py's loop
+ *      over the reference's find_duplicates).
+ *
+ *  (3) scene score — the arithmetic is NOT in /root/reference.  It lives in a
+ *      third-party dependency: the `ffmpeg` CLI installed UNPINNED by apt
+ *      (inspector/Dockerfile:13, .github/workflows/unit-tests.yml:41), reached
+ *      through the argv at inspector/app.py:202-208
+ *      (`-vf select=gt(scene\,0.3),showinfo`).  This file restates FFmpeg's
+ *      published algorithm (libavfilter/f_select.c get_scene_score + scene_sad.c,
+ *      FFmpeg 4.1 … 7.x): luma-only SAD for planar YUV, mafd, |mafd-prev_mafd|,
+ *      min(...)/100 clipped to [0,1] *in float32*, selected iff score > thr.
+ *      PARITY: UNPINNED.  The reference holds no test, fixture or golden output
+ *      for this half (analyze_file is monkeypatched out, test_app.py:29-32) and
+ *      there is no ffmpeg binary in this image.  tests/test_ffmpeg_live.py
+ *      cross-checks against a live ffmpeg wherever one exists.
+ *
+ *  (4) pts_time text — libavfilter/vf_showinfo.c prints `pts_time:%s` with
+ *      av_ts2timestr(pts, &time_base): "%.6g" of av_q2d(tb)*pts for FFmpeg <= 6.x,
+ *      "%.*f" with precision 6 (more below 1.0) and trailing zeros trimmed for
+ *      FFmpeg >= 7.0 (libavutil/timestamp.c av_ts_make_time_string2).  Both
+ *      policies are restated; the parsed double (inspector/app.py:230) is the
+ *      fingerprint element.  PARITY: UNPINNED (same reason as (3)).
+ *
+ * Build: oracle/Makefile  ->  oracle/libtvz_oracle.so   (plain C, gcc -O2)
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define ORC_API __attribute__((visibility("default")))
+
+/* ------------------------------------------------------------------ */
+/* (3) scene score                                                    */
+/* ------------------------------------------------------------------ */
+
+/* scene_sad.c ff_scene_sad_c: sum over HxW of |a-b| on 8-bit samples.
+ * sad_out[0] = 0 (first frame has no predecessor, f_select.c returns 0). */
+ORC_API int orc_luma_sad_u8(const uint8_t *luma, int64_t T, int32_t H, int32_t W,
+                            int64_t frame_stride, int64_t row_stride,
+                            uint64_t *sad_out)
+{
+    if (T <= 0) return 0;
+    sad_out[0] = 0;
+    for (int64_t t = 1; t < T; t++) {
+        const uint8_t *cur = luma + t * frame_stride;
+        const uint8_t *prv = cur - frame_stride;
+        uint64_t sad = 0;
+        for (int32_t y = 0; y < H; y++) {
+            const uint8_t *a = prv + (int64_t)y * row_stride;
+            const uint8_t *b = cur + (int64_t)y * row_stride;
+            uint32_t rs = 0;
+            for (int32_t x = 0; x < W; x++)
+                rs += (uint32_t)abs((int)a[x] - (int)b[x]);
+            sad += rs;
+        }
+        sad_out[t] = sad;
+    }
+    return 0;
+}
+
+/* multi-threaded helper for the CPU baseline leg: frames [t0,t1) only */
+ORC_API int orc_luma_sad_u8_range(const uint8_t *luma, int64_t t0, int64_t t1,
+                                  int32_t H, int32_t W, int64_t frame_stride,
+                                  int64_t row_stride, uint64_t *sad_out)
+{
+    for (int64_t t = t0; t < t1; t++) {
+        if (t == 0) { sad_out[0] = 0; continue; }
+        const uint8_t *cur = luma + t * frame_stride;
+        const uint8_t *prv = cur - frame_stride;
+        uint64_t sad = 0;
+        for (int32_t y = 0; y < H; y++) {
+            const uint8_t *a = prv + (int64_t)y * row_stride;
+            const uint8_t *b = cur + (int64_t)y * row_stride;
+            uint32_t rs = 0;
+            for (int32_t x = 0; x < W; x++)
+                rs += (uint32_t)abs((int)a[x] - (int)b[x]);
+            sad += rs;
+        }
+        sad_out[t] = sad;
+    }
+    return 0;
+}
+
+/* f_select.c get_scene_score, one step.
+ *   mafd  = (double)sad / count / (1ULL << (bitdepth - 8));
+ *   diff  = fabs(mafd - prev_mafd);
+ *   ret   = av_clipf(FFMIN(mafd, diff) / 100., 0, 1);   // float32 clip
+ *   prev_mafd = mafd;
+ * `first` != 0 means "no previous picture": score 0 and prev_mafd untouched. */
+static double scene_step(uint64_t sad, uint64_t count, int bitdepth,
+                         double *prev_mafd, int first, double *mafd_out)
+{
+    if (first) { if (mafd_out) *mafd_out = 0.0; return 0.0; }
+    double mafd = (double)sad / (double)count / (double)(1ULL << (bitdepth - 8));
+    double diff = fabs(mafd - *prev_mafd);
+    double m = (mafd > diff) ? diff : mafd;        /* FFMIN(a,b) = a > b ? b : a */
+    float f = (float)(m / 100.);
+    if (f < 0.0f) f = 0.0f; else if (f > 1.0f) f = 1.0f;   /* av_clipf */
+    *prev_mafd = mafd;
+    if (mafd_out) *mafd_out = mafd;
+    return (double)f;
+}
+
+/* sad[T] -> score[T], selected[T] (score > threshold, double compare as the
+ * expression evaluator of `select` does).  have_prev = 0: frame 0 is the
+ * first frame of the stream (score 0).  have_prev = 1: this is a later chunk
+ * of a longer stream, sad[0] is a real SAD against the previous chunk's last
+ * frame and prev_mafd_in carries that chunk's last mafd.
+ * Returns the last mafd through *prev_mafd_out. */
+ORC_API int orc_scene_select(const uint64_t *sad, int64_t T, int32_t H, int32_t W,
+                             int32_t bitdepth, double threshold,
+                             double prev_mafd_in, int32_t have_prev,
+                             uint8_t *selected, double *score, double *mafd,
+                             double *prev_mafd_out)
+{
+    double prev = prev_mafd_in;
+    uint64_t count = (uint64_t)W * (uint64_t)H;
+    for (int64_t t = 0; t < T; t++) {
+        double mf;
+        double s = scene_step(sad[t], count, bitdepth, &prev,
+                              (t == 0 && !have_prev), &mf);
+        if (score) score[t] = s;
+        if (mafd) mafd[t] = mf;
+        if (selected) selected[t] = (s > threshold) ? 1 : 0;
+    }
+    if (prev_mafd_out) *prev_mafd_out = prev;
+    return 0;
+}
+
+/* ------------------------------------------------------------------ */
+/* (4) pts_time text                                                  */
+/* ------------------------------------------------------------------ */
+
+/* policy 0: FFmpeg <= 6.x   snprintf("%.6g", av_q2d(tb) * ts)
+ * policy 1: FFmpeg >= 7.0   av_ts_make_time_string2 */
+ORC_API int orc_fmt_pts_time(int64_t pts, int32_t tb_num, int32_t tb_den,
+                             int32_t policy, char *buf, int32_t buflen)
+{
+    double val = ((double)tb_num / (double)tb_den) * (double)pts; /* av_q2d(tb) * ts */
+    if (policy == 0) {
+        snprintf(buf, (size_t)buflen, "%.6g", val);
+    } else {
+        double lg = (fpclassify(val) == FP_ZERO) ? -INFINITY : floor(log10(fabs(val)));
+        int precision = (isfinite(lg) && lg < 0) ? (int)(-lg) + 5 : 6;
+        int last = snprintf(buf, (size_t)buflen, "%.*f", precision, val);
+        if (last > buflen - 1) last = buflen - 1;
+        last -= 1;
+        for (; last && buf[last] == '0'; last--) ;
+        for (; last && buf[last] != 'f' && (buf[last] < '0' || buf[last] > '9'); last--) ;
+        buf[last + 1] = '\0';
+    }
+    return 0;
+}
+
+/* what inspector/app.py:230 recovers: float(text) */
+ORC_API double orc_pts_time_value(int64_t pts, int32_t tb_num, int32_t tb_den,
+                                  int32_t policy)
+{
+    char buf[64];
+    orc_fmt_pts_time(pts, tb_num, tb_den, policy, buf, (int32_t)sizeof buf);
+    return strtod(buf, NULL);
+}
+
+/* ------------------------------------------------------------------ */
+/* (1) find_duplicates — db.py:85-91, same loop shape                  */
+/* ------------------------------------------------------------------ */
+
+/* corpus in CSR form: candidate c owns keys[offsets[c] .. offsets[c+1]) in the
+ * order stored (NOT required sorted or unique — `in` on a list is a scan).
+ * out_ids/out_counts sized >= C.  Returns number of results, in corpus order. */
+ORC_API int64_t orc_find_duplicates(const double *query, int64_t nq,
+                                    const int64_t *offsets, const double *keys,
+                                    const int32_t *video_ids, int64_t C,
+                                    int32_t min_match,
+                                    int32_t *out_ids, int32_t *out_counts)
+{
+    int64_t n = 0;
+    for (int64_t c = 0; c < C; c++) {                       /* db.py:85 */
+        int32_t match_count = 0;                            /* db.py:86 */
+        const double *cand = keys + offsets[c];
+        int64_t L = offsets[c + 1] - offsets[c];
+        for (int64_t i = 0; i < nq; i++) {                  /* db.py:87 */
+            double new_ts = query[i];
+            int found = 0;
+            for (int64_t j = 0; j < L; j++)                 /* db.py:88 `in` */
+                if (cand[j] == new_ts) { found = 1; break; }
+            if (found) match_count++;                       /* db.py:89 */
+        }
+        if (match_count >= min_match) {                     /* db.py:90 */
+            out_ids[n] = video_ids[c];                      /* db.py:91 */
+            out_counts[n] = match_count;
+            n++;
+        }
+    }
+    return n;
+}
+
+/* (2) per-candidate index (into the query as given) of the min_match-th hit,
+ * INT32_MAX if never reached, -1 if min_match <= 0.  count_out = full count.
+ * This is the batch form of app.py:235-238: prefix k+1 is the first prefix on
+ * which candidate c is returned by find_duplicates  <=>  kth[c] == k. */
+ORC_API int orc_match_kth(const double *query, int64_t nq,
+                          const int64_t *offsets, const double *keys, int64_t C,
+                          int32_t min_match, int32_t *count_out, int32_t *kth_out)
+{
+    for (int64_t c = 0; c < C; c++) {
+        const double *cand = keys + offsets[c];
+        int64_t L = offsets[c + 1] - offsets[c];
+        int32_t cnt = 0, kth = (min_match <= 0) ? -1 : INT32_MAX;
+        for (int64_t i = 0; i < nq; i++) {
+            int found = 0;
+            for (int64_t j = 0; j < L; j++)
+                if (cand[j] == query[i]) { found = 1; break; }
+            if (found) {
+                cnt++;
+                if (cnt == min_match) kth = (int32_t)i;
+            }
+        }
+        count_out[c] = cnt;
+        kth_out[c] = kth;
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------------------ */
+/* "fair CPU bound" variant for the cpu_baseline leg: candidates       */
+/* pre-sorted + unique (caller's job), binary search per probe.        */
+/* Same results as orc_match_kth when candidates hold no NaN.          */
+/* ------------------------------------------------------------------ */
+ORC_API int orc_match_kth_sorted(const double *query, int64_t nq,
+                                 const int64_t *offsets, const double *keys,
+                                 int64_t c0, int64_t c1, int32_t min_match,
+                                 int32_t *count_out, int32_t *kth_out)
+{
+    for (int64_t c = c0; c < c1; c++) {
+        const double *cand = keys + offsets[c];
+        int64_t L = offsets[c + 1] - offsets[c];
+        int32_t cnt = 0, kth = (min_match <= 0) ? -1 : INT32_MAX;
+        for (int64_t i = 0; i < nq; i++) {
+            double q = query[i];
+            int64_t lo = 0, hi = L;
+            while (lo < hi) {
+                int64_t mid = (lo + hi) >> 1;
+                if (cand[mid] < q) lo = mid + 1; else hi = mid;
+            }
+            if (lo < L && cand[lo] == q) {
+                cnt++;
+                if (cnt == min_match) kth = (int32_t)i;
+            }
+        }
+        count_out[c] = cnt;
+        kth_out[c] = kth;
+    }
+    return 0;
+}

@@ -1,0 +1,159 @@
+"""Device-resident image of the `video_timestamps` table and the matcher over it.
+
+Host side of the seam at /root/reference/inspector/db.py:76-94 (`find_duplicates`) and of the
+per-cut loop around it (inspector/app.py:231-255).  All compute is in csrc/tvz_match.hip; this
+module only marshals arrays through the C ABI of include/tvz.h.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Iterable, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+
+KTH_NEVER = _lib.KTH_NEVER
+
+
+def rows_to_csr(rows: Iterable[Tuple[int, Sequence[float]]]):
+    """[(video_id, [ts...])] -> (ids int32[C], offsets int64[C+1], keys float64[n])."""
+    rows = list(rows)
+    ids = np.fromiter((int(v) for v, _ in rows), dtype=np.int32, count=len(rows))
+    lens = np.fromiter((len(t) for _, t in rows), dtype=np.int64, count=len(rows))
+    offs = np.zeros(len(rows) + 1, dtype=np.int64)
+    np.cumsum(lens, out=offs[1:])
+    keys = np.empty(int(offs[-1]), dtype=np.float64)
+    for (_, t), o, n in zip(rows, offs[:-1], lens):
+        if n:
+            keys[o:o + n] = np.asarray(t, dtype=np.float64)
+    return ids, offs, keys
+
+
+def _ptr(a: Optional[np.ndarray]):
+    return None if a is None or a.size == 0 else C.c_void_p(a.ctypes.data)
+
+
+class DeviceCorpus:
+    """tvz_corpus handle: rows of (video_id, sorted-unique canonical float64 keys) in HBM."""
+
+    def __init__(self, device: int = 0):
+        self.lib = _lib.load()
+        self.device = int(device)
+        h = C.c_void_p()
+        _lib.check(self.lib.tvz_corpus_create(C.byref(h), self.device))
+        self._h = h
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            self.lib.tvz_corpus_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- mutation (db.py:43-64 add_timestamps; app.py:325-333 clear-db) ----
+    def upload_csr(self, ids: np.ndarray, offsets: np.ndarray, keys: np.ndarray) -> None:
+        ids = np.ascontiguousarray(ids, dtype=np.int32)
+        offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+        keys = np.ascontiguousarray(keys, dtype=np.float64)
+        if offsets.size != ids.size + 1:
+            raise RuntimeError("offsets must have len(ids)+1 entries")
+        _lib.check(self.lib.tvz_corpus_upload(self._h, _ptr(ids), C.c_void_p(offsets.ctypes.data),
+                                              _ptr(keys), ids.size, keys.size))
+
+    def upload(self, rows: Iterable[Tuple[int, Sequence[float]]]) -> None:
+        self.upload_csr(*rows_to_csr(rows))
+
+    def upsert(self, video_id: int, timestamps: Sequence[float]) -> None:
+        k = np.ascontiguousarray(np.asarray(timestamps, dtype=np.float64))
+        _lib.check(self.lib.tvz_corpus_upsert(self._h, int(video_id), _ptr(k), k.size))
+
+    def clear(self) -> None:
+        _lib.check(self.lib.tvz_corpus_clear(self._h))
+
+    def stats(self) -> Tuple[int, int, int]:
+        a, b, c = C.c_int64(), C.c_int64(), C.c_int64()
+        _lib.check(self.lib.tvz_corpus_stats(self._h, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
+
+    # ---- single query, host in / host out: the db.find_duplicates drop-in ----
+    def find_duplicates(self, new_timestamps: Sequence[float], min_match: int = 5,
+                        exclude_id: int = -1, with_kth: bool = False):
+        q = np.ascontiguousarray(np.asarray(new_timestamps, dtype=np.float64))
+        cap = max(self.stats()[0], 1)
+        while True:
+            ids = np.empty(cap, dtype=np.int32)
+            cnt = np.empty(cap, dtype=np.int32)
+            kth = np.empty(cap, dtype=np.int32)
+            n = C.c_int64()
+            _lib.check(self.lib.tvz_find_duplicates(self._h, _ptr(q), q.size, int(min_match),
+                                                    int(exclude_id), cap, C.c_void_p(ids.ctypes.data),
+                                                    C.c_void_p(cnt.ctypes.data),
+                                                    C.c_void_p(kth.ctypes.data), C.byref(n)))
+            if n.value <= cap:
+                break
+            cap = int(n.value)  # rows were added concurrently: retry with room for all
+        m = n.value
+        if with_kth:
+            return [(int(ids[i]), int(cnt[i]), int(kth[i])) for i in range(m)]
+        return [(int(ids[i]), int(cnt[i])) for i in range(m)]
+
+    # ---- batched, device resident ----
+    def match(self, d_queries: torch.Tensor, d_q_offsets: torch.Tensor, max_query_len: int,
+              min_match: int, cap: int, d_exclude_ids: Optional[torch.Tensor] = None,
+              out_hits: Optional[torch.Tensor] = None, out_n: Optional[torch.Tensor] = None,
+              stream: Optional[torch.cuda.Stream] = None):
+        """Enqueue Q queries; returns (hits int32[Q,cap,3], hits_n int32[Q]) device tensors."""
+        dev = d_queries.device
+        if dev.type != "cuda" or dev.index != self.device:
+            raise RuntimeError(f"queries must live on cuda:{self.device}")
+        if d_queries.dtype != torch.float64 or d_q_offsets.dtype != torch.int64:
+            raise RuntimeError("queries must be float64 and offsets int64")
+        Q = d_q_offsets.numel() - 1
+        if out_hits is None:
+            out_hits = torch.empty((Q, cap, 3), dtype=torch.int32, device=dev)
+        if out_n is None:
+            out_n = torch.empty(Q, dtype=torch.int32, device=dev)
+        s = stream if stream is not None else torch.cuda.current_stream(dev)
+        _lib.check(self.lib.tvz_match(
+            self._h, d_queries.data_ptr(), d_q_offsets.data_ptr(), Q, int(max_query_len),
+            int(min_match), d_exclude_ids.data_ptr() if d_exclude_ids is not None else None,
+            int(cap), out_hits.data_ptr(), out_n.data_ptr(), s.cuda_stream))
+        return out_hits, out_n
+
+
+def topk(lists: torch.Tensor, lists_n: Optional[torch.Tensor], k: int,
+         out: Optional[torch.Tensor] = None, stream: Optional[torch.cuda.Stream] = None) -> torch.Tensor:
+    """Per-query k best hits ordered by (kth, video_id, count).
+    lists: int32 [Q,cap,3] or [n_lists,Q,cap,3] (all-gathered shards); -> int32 [Q,k,3]."""
+    if lists.dim() == 3:
+        lists = lists.unsqueeze(0)
+    if lists.dtype != torch.int32 or lists.device.type != "cuda" or not lists.is_contiguous():
+        raise RuntimeError("lists must be a contiguous int32 CUDA tensor")
+    n_lists, Q, cap, _ = lists.shape
+    if out is None:
+        out = torch.empty((Q, k, 3), dtype=torch.int32, device=lists.device)
+    s = stream if stream is not None else torch.cuda.current_stream(lists.device)
+    with torch.cuda.device(lists.device):
+        _lib.check(_lib.load().tvz_topk(lists.data_ptr(),
+                                        lists_n.data_ptr() if lists_n is not None else None,
+                                        n_lists, Q, cap, k, out.data_ptr(), s.cuda_stream))
+    return out
+
+
+def pack_queries(queries: Sequence[Sequence[float]], device) -> Tuple[torch.Tensor, torch.Tensor, int]:
+    """Host lists -> (float64 keys, int64 offsets, max_len) on `device`."""
+    lens = np.fromiter((len(q) for q in queries), dtype=np.int64, count=len(queries))
+    offs = np.zeros(len(queries) + 1, dtype=np.int64)
+    np.cumsum(lens, out=offs[1:])
+    flat = np.empty(max(int(offs[-1]), 1), dtype=np.float64)
+    for q, o, n in zip(queries, offs[:-1], lens):
+        if n:
+            flat[o:o + n] = np.asarray(q, dtype=np.float64)
+    return (torch.from_numpy(flat).to(device), torch.from_numpy(offs).to(device),
+            int(lens.max()) if len(queries) else 0)

@@ -1,0 +1,676 @@
+// tvz_match.hip — timestamp-corpus matcher for MI355X (gfx950, wave64).
+//
+// Replaces /root/reference inspector/db.py:76-94 (find_duplicates) and the per-prefix
+// loop around it, inspector/app.py:231-255.  Semantics (db.py:85-91): for every corpus
+// row, count the query elements that are `in` the row (exact float64 ==; the query keeps
+// its multiplicity, the row acts as a set); a row is a hit iff count >= min_match.
+//
+// Device image of `video_timestamps` (db.py:21-27):
+//   rows[r] = {key offset, key count, video_id}           16 B each
+//   keys    = arena of canonical float64 bit patterns (int64): per row sorted, unique,
+//             NaN dropped, -0.0 folded to +0.0; every row starts 16-byte aligned.
+//
+// Kernel ts_match_kernel: grid = (row chunks, Q).  A 256-thread block builds query q's
+//   hash set (open addressing, key -> multiplicity) in LDS once, then sweeps its chunk
+//   of rows: a 16-lane group owns one row at a time, streams its keys with 16-byte loads
+//   (row bytes are read once per (query, row) pair: 8*L_c bytes), probes the LDS table,
+//   reduces the count with 4 row-DPP adds.  Only hits (rare) take the slow path that
+//   recovers the index of the min_match-th hit by binary-searching the sorted row per
+//   query position, and append (video_id, count, kth) to the query's hit list.
+//   HBM/L2-bound integer work: no MFMA.
+// Kernel ts_topk_kernel: per query bitonic selection of the k best hits ordered by
+//   (kth, video_id, count) over one or several (all-gathered) hit lists.
+#include <algorithm>
+#include <cstring>
+#include <mutex>
+#include <shared_mutex>
+#include <unordered_map>
+#include <vector>
+
+#include "tvz_common.h"
+
+namespace {
+
+constexpr int kBlock = 256;
+constexpr int kGroup = 16;                  // lanes per corpus row
+constexpr int kGroupsPerBlock = kBlock / kGroup;
+constexpr int64_t kEmpty = 0x7ff8dead00000000LL;  // a NaN pattern: never a canonical key
+constexpr int kMaxSlots = 8192;             // 8192 * 12 B = 96 KiB of LDS
+constexpr int kMaxQueryLen = kMaxSlots / 2;
+
+struct Row {
+    int64_t off;
+    int32_t len;
+    int32_t vid;
+};
+static_assert(sizeof(Row) == 16, "Row must be 16 bytes");
+
+// ---- canonical key: integer-only so subnormals / signed zero never meet FP modes ----
+__host__ __device__ inline bool canon_key(double x, int64_t &k) {
+    int64_t b;
+    memcpy(&b, &x, 8);
+    const uint64_t mag = (uint64_t)b & 0x7fffffffffffffffULL;
+    if (mag > 0x7ff0000000000000ULL) return false;  // NaN: == is always false
+    k = (mag == 0) ? 0 : b;                         // -0.0 == +0.0
+    return true;
+}
+
+__device__ __forceinline__ uint32_t hash_key(int64_t k, int shift) {
+    const uint32_t lo = (uint32_t)k, hi = (uint32_t)((uint64_t)k >> 32);
+    uint32_t x = lo ^ (hi * 0x9E3779B1u);
+    x *= 0x85EBCA6Bu;
+    x ^= x >> 15;
+    x *= 0xC2B2AE35u;
+    return x >> shift;
+}
+
+template <int CTRL>
+__device__ __forceinline__ int dpp_row(int v) {
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true);
+}
+
+// all-reduce sum over the 16 lanes of a DPP row (all 16 lanes must be active)
+__device__ __forceinline__ int group_sum16(int v) {
+    v += dpp_row<0xB1>(v);   // quad_perm [1,0,3,2]
+    v += dpp_row<0x4E>(v);   // quad_perm [2,3,0,1]
+    v += dpp_row<0x141>(v);  // row_half_mirror
+    v += dpp_row<0x140>(v);  // row_mirror
+    return v;
+}
+
+__device__ __forceinline__ int probe(const int64_t *tab, const int32_t *mult, uint32_t mask,
+                                     int shift, int64_t k) {
+    uint32_t h = hash_key(k, shift);
+    while (true) {
+        const int64_t t = tab[h];
+        if (t == k) return mult[h];
+        if (t == kEmpty) return 0;
+        h = (h + 1) & mask;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void ts_match_kernel(
+    const Row *__restrict__ rows, int64_t n_rows, const int64_t *__restrict__ keys,
+    const double *__restrict__ queries, const int64_t *__restrict__ q_offsets, int32_t min_match,
+    const int32_t *__restrict__ exclude_ids, int32_t cap, int32_t *__restrict__ hits,
+    int32_t *__restrict__ hits_n, int32_t slots, int32_t rows_per_block) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    int64_t *tab = reinterpret_cast<int64_t *>(smem);
+    int32_t *mult = reinterpret_cast<int32_t *>(smem + (size_t)slots * 8);
+    const uint32_t mask = (uint32_t)slots - 1;
+    const int shift = 32 - (31 - __builtin_clz(slots));  // 32 - log2(slots)
+
+    const int q = blockIdx.y;
+    const int64_t qo = q_offsets[q];
+    const int32_t qlen = (int32_t)(q_offsets[q + 1] - qo);
+    const double *qv = queries + qo;
+
+    for (int i = threadIdx.x; i < slots; i += kBlock) {
+        tab[i] = kEmpty;
+        mult[i] = 0;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < qlen; i += kBlock) {
+        int64_t k;
+        if (!canon_key(qv[i], k)) continue;
+        uint32_t h = hash_key(k, shift);
+        while (true) {
+            const unsigned long long old =
+                atomicCAS(reinterpret_cast<unsigned long long *>(&tab[h]),
+                          (unsigned long long)kEmpty, (unsigned long long)k);
+            if (old == (unsigned long long)kEmpty || old == (unsigned long long)k) {
+                atomicAdd(&mult[h], 1);
+                break;
+            }
+            h = (h + 1) & mask;
+        }
+    }
+    __syncthreads();
+
+    const int gl = threadIdx.x & (kGroup - 1);
+    const int g = threadIdx.x / kGroup;
+    const int gshift = (threadIdx.x & 63) & ~(kGroup - 1);  // bit position of this group in a ballot
+    const int32_t excl = exclude_ids ? exclude_ids[q] : -1;
+    const bool use_excl = exclude_ids != nullptr;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    int64_t r1 = r0 + rows_per_block;
+    if (r1 > n_rows) r1 = n_rows;
+
+    for (int64_t r = r0 + g; r < r1; r += kGroupsPerBlock) {
+        const Row row = rows[r];
+        if (use_excl && row.vid == excl) continue;  // group-uniform
+        const int64_t *rk = keys + row.off;
+        int cnt = 0;
+        for (int i = gl * 2; i < row.len; i += kGroup * 2) {
+            const longlong2 kk = *reinterpret_cast<const longlong2 *>(rk + i);  // 16 B, aligned
+            cnt += probe(tab, mult, mask, shift, kk.x);
+            if (i + 1 < row.len) cnt += probe(tab, mult, mask, shift, kk.y);
+        }
+        const int total = group_sum16(cnt);
+        if (total < min_match) continue;  // group-uniform; the common case
+
+        // ---- hit: recover the query index of the min_match-th hit ----
+        int kth = -1;
+        if (min_match > 0) {
+            kth = TVZ_KTH_NEVER;
+            int running = 0;
+            for (int base = 0; base < qlen && kth == TVZ_KTH_NEVER; base += kGroup) {
+                const int i = base + gl;
+                bool hit = false;
+                int64_t k;
+                if (i < qlen && canon_key(qv[i], k)) {
+                    int lo = 0, hi = row.len;
+                    while (lo < hi) {
+                        const int mid = (lo + hi) >> 1;
+                        if (rk[mid] < k) lo = mid + 1; else hi = mid;
+                    }
+                    hit = lo < row.len && rk[lo] == k;
+                }
+                const uint32_t m16 = (uint32_t)(__ballot(hit) >> gshift) & 0xffffu;
+                const int c = __popc(m16);
+                if (running + c >= min_match) {
+                    uint32_t m = m16;
+                    for (int need = min_match - running; need > 1; --need) m &= m - 1;
+                    kth = base + (__ffs(m) - 1);
+                }
+                running += c;
+            }
+        }
+        if (gl == 0) {
+            const int slot = atomicAdd(&hits_n[q], 1);
+            if (slot < cap) {
+                int32_t *h = hits + ((int64_t)q * cap + slot) * 3;
+                h[0] = row.vid;
+                h[1] = total;
+                h[2] = kth;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------- top-k
+constexpr int kSortCap = 2048;
+
+__device__ __forceinline__ uint64_t sort_key(int32_t vid, int32_t kth) {
+    return ((uint64_t)(uint32_t)(kth + 1) << 32) | (uint32_t)vid;
+}
+
+__device__ void bitonic_sort(uint64_t *key, int32_t *cnt, int n /* power of two */) {
+    for (int size = 2; size <= n; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            __syncthreads();
+            for (int i = threadIdx.x; i < n / 2; i += blockDim.x) {
+                const int lo = 2 * i - (i & (stride - 1));
+                const int hi = lo + stride;
+                const bool up = (lo & size) == 0;
+                const uint64_t a = key[lo], b = key[hi];
+                const int32_t ca = cnt[lo], cb = cnt[hi];
+                const bool gt = (a > b) || (a == b && ca > cb);
+                if (gt == up) {
+                    key[lo] = b; key[hi] = a;
+                    cnt[lo] = cb; cnt[hi] = ca;
+                }
+            }
+        }
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(kBlock) void ts_topk_kernel(const int32_t *__restrict__ lists,
+                                                         const int32_t *__restrict__ lists_n,
+                                                         int32_t n_lists, int32_t Q, int32_t cap,
+                                                         int32_t k, int32_t *__restrict__ topk) {
+    __shared__ uint64_t key[kSortCap];
+    __shared__ int32_t cnt[kSortCap];
+    const int q = blockIdx.x;
+    int pos = 0;  // block-uniform fill level
+    auto sort_and_keep = [&]() {
+        int P = 2;
+        while (P < pos) P <<= 1;
+        for (int i = pos + threadIdx.x; i < P; i += kBlock) { key[i] = ~0ULL; cnt[i] = 0; }
+        bitonic_sort(key, cnt, P);
+        if (pos > k) pos = k;
+    };
+    for (int l = 0; l < n_lists; ++l) {
+        int n = lists_n ? lists_n[(int64_t)l * Q + q] : cap;
+        if (n > cap) n = cap;
+        const int32_t *src = lists + ((int64_t)l * Q + q) * (int64_t)cap * 3;
+        int j = 0;
+        while (j < n) {
+            int m = n - j;
+            if (m > kSortCap - pos) m = kSortCap - pos;
+            for (int i = threadIdx.x; i < m; i += kBlock) {
+                const int32_t vid = src[(j + i) * 3 + 0];
+                key[pos + i] = vid < 0 ? ~0ULL : sort_key(vid, src[(j + i) * 3 + 2]);
+                cnt[pos + i] = src[(j + i) * 3 + 1];
+            }
+            pos += m;
+            j += m;
+            __syncthreads();
+            if (pos == kSortCap) sort_and_keep();
+        }
+    }
+    __syncthreads();
+    sort_and_keep();
+    for (int i = threadIdx.x; i < k; i += kBlock) {
+        int32_t *o = topk + ((int64_t)q * k + i) * 3;
+        const uint64_t kk = (i < pos) ? key[i] : ~0ULL;
+        if (kk == ~0ULL) {
+            o[0] = -1; o[1] = 0; o[2] = TVZ_KTH_NEVER;
+        } else {
+            o[0] = (int32_t)(uint32_t)kk;
+            o[1] = cnt[i];
+            o[2] = (int32_t)(uint32_t)(kk >> 32) - 1;
+        }
+    }
+}
+
+// ---------------------------------------------------------------- host side
+struct Staging {
+    hipStream_t stream = nullptr;
+    double *d_query = nullptr;   int64_t query_cap = 0;
+    int64_t *d_qoff = nullptr;
+    int32_t *d_hits = nullptr;   int64_t hits_cap = 0;
+    int32_t *d_hits_n = nullptr;
+    int32_t *h_hits = nullptr;   int64_t h_hits_cap = 0;  // pinned
+    int64_t *h_small = nullptr;                          // pinned: qoff[2] + hits_n
+};
+
+template <typename T>
+struct DevBuf {
+    T *p = nullptr;
+    int64_t cap = 0;
+};
+
+}  // namespace
+
+struct tvz_corpus {
+    int device = 0;
+    std::shared_mutex mu;        // exclusive: mutation; shared: enqueueing a match
+    std::mutex ev_mu;
+    std::mutex stage_mu;
+    DevBuf<int64_t> keys;
+    DevBuf<Row> rows;
+    std::vector<int64_t> h_keys;  // host mirror of the arena (for compaction)
+    std::vector<Row> h_rows;
+    std::unordered_map<int32_t, int64_t> first_row;  // video_id -> first row index
+    int64_t live_keys = 0;
+    static constexpr int kEvents = 32;
+    hipEvent_t events[kEvents] = {};
+    bool ev_pending[kEvents] = {};
+    int ev_next = 0;
+    std::vector<Staging *> free_staging;
+};
+
+namespace {
+
+struct DeviceGuard {
+    int prev = -1;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) (void)hipSetDevice(dev); else prev = -1;
+    }
+    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+
+// canonical, sorted, unique keys of one row appended to `out` (padded to an even count)
+int64_t canon_row(const double *src, int64_t n, std::vector<int64_t> &out) {
+    const size_t start = out.size();
+    for (int64_t i = 0; i < n; ++i) {
+        int64_t k;
+        if (canon_key(src[i], k)) out.push_back(k);
+    }
+    std::sort(out.begin() + start, out.end());
+    out.erase(std::unique(out.begin() + start, out.end()), out.end());
+    const int64_t len = (int64_t)(out.size() - start);
+    if (out.size() & 1) out.push_back(kEmpty);  // keep every row 16-byte aligned
+    return len;
+}
+
+template <typename T>
+int ensure(DevBuf<T> &b, int64_t need, int64_t keep) {
+    if (need <= b.cap) return TVZ_OK;
+    int64_t cap = std::max<int64_t>(need, b.cap * 2);
+    cap = std::max<int64_t>(cap, 1024);
+    T *np = nullptr;
+    if (hipMalloc(&np, (size_t)cap * sizeof(T)) != hipSuccess)
+        return tvz::fail(TVZ_ERR_NOMEM, "hipMalloc of %lld bytes failed",
+                         (long long)(cap * (int64_t)sizeof(T)));
+    if (b.p && keep > 0) TVZ_HIP(hipMemcpy(np, b.p, (size_t)keep * sizeof(T), hipMemcpyDeviceToDevice));
+    if (b.p) (void)hipFree(b.p);
+    b.p = np;
+    b.cap = cap;
+    return TVZ_OK;
+}
+
+// wait for every match kernel enqueued so far (caller holds mu exclusively)
+int drain(tvz_corpus *c) {
+    std::lock_guard<std::mutex> lk(c->ev_mu);
+    for (int i = 0; i < tvz_corpus::kEvents; ++i)
+        if (c->ev_pending[i]) {
+            TVZ_HIP(hipEventSynchronize(c->events[i]));
+            c->ev_pending[i] = false;
+        }
+    return TVZ_OK;
+}
+
+int record(tvz_corpus *c, hipStream_t st) {
+    std::lock_guard<std::mutex> lk(c->ev_mu);
+    const int i = c->ev_next;
+    c->ev_next = (i + 1) % tvz_corpus::kEvents;
+    if (c->ev_pending[i]) TVZ_HIP(hipEventSynchronize(c->events[i]));
+    TVZ_HIP(hipEventRecord(c->events[i], st));
+    c->ev_pending[i] = true;
+    return TVZ_OK;
+}
+
+int upload_all(tvz_corpus *c) {
+    if (int rc = ensure(c->keys, (int64_t)c->h_keys.size() + 2, 0)) return rc;
+    if (int rc = ensure(c->rows, (int64_t)c->h_rows.size() + 1, 0)) return rc;
+    if (!c->h_keys.empty())
+        TVZ_HIP(hipMemcpy(c->keys.p, c->h_keys.data(), c->h_keys.size() * 8, hipMemcpyHostToDevice));
+    if (!c->h_rows.empty())
+        TVZ_HIP(hipMemcpy(c->rows.p, c->h_rows.data(), c->h_rows.size() * sizeof(Row),
+                          hipMemcpyHostToDevice));
+    return TVZ_OK;
+}
+
+int compact(tvz_corpus *c) {
+    std::vector<int64_t> nk;
+    nk.reserve((size_t)c->live_keys + c->h_rows.size());
+    for (Row &r : c->h_rows) {
+        const int64_t off = (int64_t)nk.size();
+        nk.insert(nk.end(), c->h_keys.begin() + r.off, c->h_keys.begin() + r.off + r.len);
+        if (nk.size() & 1) nk.push_back(kEmpty);
+        r.off = off;
+    }
+    c->h_keys.swap(nk);
+    return upload_all(c);
+}
+
+int launch_match(tvz_corpus *c, const double *d_queries, const int64_t *d_q_offsets, int32_t Q,
+                 int32_t max_query_len, int32_t min_match, const int32_t *d_exclude_ids,
+                 int32_t cap, int32_t *d_hits, int32_t *d_hits_n, hipStream_t st) {
+    if (max_query_len > kMaxQueryLen)
+        return tvz::fail(TVZ_ERR_UNSUPPORTED, "query of %d timestamps exceeds the supported %d",
+                         max_query_len, kMaxQueryLen);
+    TVZ_HIP(hipMemsetAsync(d_hits_n, 0, (size_t)Q * sizeof(int32_t), st));
+    const int64_t n_rows = (int64_t)c->h_rows.size();
+    if (n_rows == 0 || Q == 0) return TVZ_OK;
+    int slots = 64;
+    while (slots < 4 * max_query_len && slots < kMaxSlots) slots <<= 1;
+    while (slots < 2 * max_query_len) slots <<= 1;
+    const size_t lds = (size_t)slots * 12;
+    // enough blocks to fill 256 CUs several times over, but >= 4 rows per 16-lane group
+    int64_t want_chunks = std::max<int64_t>(1, 8192 / Q);
+    int64_t rpb = tvz::ceil_div(n_rows, want_chunks);
+    rpb = std::max<int64_t>(rpb, 4 * kGroupsPerBlock);
+    rpb = tvz::round_up(rpb, kGroupsPerBlock);
+    const int64_t chunks = tvz::ceil_div(n_rows, rpb);
+    hipLaunchKernelGGL(ts_match_kernel, dim3((unsigned)chunks, (unsigned)Q), dim3(kBlock), lds, st,
+                       c->rows.p, n_rows, c->keys.p, d_queries, d_q_offsets, min_match,
+                       d_exclude_ids, cap, d_hits, d_hits_n, slots, (int32_t)rpb);
+    TVZ_HIP(hipGetLastError());
+    return TVZ_OK;
+}
+
+int staging_get(tvz_corpus *c, Staging **out) {
+    {
+        std::lock_guard<std::mutex> lk(c->stage_mu);
+        if (!c->free_staging.empty()) {
+            *out = c->free_staging.back();
+            c->free_staging.pop_back();
+            return TVZ_OK;
+        }
+    }
+    Staging *s = new Staging();
+    TVZ_HIP(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+    TVZ_HIP(hipMalloc(&s->d_qoff, 2 * sizeof(int64_t)));
+    TVZ_HIP(hipMalloc(&s->d_hits_n, sizeof(int32_t)));
+    TVZ_HIP(hipHostMalloc(&s->h_small, 4 * sizeof(int64_t)));
+    *out = s;
+    return TVZ_OK;
+}
+
+void staging_put(tvz_corpus *c, Staging *s) {
+    std::lock_guard<std::mutex> lk(c->stage_mu);
+    c->free_staging.push_back(s);
+}
+
+void staging_free(Staging *s) {
+    if (s->d_query) (void)hipFree(s->d_query);
+    if (s->d_qoff) (void)hipFree(s->d_qoff);
+    if (s->d_hits) (void)hipFree(s->d_hits);
+    if (s->d_hits_n) (void)hipFree(s->d_hits_n);
+    if (s->h_hits) (void)hipHostFree(s->h_hits);
+    if (s->h_small) (void)hipHostFree(s->h_small);
+    if (s->stream) (void)hipStreamDestroy(s->stream);
+    delete s;
+}
+
+}  // namespace
+
+TVZ_EXPORT int tvz_corpus_create(tvz_corpus **out, int device) {
+    TVZ_REQUIRE(out != nullptr, "out is NULL");
+    int n = 0;
+    TVZ_HIP(hipGetDeviceCount(&n));
+    TVZ_REQUIRE(device >= 0 && device < n, "device %d out of range (%d visible)", device, n);
+    DeviceGuard dg(device);
+    tvz_corpus *c = new tvz_corpus();
+    c->device = device;
+    for (int i = 0; i < tvz_corpus::kEvents; ++i)
+        TVZ_HIP(hipEventCreateWithFlags(&c->events[i], hipEventDisableTiming));
+    TVZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(ts_match_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, kMaxSlots * 12));
+    if (int rc = upload_all(c)) { delete c; return rc; }
+    *out = c;
+    return TVZ_OK;
+}
+
+TVZ_EXPORT int tvz_corpus_destroy(tvz_corpus *c) {
+    if (!c) return TVZ_OK;
+    DeviceGuard dg(c->device);
+    {
+        std::unique_lock<std::shared_mutex> lk(c->mu);
+        (void)drain(c);
+        for (Staging *s : c->free_staging) staging_free(s);
+        c->free_staging.clear();
+        if (c->keys.p) (void)hipFree(c->keys.p);
+        if (c->rows.p) (void)hipFree(c->rows.p);
+        for (int i = 0; i < tvz_corpus::kEvents; ++i)
+            if (c->events[i]) (void)hipEventDestroy(c->events[i]);
+    }
+    delete c;
+    return TVZ_OK;
+}
+
+TVZ_EXPORT int tvz_corpus_upload(tvz_corpus *c, const int32_t *h_video_ids,
+                                 const int64_t *h_offsets, const double *h_keys, int64_t n_rows,
+                                 int64_t n_keys) {
+    TVZ_REQUIRE(c != nullptr, "corpus is NULL");
+    TVZ_REQUIRE(n_rows >= 0 && n_keys >= 0, "negative size");
+    TVZ_REQUIRE(n_rows == 0 || (h_video_ids && h_offsets), "NULL row arrays");
+    TVZ_REQUIRE(n_keys == 0 || h_keys, "NULL keys");
+    for (int64_t r = 0; r < n_rows; ++r) {
+        TVZ_REQUIRE(h_offsets[r] <= h_offsets[r + 1] && h_offsets[r] >= 0 &&
+                        h_offsets[r + 1] <= n_keys,
+                    "offsets of row %lld are not monotone within [0, n_keys]", (long long)r);
+        TVZ_REQUIRE(h_offsets[r + 1] - h_offsets[r] <= INT32_MAX, "row %lld too long", (long long)r);
+    }
+    DeviceGuard dg(c->device);
+    std::unique_lock<std::shared_mutex> lk(c->mu);
+    if (int rc = drain(c)) return rc;
+    c->h_keys.clear();
+    c->h_rows.clear();
+    c->first_row.clear();
+    c->h_keys.reserve((size_t)n_keys + (size_t)n_rows);
+    c->h_rows.reserve((size_t)n_rows);
+    c->live_keys = 0;
+    for (int64_t r = 0; r < n_rows; ++r) {
+        Row row;
+        row.off = (int64_t)c->h_keys.size();
+        row.len = (int32_t)canon_row(h_keys + h_offsets[r], h_offsets[r + 1] - h_offsets[r], c->h_keys);
+        row.vid = h_video_ids[r];
+        c->first_row.emplace(row.vid, r);
+        c->h_rows.push_back(row);
+        c->live_keys += row.len;
+    }
+    return upload_all(c);
+}
+
+TVZ_EXPORT int tvz_corpus_upsert(tvz_corpus *c, int32_t video_id, const double *h_keys, int64_t n) {
+    TVZ_REQUIRE(c != nullptr, "corpus is NULL");
+    TVZ_REQUIRE(n >= 0 && n <= INT32_MAX && (n == 0 || h_keys), "bad key array");
+    DeviceGuard dg(c->device);
+    std::unique_lock<std::shared_mutex> lk(c->mu);
+    if (int rc = drain(c)) return rc;
+    const int64_t off = (int64_t)c->h_keys.size();
+    const int64_t len = canon_row(h_keys, n, c->h_keys);
+    const int64_t added = (int64_t)c->h_keys.size() - off;
+    auto it = c->first_row.find(video_id);
+    const int64_t rows_before = (int64_t)c->h_rows.size();
+    int64_t r;
+    if (it == c->first_row.end()) {
+        r = rows_before;
+        c->h_rows.push_back(Row{off, (int32_t)len, video_id});
+        c->first_row.emplace(video_id, r);
+    } else {
+        r = it->second;
+        c->live_keys -= c->h_rows[r].len;
+        c->h_rows[r].off = off;
+        c->h_rows[r].len = (int32_t)len;
+    }
+    c->live_keys += len;
+    // garbage-collect the arena when more than half of it is dead
+    if ((int64_t)c->h_keys.size() > 2 * (c->live_keys + (int64_t)c->h_rows.size()) + 4096)
+        return compact(c);
+    if (int rc = ensure(c->keys, (int64_t)c->h_keys.size() + 2, off)) return rc;
+    if (int rc = ensure(c->rows, (int64_t)c->h_rows.size() + 1, rows_before)) return rc;
+    if (added)
+        TVZ_HIP(hipMemcpy(c->keys.p + off, c->h_keys.data() + off, (size_t)added * 8,
+                          hipMemcpyHostToDevice));
+    TVZ_HIP(hipMemcpy(c->rows.p + r, &c->h_rows[r], sizeof(Row), hipMemcpyHostToDevice));
+    return TVZ_OK;
+}
+
+TVZ_EXPORT int tvz_corpus_clear(tvz_corpus *c) {
+    TVZ_REQUIRE(c != nullptr, "corpus is NULL");
+    DeviceGuard dg(c->device);
+    std::unique_lock<std::shared_mutex> lk(c->mu);
+    if (int rc = drain(c)) return rc;
+    c->h_keys.clear();
+    c->h_rows.clear();
+    c->first_row.clear();
+    c->live_keys = 0;
+    return TVZ_OK;
+}
+
+TVZ_EXPORT int tvz_corpus_stats(tvz_corpus *c, int64_t *n_rows, int64_t *n_keys,
+                                int64_t *arena_keys) {
+    TVZ_REQUIRE(c != nullptr, "corpus is NULL");
+    std::shared_lock<std::shared_mutex> lk(c->mu);
+    if (n_rows) *n_rows = (int64_t)c->h_rows.size();
+    if (n_keys) *n_keys = c->live_keys;
+    if (arena_keys) *arena_keys = (int64_t)c->h_keys.size();
+    return TVZ_OK;
+}
+
+TVZ_EXPORT int tvz_match(tvz_corpus *c, const double *d_queries, const int64_t *d_q_offsets,
+                         int32_t Q, int32_t max_query_len, int32_t min_match,
+                         const int32_t *d_exclude_ids, int32_t cap, int32_t *d_hits,
+                         int32_t *d_hits_n, void *hip_stream) {
+    TVZ_REQUIRE(c != nullptr, "corpus is NULL");
+    TVZ_REQUIRE(Q >= 0 && Q <= 65535, "Q=%d out of range [0, 65535]", Q);
+    TVZ_REQUIRE(max_query_len >= 0 && cap >= 0, "negative size");
+    if (Q == 0) return TVZ_OK;
+    TVZ_REQUIRE(d_q_offsets && d_hits_n && (cap == 0 || d_hits), "NULL output / offsets");
+    TVZ_REQUIRE(d_queries || max_query_len == 0, "d_queries is NULL");
+    DeviceGuard dg(c->device);
+    hipStream_t st = reinterpret_cast<hipStream_t>(hip_stream);
+    std::shared_lock<std::shared_mutex> lk(c->mu);
+    if (int rc = launch_match(c, d_queries, d_q_offsets, Q, max_query_len, min_match,
+                              d_exclude_ids, cap, d_hits, d_hits_n, st))
+        return rc;
+    return record(c, st);
+}
+
+TVZ_EXPORT int tvz_find_duplicates(tvz_corpus *c, const double *h_query, int64_t n,
+                                   int32_t min_match, int32_t exclude_id, int64_t cap,
+                                   int32_t *h_out_ids, int32_t *h_out_counts, int32_t *h_out_kth,
+                                   int64_t *n_out) {
+    TVZ_REQUIRE(c != nullptr && n_out != nullptr, "NULL argument");
+    TVZ_REQUIRE(n >= 0 && cap >= 0 && cap <= INT32_MAX, "bad size");
+    TVZ_REQUIRE(n == 0 || h_query, "h_query is NULL");
+    TVZ_REQUIRE(cap == 0 || (h_out_ids && h_out_counts), "NULL outputs");
+    if (n > kMaxQueryLen)
+        return tvz::fail(TVZ_ERR_UNSUPPORTED, "query of %lld timestamps exceeds the supported %d",
+                         (long long)n, kMaxQueryLen);
+    DeviceGuard dg(c->device);
+    Staging *s = nullptr;
+    if (int rc = staging_get(c, &s)) return rc;
+    struct Put { tvz_corpus *c; Staging *s; ~Put() { staging_put(c, s); } } put{c, s};
+    if (n > s->query_cap) {
+        if (s->d_query) (void)hipFree(s->d_query);
+        s->query_cap = std::max<int64_t>(n, 256);
+        TVZ_HIP(hipMalloc(&s->d_query, (size_t)s->query_cap * 8));
+    }
+    if (cap > s->hits_cap) {
+        if (s->d_hits) (void)hipFree(s->d_hits);
+        if (s->h_hits) (void)hipHostFree(s->h_hits);
+        s->hits_cap = std::max<int64_t>(cap, 1024);
+        TVZ_HIP(hipMalloc(&s->d_hits, (size_t)s->hits_cap * 12));
+        TVZ_HIP(hipHostMalloc(&s->h_hits, (size_t)s->hits_cap * 12));
+    }
+    s->h_small[0] = 0;
+    s->h_small[1] = n;
+    TVZ_HIP(hipMemcpyAsync(s->d_qoff, s->h_small, 16, hipMemcpyHostToDevice, s->stream));
+    if (n) TVZ_HIP(hipMemcpyAsync(s->d_query, h_query, (size_t)n * 8, hipMemcpyHostToDevice, s->stream));
+    int32_t *d_excl = nullptr;  // exclusion is applied on the host for the single-query form
+    {
+        std::shared_lock<std::shared_mutex> lk(c->mu);
+        if (int rc = launch_match(c, s->d_query, s->d_qoff, 1, (int32_t)n, min_match, d_excl,
+                                  (int32_t)cap, s->d_hits, s->d_hits_n, s->stream))
+            return rc;
+        if (int rc = record(c, s->stream)) return rc;
+    }
+    int32_t *h_n = reinterpret_cast<int32_t *>(s->h_small + 2);
+    TVZ_HIP(hipMemcpyAsync(h_n, s->d_hits_n, 4, hipMemcpyDeviceToHost, s->stream));
+    TVZ_HIP(hipStreamSynchronize(s->stream));
+    int64_t found = *h_n;
+    int64_t stored = std::min<int64_t>(found, cap);
+    if (stored) {
+        TVZ_HIP(hipMemcpyAsync(s->h_hits, s->d_hits, (size_t)stored * 12, hipMemcpyDeviceToHost, s->stream));
+        TVZ_HIP(hipStreamSynchronize(s->stream));
+    }
+    struct Hit { int32_t vid, cnt, kth; };
+    Hit *hh = reinterpret_cast<Hit *>(s->h_hits);
+    std::sort(hh, hh + stored, [](const Hit &a, const Hit &b) {
+        if (a.vid != b.vid) return a.vid < b.vid;
+        if (a.cnt != b.cnt) return a.cnt < b.cnt;
+        return a.kth < b.kth;
+    });
+    int64_t w = 0;
+    for (int64_t i = 0; i < stored; ++i) {
+        if (hh[i].vid == exclude_id && exclude_id >= 0) { --found; continue; }
+        h_out_ids[w] = hh[i].vid;
+        h_out_counts[w] = hh[i].cnt;
+        if (h_out_kth) h_out_kth[w] = hh[i].kth;
+        ++w;
+    }
+    // truncated: report the device count so the caller can retry with cap >= *n_out
+    *n_out = (*h_n > cap) ? found : w;
+    return TVZ_OK;
+}
+
+TVZ_EXPORT int tvz_topk(const int32_t *d_lists, const int32_t *d_lists_n, int32_t n_lists,
+                        int32_t Q, int32_t cap, int32_t k, int32_t *d_topk, void *hip_stream) {
+    TVZ_REQUIRE(n_lists >= 1 && Q >= 0 && cap >= 0, "bad list shape");
+    TVZ_REQUIRE(k >= 1 && k <= kSortCap / 2, "k=%d out of range [1, %d]", k, kSortCap / 2);
+    if (Q == 0) return TVZ_OK;
+    TVZ_REQUIRE((d_lists || cap == 0) && d_topk, "NULL argument");
+    hipLaunchKernelGGL(ts_topk_kernel, dim3((unsigned)Q), dim3(kBlock), 0,
+                       reinterpret_cast<hipStream_t>(hip_stream), d_lists, d_lists_n, n_lists, Q,
+                       cap, k, d_topk);
+    TVZ_HIP(hipGetLastError());
+    return TVZ_OK;
+}

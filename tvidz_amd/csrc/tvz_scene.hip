@@ -1,0 +1,456 @@
+// tvz_scene.hip — scene-cut scoring kernels for MI355X (gfx950, wave64).
+//
+// Replaces the arithmetic reached through /root/reference inspector/app.py:202-209
+// (ffmpeg `select=gt(scene\,0.3)`: upstream libavfilter f_select.c get_scene_score +
+// scene_sad.c).  Integer part (luma SAD) is exact; the epilogue reproduces the
+// double / float32 operation order of get_scene_score.
+//
+// Kernel 1  luma_sad_flat_kernel<U>   HBM-bound streaming reduction.
+//   A wave owns a spatial strip of U KiB (64 lanes x U x 16 B) and WALKS TIME over a
+//   chunk of `tc` frames keeping the previous frame's strip in registers, so every
+//   luma byte crosses HBM once (+1 halo frame per chunk).  16-byte loads, 1 KiB per
+//   wave-instruction, v_sad_u8 (4 bytes / instruction) into a per-lane u32, DPP row
+//   reduction + row_bcast to lane 63 per frame, result parked in lane (t & 63) and
+//   written as one 256-byte store per 64 frames to partial[strip][t].
+//   No LDS, no atomics, no MFMA (a reduction, not a contraction).
+// Kernel 2  scene_finalize_kernel     sums partial[.][t] over strips (u64) and applies
+//   the get_scene_score epilogue (mafd, diff, float32 clip, threshold).
+// Kernel 1g luma_sad_generic_kernel   same structure on 4-byte granules for padded
+//   rows / unaligned planes (slower, identical results).
+#include "tvz_common.h"
+
+namespace {
+
+constexpr int kWave = 64;
+constexpr int kBlock = 256;           // 4 waves
+constexpr int kWavesPerBlock = kBlock / kWave;
+
+struct Tuning {
+    int U = 4;     // 16-byte loads per lane per frame on the flat path (1,2,4,8)
+    int tc = 128;  // frames per time chunk (multiple of 64)
+};
+Tuning g_tune;
+
+// ---- wave64 sum to lane 63 with DPP (row_shr within 16-lane rows, then row_bcast) ----
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_add(uint32_t v) {
+    // lanes whose DPP source is invalid or masked take `old` = 0
+    return v + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xf, false);
+}
+
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
+    v = dpp_add<0x111, 0xf>(v);  // row_shr:1
+    v = dpp_add<0x112, 0xf>(v);  // row_shr:2
+    v = dpp_add<0x114, 0xf>(v);  // row_shr:4
+    v = dpp_add<0x118, 0xf>(v);  // row_shr:8   -> lane 15 of each row = row total
+    v = dpp_add<0x142, 0xa>(v);  // row_bcast:15 into rows 1,3
+    v = dpp_add<0x143, 0xc>(v);  // row_bcast:31 into rows 2,3 -> lane 63 = wave total
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+__device__ __forceinline__ uint32_t sad16(const uint4 &a, const uint4 &b, uint32_t acc) {
+    acc = __builtin_amdgcn_sad_u8(a.x, b.x, acc);
+    acc = __builtin_amdgcn_sad_u8(a.y, b.y, acc);
+    acc = __builtin_amdgcn_sad_u8(a.z, b.z, acc);
+    acc = __builtin_amdgcn_sad_u8(a.w, b.w, acc);
+    return acc;
+}
+
+// Park per-frame totals in lanes and flush 64 of them with one coalesced store.
+struct Stash {
+    uint32_t v = 0;
+    __device__ __forceinline__ void put(int lane, int64_t t, uint32_t total) {
+        if (lane == (int)(t & 63)) v = total;
+    }
+    // call after frame t was put; flushes when the 64-slot group is full or t is the last
+    __device__ __forceinline__ void maybe_flush(int lane, int64_t t, int64_t t_lo, int64_t t_last,
+                                                uint32_t *__restrict__ row) {
+        if ((t & 63) == 63 || t == t_last) {
+            const int64_t tb = t & ~(int64_t)63;
+            const int64_t lt = tb + lane;
+            if (lt >= t_lo && lt <= t) row[lt] = v;
+        }
+    }
+};
+
+template <int U>
+__global__ __launch_bounds__(kBlock) void luma_sad_flat_kernel(
+    const uint8_t *__restrict__ luma, const uint8_t *__restrict__ prev0, int64_t T,
+    int64_t frame_stride, int64_t n16, int32_t n_strips, int32_t tc, int32_t t_first,
+    uint32_t *__restrict__ partial, int64_t Tpad) {
+    const int lane = threadIdx.x & 63;
+    const int strip = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    if (strip >= n_strips) return;  // wave-uniform
+    int64_t t0 = (int64_t)blockIdx.y * tc;
+    const int64_t t1 = (t0 + tc < T) ? t0 + tc : T;
+    if (t0 < t_first) t0 = t_first;
+    if (t0 >= t1) return;
+
+    int64_t idx[U];
+    bool ok[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int64_t i = ((int64_t)strip * U + u) * kWave + lane;
+        ok[u] = i < n16;
+        idx[u] = ok[u] ? i : 0;
+    }
+    const uint4 *pp = (t0 == 0) ? reinterpret_cast<const uint4 *>(prev0)
+                                : reinterpret_cast<const uint4 *>(luma + (t0 - 1) * frame_stride);
+    const uint4 *pc = reinterpret_cast<const uint4 *>(luma + t0 * frame_stride);
+    uint4 prev[U], cur[U], nxt[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) prev[u] = pp[idx[u]];
+#pragma unroll
+    for (int u = 0; u < U; ++u) cur[u] = pc[idx[u]];
+
+    uint32_t *row = partial + (int64_t)strip * Tpad;
+    Stash stash;
+    for (int64_t t = t0; t < t1; ++t) {
+        if (t + 1 < t1) {  // wave-uniform: keep the next frame's strip in flight
+            const uint4 *pn = reinterpret_cast<const uint4 *>(luma + (t + 1) * frame_stride);
+#pragma unroll
+            for (int u = 0; u < U; ++u) nxt[u] = pn[idx[u]];
+        } else {
+#pragma unroll
+            for (int u = 0; u < U; ++u) nxt[u] = cur[u];
+        }
+        uint32_t acc = 0;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t a = sad16(cur[u], prev[u], acc);
+            acc = ok[u] ? a : acc;
+        }
+        const uint32_t total = wave_sum_u32(acc);
+        stash.put(lane, t, total);
+        stash.maybe_flush(lane, t, t0, t1 - 1, row);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            prev[u] = cur[u];
+            cur[u] = nxt[u];
+        }
+    }
+}
+
+// 4-byte granules, arbitrary row stride / alignment.  granule g -> row g / gpr, x = 4*(g % gpr)
+__device__ __forceinline__ uint32_t load_granule(const uint8_t *p, int nb) {
+    uint32_t v = 0;
+    if (nb == 4) {
+        __builtin_memcpy(&v, p, 4);
+    } else {
+        for (int i = 0; i < nb; ++i) v |= (uint32_t)p[i] << (8 * i);
+    }
+    return v;
+}
+
+template <int U>
+__global__ __launch_bounds__(kBlock) void luma_sad_generic_kernel(
+    const uint8_t *__restrict__ luma, const uint8_t *__restrict__ prev0, int64_t T,
+    int64_t frame_stride, int64_t row_stride, int32_t H, int32_t W, int32_t gpr, int64_t n_gran,
+    int32_t n_strips, int32_t tc, int32_t t_first, uint32_t *__restrict__ partial, int64_t Tpad) {
+    const int lane = threadIdx.x & 63;
+    const int strip = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    if (strip >= n_strips) return;
+    int64_t t0 = (int64_t)blockIdx.y * tc;
+    const int64_t t1 = (t0 + tc < T) ? t0 + tc : T;
+    if (t0 < t_first) t0 = t_first;
+    if (t0 >= t1) return;
+
+    int64_t off[U], off0[U];
+    int nb[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int64_t g = ((int64_t)strip * U + u) * kWave + lane;
+        if (g < n_gran) {
+            const int64_t y = g / gpr;
+            const int32_t x = (int32_t)(g - y * gpr) * 4;
+            nb[u] = (W - x < 4) ? (W - x) : 4;
+            off[u] = y * row_stride + x;
+            off0[u] = y * (int64_t)W + x;  // prev0 is tightly packed
+        } else {
+            nb[u] = 0;
+            off[u] = 0;
+            off0[u] = 0;
+        }
+    }
+    uint32_t prev[U], cur[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+        prev[u] = (t0 == 0) ? load_granule(prev0 + off0[u], nb[u])
+                            : load_granule(luma + (t0 - 1) * frame_stride + off[u], nb[u]);
+    uint32_t *row = partial + (int64_t)strip * Tpad;
+    Stash stash;
+    for (int64_t t = t0; t < t1; ++t) {
+        const uint8_t *pc = luma + t * frame_stride;
+        uint32_t acc = 0;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            cur[u] = load_granule(pc + off[u], nb[u]);
+            acc = __builtin_amdgcn_sad_u8(cur[u], prev[u], acc);
+            prev[u] = cur[u];
+        }
+        const uint32_t total = wave_sum_u32(acc);
+        stash.put(lane, t, total);
+        stash.maybe_flush(lane, t, t0, t1 - 1, row);
+    }
+}
+
+// ---- get_scene_score epilogue (f_select.c): same operation order, true divisions ----
+struct SelectParams {
+    double count;      // (double)(W*H)
+    double depth_div;  // (double)(1ULL << (bitdepth-8))
+    double threshold;
+    double prev_mafd_in;
+};
+
+__device__ __forceinline__ double mafd_of(uint64_t sad, const SelectParams &p) {
+    return (double)sad / p.count / p.depth_div;
+}
+
+__device__ __forceinline__ void scene_epilogue(uint64_t sad, bool first, double prev_mafd,
+                                               const SelectParams &p, double &mafd, double &score,
+                                               uint8_t &sel) {
+    if (first) {
+        mafd = 0.0;
+        score = 0.0;
+        sel = 0;
+        return;
+    }
+    mafd = mafd_of(sad, p);
+    const double diff = fabs(mafd - prev_mafd);
+    const double m = (mafd > diff) ? diff : mafd;  // FFMIN
+    float f = (float)(m / 100.);
+    f = (f < 0.0f) ? 0.0f : ((f > 1.0f) ? 1.0f : f);  // av_clipf
+    score = (double)f;
+    sel = (score > p.threshold) ? 1 : 0;
+}
+
+constexpr int kFinT = 64;   // frames per finalize block
+constexpr int kFinG = 16;   // strip groups per finalize block
+
+// sum partial[s][t] over strips, then (optionally) the epilogue.  t_first = first scored frame
+// (1 when the batch starts a stream, 0 when a previous frame was supplied).
+__global__ __launch_bounds__(kFinT *kFinG) void scene_finalize_kernel(
+    const uint32_t *__restrict__ partial, int32_t n_strips, int64_t Tpad, int64_t T,
+    int32_t t_first, SelectParams sp, uint64_t *__restrict__ sad_out, double *__restrict__ mafd_out,
+    double *__restrict__ score_out, uint8_t *__restrict__ sel_out) {
+    __shared__ uint64_t red[kFinG][kFinT + 1];
+    const int tl = threadIdx.x & (kFinT - 1);
+    const int sg = threadIdx.x / kFinT;
+    const int64_t bt = (int64_t)blockIdx.x * kFinT;
+    const int64_t t = bt + tl;
+    uint64_t acc = 0, halo = 0;
+    if (t < T && t >= t_first)
+        for (int s = sg; s < n_strips; s += kFinG) acc += partial[(int64_t)s * Tpad + t];
+    if (tl == 0 && bt - 1 >= t_first)
+        for (int s = sg; s < n_strips; s += kFinG) halo += partial[(int64_t)s * Tpad + bt - 1];
+    red[sg][tl] = acc;
+    if (tl == 0) red[sg][kFinT] = halo;
+    __syncthreads();
+    if (threadIdx.x <= kFinT) {
+        uint64_t s = 0;
+#pragma unroll
+        for (int g = 0; g < kFinG; ++g) s += red[g][threadIdx.x];
+        red[0][threadIdx.x] = s;
+    }
+    __syncthreads();
+    if (sg == 0 && t < T) {
+        const uint64_t sad = red[0][tl];
+        if (sad_out) sad_out[t] = sad;
+        if (sel_out || score_out || mafd_out) {
+            const bool first = t < t_first;
+            double prev_mafd = sp.prev_mafd_in;
+            if (t - 1 >= t_first) prev_mafd = mafd_of(tl ? red[0][tl - 1] : red[0][kFinT], sp);
+            double mafd, score;
+            uint8_t sel;
+            scene_epilogue(sad, first, prev_mafd, sp, mafd, score, sel);
+            if (mafd_out) mafd_out[t] = mafd;
+            if (score_out) score_out[t] = score;
+            if (sel_out) sel_out[t] = sel;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void scene_select_kernel(const uint64_t *__restrict__ sad,
+                                                           int64_t T, int32_t have_prev,
+                                                           SelectParams sp,
+                                                           uint8_t *__restrict__ sel_out,
+                                                           double *__restrict__ score_out,
+                                                           double *__restrict__ mafd_out) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= T) return;
+    const int64_t t_first = have_prev ? 0 : 1;
+    double prev_mafd = sp.prev_mafd_in;
+    if (t - 1 >= t_first) prev_mafd = mafd_of(sad[t - 1], sp);
+    double mafd, score;
+    uint8_t sel;
+    scene_epilogue(sad[t], t < t_first, prev_mafd, sp, mafd, score, sel);
+    sel_out[t] = sel;
+    if (score_out) score_out[t] = score;
+    if (mafd_out) mafd_out[t] = mafd;
+}
+
+// ---------------------------------------------------------------- host side
+struct Plan {
+    bool flat;
+    int U;
+    int tc;
+    int64_t n16;      // flat: 16-byte chunks per frame
+    int64_t n_gran;   // generic: 4-byte granules per frame
+    int32_t gpr;
+    int32_t n_strips;
+    int64_t Tpad;
+    int32_t tail;     // flat: bytes of H*W not covered by 16-byte chunks (always 0 here)
+};
+
+constexpr int kGenericU = 8;
+
+bool flat_ok(const void *p, int64_t fs, int64_t rs, int32_t H, int32_t W) {
+    return rs == W && ((int64_t)H * W) % 16 == 0 && fs % 16 == 0 &&
+           (reinterpret_cast<uintptr_t>(p) % 16) == 0;
+}
+
+Plan make_plan(bool flat, int64_t T, int32_t H, int32_t W) {
+    Plan p{};
+    p.flat = flat;
+    p.tc = g_tune.tc;
+    p.Tpad = tvz::round_up(T > 0 ? T : 1, 64);
+    if (flat) {
+        p.U = g_tune.U;
+        p.n16 = (int64_t)H * W / 16;
+        p.n_strips = (int32_t)tvz::ceil_div(p.n16, (int64_t)kWave * p.U);
+    } else {
+        p.U = kGenericU;
+        p.gpr = (W + 3) / 4;
+        p.n_gran = (int64_t)H * p.gpr;
+        p.n_strips = (int32_t)tvz::ceil_div(p.n_gran, (int64_t)kWave * p.U);
+    }
+    return p;
+}
+
+size_t plan_bytes(const Plan &p) { return (size_t)p.n_strips * (size_t)p.Tpad * sizeof(uint32_t); }
+
+int check_dims(int64_t T, int32_t H, int32_t W) {
+    TVZ_REQUIRE(T >= 0, "T must be >= 0 (got %lld)", (long long)T);
+    TVZ_REQUIRE(H > 0 && W > 0, "H and W must be positive (got %d x %d)", H, W);
+    if ((int64_t)H * W > (int64_t)1 << 31)
+        return tvz::fail(TVZ_ERR_UNSUPPORTED, "frame of %d x %d exceeds 2^31 pixels", H, W);
+    return TVZ_OK;
+}
+
+int launch_sad(const uint8_t *d_luma, const uint8_t *d_prev0, int64_t T, int32_t H, int32_t W,
+               int64_t fs, int64_t rs, const Plan &p, uint32_t *partial, hipStream_t st) {
+    const int32_t t_first = d_prev0 ? 0 : 1;
+    if (T <= t_first) return TVZ_OK;
+    dim3 grid((unsigned)tvz::ceil_div(p.n_strips, kWavesPerBlock), (unsigned)tvz::ceil_div(T, p.tc));
+    if (grid.y > 65535u)
+        return tvz::fail(TVZ_ERR_UNSUPPORTED, "batch of %lld frames needs more than 65535 time chunks",
+                         (long long)T);
+    if (p.flat) {
+#define TVZ_FLAT(UU)                                                                            \
+    hipLaunchKernelGGL(luma_sad_flat_kernel<UU>, grid, dim3(kBlock), 0, st, d_luma, d_prev0, T, \
+                       fs, p.n16, p.n_strips, p.tc, t_first, partial, p.Tpad)
+        switch (p.U) {
+            case 1: TVZ_FLAT(1); break;
+            case 2: TVZ_FLAT(2); break;
+            case 4: TVZ_FLAT(4); break;
+            case 8: TVZ_FLAT(8); break;
+            default: return tvz::fail(TVZ_ERR_INVALID, "unsupported U=%d", p.U);
+        }
+#undef TVZ_FLAT
+    } else {
+        hipLaunchKernelGGL(luma_sad_generic_kernel<kGenericU>, grid, dim3(kBlock), 0, st, d_luma,
+                           d_prev0, T, fs, rs, H, W, p.gpr, p.n_gran, p.n_strips, p.tc, t_first,
+                           partial, p.Tpad);
+    }
+    TVZ_HIP(hipGetLastError());
+    return TVZ_OK;
+}
+
+SelectParams make_sp(int32_t H, int32_t W, int32_t bitdepth, double thr, double prev_mafd) {
+    SelectParams sp;
+    sp.count = (double)((uint64_t)W * (uint64_t)H);
+    sp.depth_div = (double)(1ULL << (bitdepth - 8));
+    sp.threshold = thr;
+    sp.prev_mafd_in = prev_mafd;
+    return sp;
+}
+
+}  // namespace
+
+// Not part of the stable ABI: kernel-shape knobs for A/B runs inside one process.
+TVZ_EXPORT int tvz_scene_set_tuning(int U, int tc) {
+    TVZ_REQUIRE(U == 1 || U == 2 || U == 4 || U == 8, "U must be 1, 2, 4 or 8");
+    TVZ_REQUIRE(tc >= 64 && tc % 64 == 0, "tc must be a positive multiple of 64");
+    g_tune.U = U;
+    g_tune.tc = tc;
+    return TVZ_OK;
+}
+
+TVZ_EXPORT size_t tvz_scene_workspace_bytes(int64_t T, int32_t H, int32_t W) {
+    if (T < 0 || H <= 0 || W <= 0) return 0;
+    const size_t a = plan_bytes(make_plan(true, T, H, W));
+    const size_t b = plan_bytes(make_plan(false, T, H, W));
+    return (a > b ? a : b) + 256;
+}
+
+TVZ_EXPORT int tvz_scene_scores_u8(const uint8_t *d_luma, int64_t T, int32_t H, int32_t W,
+                                   int64_t frame_stride_bytes, int64_t row_stride_bytes,
+                                   const uint8_t *d_prev_frame, double prev_mafd_in,
+                                   int32_t bitdepth, double threshold, uint64_t *d_sad_out,
+                                   double *d_mafd, double *d_score, uint8_t *d_selected,
+                                   void *d_workspace, size_t workspace_bytes, void *hip_stream) {
+    if (int rc = check_dims(T, H, W)) return rc;
+    if (T == 0) return TVZ_OK;
+    TVZ_REQUIRE(d_luma != nullptr, "d_luma is NULL");
+    TVZ_REQUIRE(row_stride_bytes >= W, "row stride %lld < W %d", (long long)row_stride_bytes, W);
+    TVZ_REQUIRE(frame_stride_bytes >= (int64_t)(H - 1) * row_stride_bytes + W || T == 1,
+                "frame stride %lld smaller than a plane", (long long)frame_stride_bytes);
+    TVZ_REQUIRE(bitdepth == 8, "only 8-bit luma is supported (bitdepth=%d)", bitdepth);
+    TVZ_REQUIRE(d_sad_out || d_selected || d_score || d_mafd, "nothing to compute: every output is NULL");
+    TVZ_REQUIRE(d_workspace != nullptr, "d_workspace is NULL");
+    hipStream_t st = reinterpret_cast<hipStream_t>(hip_stream);
+    bool flat = flat_ok(d_luma, frame_stride_bytes, row_stride_bytes, H, W);
+    if (d_prev_frame && (reinterpret_cast<uintptr_t>(d_prev_frame) % 16) != 0) flat = false;
+    const Plan p = make_plan(flat, T, H, W);
+    uintptr_t ws = (reinterpret_cast<uintptr_t>(d_workspace) + 255) & ~(uintptr_t)255;
+    const size_t lost = ws - reinterpret_cast<uintptr_t>(d_workspace);
+    if (workspace_bytes < lost + plan_bytes(p))
+        return tvz::fail(TVZ_ERR_WORKSPACE, "workspace of %zu bytes, need %zu", workspace_bytes,
+                         lost + plan_bytes(p));
+    uint32_t *partial = reinterpret_cast<uint32_t *>(ws);
+    if (int rc = launch_sad(d_luma, d_prev_frame, T, H, W, frame_stride_bytes, row_stride_bytes, p,
+                            partial, st))
+        return rc;
+    const SelectParams sp = make_sp(H, W, bitdepth, threshold, prev_mafd_in);
+    hipLaunchKernelGGL(scene_finalize_kernel, dim3((unsigned)tvz::ceil_div(T, kFinT)),
+                       dim3(kFinT * kFinG), 0, st, partial, p.n_strips, p.Tpad, T,
+                       d_prev_frame ? 0 : 1, sp, d_sad_out, d_mafd, d_score, d_selected);
+    TVZ_HIP(hipGetLastError());
+    return TVZ_OK;
+}
+
+TVZ_EXPORT int tvz_luma_sad_u8(const uint8_t *d_luma, int64_t T, int32_t H, int32_t W,
+                               int64_t frame_stride_bytes, int64_t row_stride_bytes,
+                               uint64_t *d_sad_out, void *d_workspace, size_t workspace_bytes,
+                               void *hip_stream) {
+    TVZ_REQUIRE(d_sad_out != nullptr || T == 0, "d_sad_out is NULL");
+    return tvz_scene_scores_u8(d_luma, T, H, W, frame_stride_bytes, row_stride_bytes, nullptr, 0.0,
+                               8, 0.0, d_sad_out, nullptr, nullptr, nullptr, d_workspace,
+                               workspace_bytes, hip_stream);
+}
+
+TVZ_EXPORT int tvz_scene_select(const uint64_t *d_sad, int64_t T, int32_t H, int32_t W,
+                                int32_t bitdepth, double threshold, double prev_mafd_in,
+                                int32_t have_prev, uint8_t *d_selected, double *d_score,
+                                double *d_mafd, void *hip_stream) {
+    if (int rc = check_dims(T, H, W)) return rc;
+    if (T == 0) return TVZ_OK;
+    TVZ_REQUIRE(d_sad && d_selected, "d_sad / d_selected is NULL");
+    TVZ_REQUIRE(bitdepth >= 8 && bitdepth <= 16, "bitdepth %d out of range", bitdepth);
+    const SelectParams sp = make_sp(H, W, bitdepth, threshold, prev_mafd_in);
+    hipLaunchKernelGGL(scene_select_kernel, dim3((unsigned)tvz::ceil_div(T, 256)), dim3(256), 0,
+                       reinterpret_cast<hipStream_t>(hip_stream), d_sad, T, have_prev, sp,
+                       d_selected, d_score, d_mafd);
+    TVZ_HIP(hipGetLastError());
+    return TVZ_OK;
+}
