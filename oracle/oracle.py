@@ -41,7 +41,7 @@ def build(force: bool = False) -> str:
     src = os.path.join(_HERE, "tvz_oracle.c")
     if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
         subprocess.check_call(
-            ["gcc", "-O2", "-fPIC", "-std=c11", "-fvisibility=hidden", "-shared",
+            ["gcc", "-O3", "-fPIC", "-std=c11", "-fvisibility=hidden", "-shared",
              "-o", _SO, src, "-lm"])
     return _SO
 

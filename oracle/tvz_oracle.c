@@ -43,7 +43,7 @@
  *      policies are restated; the parsed double (inspector/app.py:230) is the
  *      fingerprint element.  PARITY: UNPINNED (same reason as (3)).
  *
- * Build: oracle/Makefile  ->  oracle/libtvz_oracle.so   (plain C, gcc -O2)
+ * Build: oracle/Makefile  ->  oracle/libtvz_oracle.so   (plain C, gcc -O3)
  */
 #include <math.h>
 #include <stdint.h>

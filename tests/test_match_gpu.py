@@ -1,0 +1,235 @@
+"""GPU parity: HIP corpus matcher (through the C ABI) vs the oracle and the golden fixtures
+generated from the reference's own db.find_duplicates (bit-exact: integer/index work)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle
+from tvidz_amd import _lib, corpus as tc, synth
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+NEVER = tc.KTH_NEVER
+
+
+def _load(golden_dir, name):
+    with open(os.path.join(golden_dir, name)) as f:
+        return json.load(f)
+
+
+def _rows(corpus):
+    return [(int(v), [float("nan") if x is None else float(x) for x in t]) for v, t in corpus]
+
+
+@pytest.fixture(scope="module")
+def dc():
+    c = tc.DeviceCorpus(0)
+    yield c
+    c.close()
+
+
+def test_reference_kat_test_app_66_83(dc):
+    dc.upload([(1, [1.0, 2.0, 3.0, 4.0, 5.0]), (2, [10.0, 20.0, 30.0, 40.0, 50.0])])
+    dups = dc.find_duplicates([10.0, 20.0, 30.0, 40.0, 50.0], min_match=5)
+    assert (1, 0) not in dups and (2, 5) in dups
+    dc.upsert(3, [1.0, 2.0, 3.0, 4.0, 5.0])
+    dups = dc.find_duplicates([1.0, 2.0, 3.0, 4.0, 5.0], min_match=5)
+    assert (1, 5) in dups and (3, 5) in dups and len(dups) == 2
+
+
+def test_golden_kat(dc, golden_dir):
+    g = _load(golden_dir, "match_kat.json")
+    for case in g["cases"] + [g["nan_case"]]:
+        dc.upload(_rows(case["corpus"]))
+        q = [float("nan") if x is None else x for x in case["query"]]
+        got = dc.find_duplicates(q, case["min_match"])
+        assert got == [tuple(e) for e in case["expected"]], case["name"]
+
+
+def test_golden_random(dc, golden_dir):
+    g = _load(golden_dir, "match_random.json")
+    last = None
+    for case in g["cases"]:
+        if case["corpus_ref"] != last:
+            dc.upload(_rows(g["corpora"][str(case["corpus_ref"])]))
+            last = case["corpus_ref"]
+        got = dc.find_duplicates(case["query"], case["min_match"])
+        assert got == [tuple(e) for e in case["expected"]], case["name"]
+
+
+def test_golden_streaming_verdicts(dc, golden_dir):
+    """One call with kth replaces the per-prefix loop of app.py:231-255."""
+    g = _load(golden_dir, "match_streaming.json")
+    for case in g["cases"]:
+        dc.upload(_rows(case["corpus"]))
+        dedup = []
+        for ts in case["stream"]:
+            if not dedup or ts != dedup[-1]:
+                dedup.append(ts)
+        hits = dc.find_duplicates(dedup, case["min_match"], exclude_id=case["self_id"], with_kth=True)
+        assert all(v != case["self_id"] for v, _, _ in hits)
+        if not hits:
+            assert case["dup_ids"] == [] and case["scene_timestamps"] == dedup
+            continue
+        kstar = min(k for _, _, k in hits)
+        assert sorted(v for v, _, k in hits if k == kstar) == case["dup_ids"], case["name"]
+        assert dedup[:kstar + 1] == case["scene_timestamps"], case["name"]
+        # and the prefix query at k* returns exactly the reference's (id, count) pairs
+        pref = dc.find_duplicates(dedup[:kstar + 1], case["min_match"], exclude_id=case["self_id"])
+        assert pref == [tuple(e) for e in case["dups"]]
+
+
+def _check_batch(dc, ids, offs, keys, queries, min_match, excl=None, cap=None):
+    d_q, d_off, max_len = tc.pack_queries(queries, DEV)
+    C = len(ids)
+    cap = cap or max(C, 1)
+    d_ex = torch.tensor(excl, dtype=torch.int32, device=DEV) if excl is not None else None
+    hits, n = dc.match(d_q, d_off, max_len, min_match, cap, d_exclude_ids=d_ex)
+    torch.cuda.synchronize()
+    hits, n = hits.cpu().numpy(), n.cpu().numpy()
+    for qi, q in enumerate(queries):
+        cnt, kth = oracle.match_kth_csr(np.asarray(q, dtype=np.float64), offs, keys, min_match)
+        exp = sorted((int(ids[c]), int(cnt[c]), int(kth[c])) for c in range(C)
+                     if cnt[c] >= min_match and (excl is None or ids[c] != excl[qi]))
+        assert n[qi] == len(exp), (qi, n[qi], len(exp))
+        got = sorted(tuple(int(x) for x in h) for h in hits[qi, :min(n[qi], cap)])
+        assert got == exp[:len(got)] if n[qi] > cap else got == exp
+    return hits, n
+
+
+@pytest.mark.parametrize("C,mean_len,Q,mm", [(300, 40, 9, 2), (2000, 200, 16, 2), (500, 200, 5, 1),
+                                             (64, 12, 7, 3), (1000, 200, 4, 5), (17, 5, 3, 0)])
+def test_batched_match_vs_oracle(dc, C, mean_len, Q, mm):
+    ids, offs, keys = synth.synth_timestamp_corpus(C, seed=C + mm, mean_len=mean_len, dup_frac=0.05,
+                                                   frag_frac=0.05)
+    dc.upload_csr(ids, offs, keys)
+    queries = synth.synth_queries(ids, offs, keys, Q, seed=Q, mean_len=mean_len)
+    queries[0] = np.concatenate([queries[0], queries[0][:7]])        # multiplicity
+    if Q > 2:
+        queries[2] = np.zeros(0)                                      # empty query
+    _check_batch(dc, ids, offs, keys, queries, mm)
+    excl = [int(ids[(7 * i) % C]) for i in range(Q)]
+    _check_batch(dc, ids, offs, keys, queries, mm, excl=excl)
+
+
+def test_ragged_rows_and_long_queries(dc):
+    rng = np.random.default_rng(9)
+    rows = []
+    for v in range(200):
+        L = int(rng.choice([0, 1, 2, 3, 15, 16, 17, 31, 32, 33, 64, 257, 1000]))
+        rows.append((v + 10, np.round(rng.uniform(0, 500, L), 2).tolist()))
+    dc.upload(rows)
+    ids, offs, keys = tc.rows_to_csr(rows)
+    queries = [np.round(rng.uniform(0, 500, n), 2) for n in (1, 16, 17, 300, 1500, 4096)]
+    for mm in (1, 2, 4):
+        _check_batch(dc, ids, offs, keys, queries, mm)
+
+
+def test_query_too_long_is_rejected(dc):
+    dc.upload([(1, [1.0])])
+    with pytest.raises(RuntimeError, match="exceeds the supported"):
+        dc.find_duplicates(np.arange(5000, dtype=np.float64), 1)
+
+
+def test_hit_list_overflow_reports_true_count(dc):
+    ids, offs, keys = synth.synth_timestamp_corpus(400, seed=2, mean_len=30)
+    dc.upload_csr(ids, offs, keys)
+    d_q, d_off, max_len = tc.pack_queries([keys[:60]], DEV)
+    hits, n = dc.match(d_q, d_off, max_len, 0, cap=10)   # min_match 0: every row is a hit
+    torch.cuda.synchronize()
+    assert int(n[0]) == 400
+    assert (hits[0, :, 0] >= 1).all()
+
+
+def test_upsert_replaces_first_row_and_compacts(dc):
+    dc.upload([(1, [1.0, 2.0]), (2, [3.0, 4.0]), (1, [9.0])])     # duplicate video_id rows allowed
+    assert dc.find_duplicates([9.0, 1.0], 1) == [(1, 1), (1, 1)]
+    dc.upsert(1, [5.0, 6.0, 7.0])                                    # replaces the FIRST row of id 1
+    assert dc.find_duplicates([5.0, 6.0, 9.0], 1) == [(1, 1), (1, 2)]
+    prefix = []
+    for i in range(3000):                                            # growing prefix, as app.py:234
+        prefix.append(100.0 + i)
+        if i % 50 == 0:
+            dc.upsert(7, prefix)
+    dc.upsert(7, prefix)
+    n_rows, n_keys, arena = dc.stats()
+    assert n_rows == 4 and n_keys == 3 + 2 + 1 + 3000
+    assert arena < 4 * n_keys + 8192                                # dead prefixes were collected
+    assert dc.find_duplicates(prefix[-3:], 3) == [(7, 3)]
+    dc.clear()
+    assert dc.stats()[0] == 0 and dc.find_duplicates([1.0], 0) == []
+
+
+def test_topk_order_and_padding(dc):
+    ids, offs, keys = synth.synth_timestamp_corpus(3000, seed=4, mean_len=60, dup_frac=0.05)
+    dc.upload_csr(ids, offs, keys)
+    queries = synth.synth_queries(ids, offs, keys, 6, seed=3, mean_len=60)
+    d_q, d_off, max_len = tc.pack_queries(queries, DEV)
+    for cap in (3000, 40):
+        hits, n = dc.match(d_q, d_off, max_len, 1, cap)
+        for k in (1, 8, 64):
+            top = tc.topk(hits, n, k).cpu().numpy()
+            hh, nn = hits.cpu().numpy(), n.cpu().numpy()
+            for qi in range(len(queries)):
+                lst = [tuple(int(x) for x in h) for h in hh[qi, :min(nn[qi], cap)]]
+                exp = sorted(lst, key=lambda h: (h[2], h[0], h[1]))[:k]
+                exp += [(-1, 0, NEVER)] * (k - len(exp))
+                assert [tuple(int(x) for x in r) for r in top[qi]] == exp
+
+
+def test_topk_merges_gathered_shards(dc):
+    rng = np.random.default_rng(1)
+    R, Q, k = 4, 5, 8
+    lists = np.full((R, Q, k, 3), 0, dtype=np.int32)
+    for r in range(R):
+        for q in range(Q):
+            m = int(rng.integers(0, k + 1))
+            ent = sorted(((int(rng.integers(0, 6)), int(rng.integers(1, 10**6)), int(rng.integers(1, 9)))
+                          for _ in range(m)))
+            for j in range(k):
+                lists[r, q, j] = (ent[j][1], ent[j][2], ent[j][0]) if j < m else (-1, 0, NEVER)
+    out = tc.topk(torch.from_numpy(lists).to(DEV), None, k).cpu().numpy()
+    for q in range(Q):
+        flat = [tuple(int(x) for x in e) for r in range(R) for e in lists[r, q] if e[0] >= 0]
+        exp = sorted(flat, key=lambda h: (h[2], h[0], h[1]))[:k]
+        exp += [(-1, 0, NEVER)] * (k - len(exp))
+        assert [tuple(int(x) for x in r) for r in out[q]] == exp
+
+
+def test_concurrent_find_duplicates_threads(dc):
+    import threading
+    ids, offs, keys = synth.synth_timestamp_corpus(1500, seed=8, mean_len=50, dup_frac=0.05)
+    dc.upload_csr(ids, offs, keys)
+    queries = synth.synth_queries(ids, offs, keys, 8, seed=5, mean_len=50)
+    exp = []
+    for q in queries:
+        cnt, kth = oracle.match_kth_csr(q, offs, keys, 2)
+        exp.append(sorted((int(ids[c]), int(cnt[c])) for c in range(len(ids)) if cnt[c] >= 2))
+    errs = []
+
+    def work(i):
+        try:
+            for _ in range(20):
+                assert dc.find_duplicates(queries[i], 2) == exp[i]
+        except Exception as e:  # pragma: no cover
+            errs.append(e)
+    th = [threading.Thread(target=work, args=(i,)) for i in range(8)]
+    [t.start() for t in th]; [t.join() for t in th]
+    assert not errs
+
+
+def test_config3_size_round_trip_property(dc):
+    """BASELINE config 3 size (1 query vs 5k videos x ~200 cuts): every row is found by its own
+    timestamps with count == len(row), kth == min_match-1 (size-independent property)."""
+    ids, offs, keys = synth.synth_timestamp_corpus(5000, seed=synth.CORPUS_SEED)
+    dc.upload_csr(ids, offs, keys)
+    for c in (0, 17, 4999):
+        row = keys[offs[c]:offs[c + 1]]
+        hits = dc.find_duplicates(row, min_match=len(row), with_kth=True)
+        assert (int(ids[c]), len(row), len(row) - 1) in hits
+        cnt, kth = oracle.match_kth_csr(row, offs, keys, 2)
+        exp = sorted((int(ids[i]), int(cnt[i]), int(kth[i])) for i in range(5000) if cnt[i] >= 2)
+        assert dc.find_duplicates(row, 2, with_kth=True) == exp

@@ -1,0 +1,186 @@
+"""GPU parity: HIP scene-cut kernels (through the C ABI) vs the CPU oracle.
+
+Integer SAD is compared bit-exactly; mafd/score are IEEE double/float32 operations in the same
+order as the oracle, so they are compared bit-exactly too (tolerance 0).  The oracle's scene
+half is a restatement of FFmpeg's algorithm: PARITY UNPINNED against ffmpeg itself (no binary,
+no reference fixture) — see oracle/tvz_oracle.c.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle
+from tvidz_amd import _lib, scene, synth
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _oracle_all(frames_np, threshold=0.3):
+    T, H, W = frames_np.shape
+    sad = oracle.luma_sad(frames_np)
+    sel, score, mafd, _ = oracle.scene_select(sad, H, W, threshold)
+    return sad, sel, score, mafd
+
+
+def _gpu_all(frames, threshold=0.3, max_batch=None):
+    T, H, W = frames.shape
+    sc = scene.SceneScorer(H, W, max_batch or max(T, 1), DEV, threshold)
+    sad, mafd, score, sel = sc.score_batch(frames)
+    torch.cuda.synchronize()
+    return (sad.cpu().numpy().view(np.uint64), sel.cpu().numpy(), score.cpu().numpy(),
+            mafd.cpu().numpy())
+
+
+@pytest.mark.parametrize("shape", [(40, 480, 854), (33, 1080, 1920), (3, 16, 64), (2, 1, 16),
+                                   (130, 64, 64), (257, 48, 80), (5, 2160, 3840)])
+def test_flat_path_random_frames_bit_exact(shape):
+    T, H, W = shape
+    g = torch.Generator(device=DEV); g.manual_seed(T * 7 + W)
+    frames = torch.randint(0, 256, shape, dtype=torch.uint8, device=DEV, generator=g)
+    sad, sel, score, mafd = _gpu_all(frames)
+    o_sad, o_sel, o_score, o_mafd = _oracle_all(frames.cpu().numpy())
+    assert (sad == o_sad).all()
+    assert (mafd == o_mafd).all() and (score == o_score).all() and (sel == o_sel).all()
+
+
+@pytest.mark.parametrize("shape", [(9, 37, 53), (20, 480, 853), (4, 5, 3), (70, 33, 130), (3, 7, 1)])
+def test_generic_path_odd_sizes_bit_exact(shape):
+    T, H, W = shape
+    g = torch.Generator(device=DEV); g.manual_seed(W)
+    frames = torch.randint(0, 256, shape, dtype=torch.uint8, device=DEV, generator=g)
+    sad, sel, score, mafd = _gpu_all(frames)
+    o_sad, o_sel, o_score, o_mafd = _oracle_all(frames.cpu().numpy())
+    assert (sad == o_sad).all() and (score == o_score).all() and (sel == o_sel).all()
+
+
+def test_padded_rows_and_frames_take_generic_path():
+    T, H, W = 12, 30, 100
+    g = torch.Generator(device=DEV); g.manual_seed(3)
+    big = torch.randint(0, 256, (T, H + 5, W + 28), dtype=torch.uint8, device=DEV, generator=g)
+    view = big[:, 2:2 + H, 7:7 + W]          # unaligned base, padded rows and frames
+    assert not view.is_contiguous()
+    sad, sel, score, _ = _gpu_all(view)
+    o_sad, o_sel, o_score, _ = _oracle_all(view.cpu().numpy())
+    assert (sad == o_sad).all() and (score == o_score).all() and (sel == o_sel).all()
+
+
+def test_extremes_all_black_white_and_identical():
+    T, H, W = 6, 64, 128
+    frames = torch.zeros((T, H, W), dtype=torch.uint8, device=DEV)
+    frames[1] = 255; frames[3] = 255; frames[4] = 255
+    sad, sel, score, mafd = _gpu_all(frames)
+    assert sad.tolist() == [0, 255 * H * W, 255 * H * W, 255 * H * W, 0, 255 * H * W]
+    o_sad, o_sel, o_score, _ = _oracle_all(frames.cpu().numpy())
+    assert (sel == o_sel).all() and (score == o_score).all()
+    # back-to-back cuts: the second is suppressed by |mafd - prev_mafd| (f_select.c)
+    assert sel.tolist() == [0, 1, 0, 0, 0, 1]
+
+
+def test_empty_and_single_frame_batches():
+    sc = scene.SceneScorer(32, 32, 8, DEV)
+    sad, mafd, score, sel = sc.score_batch(torch.empty((0, 32, 32), dtype=torch.uint8, device=DEV))
+    assert sad.numel() == 0 and sel.numel() == 0
+    one = torch.randint(0, 256, (1, 32, 32), dtype=torch.uint8, device=DEV)
+    sad, mafd, score, sel = sc.score_batch(one, carry=False)
+    torch.cuda.synchronize()
+    assert sad.item() == 0 and score.item() == 0.0 and sel.item() == 0
+
+
+def test_synthetic_scenes_cuts_match_oracle_and_layout():
+    T, H, W = 900, 480, 854
+    frames, layout_cuts = synth.synth_luma(T, H, W, device=DEV, seed=synth.FRAME_SEED)
+    sad, sel, score, mafd = _gpu_all(frames)
+    o_sad, o_sel, o_score, o_mafd = _oracle_all(frames.cpu().numpy())
+    assert (sad == o_sad).all() and (sel == o_sel).all() and (score == o_score).all()
+    got = np.flatnonzero(sel).tolist()
+    # every selected frame is a scene boundary of the generator (or its flash frame)...
+    assert len(got) >= 3
+    # ...and every plain boundary that is not back-to-back with another is selected
+    for c in layout_cuts:
+        if (c - 1) not in layout_cuts and (c + 1) not in layout_cuts and c not in got:
+            # the fade scene's entry can be softened by its ramp; everything else must be a cut
+            assert o_mafd[c] <= 30.0 or abs(o_mafd[c] - o_mafd[c - 1]) <= 30.0
+
+
+def test_streaming_batches_equal_whole_stream():
+    T, H, W = 300, 120, 160
+    frames, _ = synth.synth_luma(T, H, W, device=DEV, seed=11, min_scene=10, max_scene=40)
+    whole = _gpu_all(frames)
+    sc = scene.SceneScorer(H, W, 64, DEV)
+    sads, sels, scores = [], [], []
+    for s in range(0, T, 50):   # batches that are not multiples of the kernel's time chunk
+        part = frames[s:s + 50]
+        sad, mafd, score, sel = sc.score_batch(part)
+        sc.remember_tail(part)
+        sads.append(sad.cpu().numpy().view(np.uint64).copy()); sels.append(sel.cpu().numpy().copy())
+        scores.append(score.cpu().numpy().copy())
+    assert (np.concatenate(sads) == whole[0]).all()
+    assert (np.concatenate(sels) == whole[1]).all()
+    assert (np.concatenate(scores) == whole[2]).all()
+
+
+def test_detect_scene_cuts_yields_reference_parser_values():
+    T, H, W = 240, 96, 128
+    frames, _ = synth.synth_luma(T, H, W, device=DEV, seed=5, min_scene=20, max_scene=50, adversarial=False)
+    got = list(scene.detect_scene_cuts(frames, time_base=(1, 30), batch=64))
+    o_sad, o_sel, _, _ = _oracle_all(frames.cpu().numpy())
+    idx = np.flatnonzero(o_sel).tolist()
+    assert [n for n, _ in got] == idx
+    for n, ts in got:
+        assert ts == oracle.pts_time_value(n, 1, 30, 0)
+        assert scene.parse_showinfo_line(
+            f"[Parsed_showinfo_1 @ 0x1] n:{len(idx):4d} pts:{n:7d} pts_time:{oracle.fmt_pts_time(n, 1, 30, 0):<7s} pos: 0") == ts
+
+
+def test_standalone_sad_and_select_entry_points():
+    T, H, W = 70, 64, 96
+    frames = torch.randint(0, 256, (T, H, W), dtype=torch.uint8, device=DEV)
+    sc = scene.SceneScorer(H, W, T, DEV)
+    sad = sc.luma_sad(frames).clone()
+    sel, score, mafd = scene.scene_select(sad, H, W, 0.3)
+    torch.cuda.synchronize()
+    o_sad, o_sel, o_score, o_mafd = _oracle_all(frames.cpu().numpy())
+    assert (sad.cpu().numpy().view(np.uint64) == o_sad).all()
+    assert (sel.cpu().numpy() == o_sel).all() and (score.cpu().numpy() == o_score).all()
+    assert (mafd.cpu().numpy() == o_mafd).all()
+
+
+def test_tuning_variants_give_identical_results():
+    lib = _lib.load()
+    T, H, W = 150, 270, 480
+    frames = torch.randint(0, 256, (T, H, W), dtype=torch.uint8, device=DEV)
+    o_sad, _, _, _ = _oracle_all(frames.cpu().numpy())
+    try:
+        for U in (1, 2, 4, 8):
+            for tc in (64, 128, 256):
+                _lib.check(lib.tvz_scene_set_tuning(U, tc))
+                sad, _, _, _ = _gpu_all(frames)
+                assert (sad == o_sad).all(), (U, tc)
+    finally:
+        _lib.check(lib.tvz_scene_set_tuning(4, 128))
+
+
+def test_bad_arguments_raise():
+    sc = scene.SceneScorer(32, 32, 4, DEV)
+    with pytest.raises(RuntimeError):
+        sc.score_batch(torch.zeros((5, 32, 32), dtype=torch.uint8, device=DEV))   # > max_batch
+    with pytest.raises(RuntimeError):
+        sc.score_batch(torch.zeros((2, 32, 32), dtype=torch.float32, device=DEV))
+    lib = _lib.load()
+    rc = lib.tvz_luma_sad_u8(None, 4, 32, 32, 1024, 32, None, None, 0, None)
+    assert rc != 0 and b"NULL" in lib.tvz_last_error()
+    with pytest.raises(RuntimeError, match="libtvz error"):
+        _lib.check(rc)
+
+
+def test_full_size_property_linearity_of_sad():
+    """BASELINE config size (1080p) property check without the oracle: SAD against a constant
+    shift is exactly shift * H * W, and sad(a,b) == sad(b,a)."""
+    H, W = 1080, 1920
+    base = torch.randint(10, 200, (1, H, W), dtype=torch.uint8, device=DEV)
+    frames = torch.cat([base, base + 7, base, base + 31, base + 31], dim=0)
+    sad, sel, score, mafd = _gpu_all(frames)
+    assert sad.tolist() == [0, 7 * H * W, 7 * H * W, 31 * H * W, 0]
+    assert mafd.tolist() == [0.0, 7.0, 7.0, 31.0, 0.0]
+    assert sel.tolist() == [0, 0, 0, 0, 0]   # |31-7| = 24 <= 30: not a cut

@@ -52,6 +52,18 @@ _lock = threading.Lock()
 _lib = None
 
 
+def _preload_torch_hip_runtime() -> None:
+    """One HIP runtime per process.  PyTorch-ROCm wheels bundle their own libamdhip64.so (SONAME
+    libamdhip64.so.7); libtvz.so NEEDs libamdhip64.so.7.  If libtvz.so were loaded first the loader
+    would take /opt/rocm's copy and torch would later map a SECOND runtime (its NEEDED name is
+    the unversioned file name, so no SONAME match), and launches through one of them fail with
+    "no ROCm-capable device".  Loading torch's copy first makes libtvz.so bind to it."""
+    import torch  # noqa: F401  (maps torch/lib/libamdhip64.so)
+    cand = os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        C.CDLL(cand, mode=C.RTLD_GLOBAL)
+
+
 def load() -> C.CDLL:
     """Load libtvz.so; RuntimeError if it was not built (python -m tvidz_amd.build)."""
     global _lib
@@ -63,6 +75,7 @@ def load() -> C.CDLL:
                 raise RuntimeError(
                     f"{SO_PATH} is missing: the HIP extension is not built and there is no CPU "
                     "fallback. Run `python -m tvidz_amd.build` (needs hipcc).")
+            _preload_torch_hip_runtime()
             lib = C.CDLL(SO_PATH)
             for name, (res, args) in SIGNATURES.items():
                 fn = getattr(lib, name)

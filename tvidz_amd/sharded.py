@@ -1,0 +1,100 @@
+"""Corpus match sharded over the GPUs of one node.
+
+The candidate axis shards naturally: rows are independent.  Each rank (one process per GPU)
+holds a contiguous range of the `video_timestamps` rows balanced by key count, queries are
+replicated (tiny), every rank runs the local match + per-shard top-k, and ONE all-gather of
+[Q, k] int32 triples (RCCL over xGMI; <= 768 B per query per rank, latency-bound) is followed by
+the same k-way merge on every rank.  There is no other collective on the data path.
+
+The reference has no counterpart (it scans one Postgres table in one Python process,
+inspector/db.py:83-91); the merged result is what its find_duplicates + the first-hit rule of
+inspector/app.py:235-255 would report, ordered by (kth, video_id).
+"""
+from __future__ import annotations
+
+from typing import Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+KTH_NEVER = 0x7FFFFFFF
+
+
+def shard_bounds(offsets: np.ndarray, world: int) -> np.ndarray:
+    """Row boundaries [world+1] of contiguous shards with ~equal key counts (not row counts)."""
+    offsets = np.asarray(offsets, dtype=np.int64)
+    C = offsets.size - 1
+    total = int(offsets[-1])
+    targets = (np.arange(world + 1, dtype=np.float64) * total / world)
+    b = np.searchsorted(offsets, targets, side="left").astype(np.int64)
+    b[0], b[-1] = 0, C
+    return np.maximum.accumulate(np.clip(b, 0, C))
+
+
+def shard_csr(ids: np.ndarray, offsets: np.ndarray, keys: np.ndarray, rank: int, world: int):
+    b = shard_bounds(offsets, world)
+    r0, r1 = int(b[rank]), int(b[rank + 1])
+    k0, k1 = int(offsets[r0]), int(offsets[r1])
+    return ids[r0:r1], offsets[r0:r1 + 1] - k0, keys[k0:k1]
+
+
+class HipBackend:
+    """The product backend: DeviceCorpus.match + tvz_topk on this rank's GPU."""
+
+    def __init__(self, corpus):
+        from . import corpus as tc
+        self._tc = tc
+        self.corpus = corpus
+
+    def match(self, d_q, d_off, max_len, min_match, cap, d_excl):
+        return self.corpus.match(d_q, d_off, max_len, min_match, cap, d_exclude_ids=d_excl)
+
+    def topk(self, lists, lists_n, k):
+        return self._tc.topk(lists, lists_n, k)
+
+
+class ShardedMatcher:
+    """rank-local shard + all-gather of per-shard top-k + identical merge on every rank."""
+
+    def __init__(self, backend, k: int = 64, cap: int = 1024, group=None):
+        self.backend = backend
+        self.k = int(k)
+        self.cap = max(int(cap), self.k)
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if self.world > 1 else 0
+
+    def match_topk(self, d_queries: torch.Tensor, d_q_offsets: torch.Tensor, max_query_len: int,
+                   min_match: int, d_exclude_ids: Optional[torch.Tensor] = None):
+        """-> (merged int32 [Q,k,3] of (video_id, count, kth), total_hits int32 [Q]) — identical on
+        every rank.  total_hits > k means the list was truncated to the k best."""
+        hits, n = self.backend.match(d_queries, d_q_offsets, max_query_len, min_match, self.cap,
+                                     d_exclude_ids)
+        local = self.backend.topk(hits, n, self.k)
+        if self.world == 1:
+            return local, n
+        Q = local.shape[0]
+        gathered = torch.empty((self.world, Q, self.k, 3), dtype=torch.int32, device=local.device)
+        dist.all_gather_into_tensor(gathered, local.contiguous(), group=self.group)
+        totals = n.clone()
+        dist.all_reduce(totals, op=dist.ReduceOp.SUM, group=self.group)
+        return self.backend.topk(gathered, None, self.k), totals
+
+
+def verdicts_from_topk(merged: np.ndarray):
+    """Per query: (k*, sorted dup ids) = rows whose kth is minimal (app.py:235-255 batch form),
+    or (None, []) when nothing reached min_match.  `truncated` is True when the tie set may
+    exceed k (caller should re-query with a larger k)."""
+    out = []
+    for rows in merged:
+        valid = rows[rows[:, 0] >= 0]
+        valid = valid[valid[:, 2] < KTH_NEVER]
+        if valid.shape[0] == 0:
+            out.append((None, [], False))
+            continue
+        kstar = int(valid[:, 2].min())
+        ids = sorted(int(v) for v in valid[valid[:, 2] == kstar][:, 0])
+        truncated = bool(rows[-1, 0] >= 0 and rows[-1, 2] == kstar)
+        out.append((kstar, ids, truncated))
+    return out
