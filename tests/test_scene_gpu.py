@@ -154,11 +154,12 @@ def test_tuning_variants_give_identical_results():
     try:
         for U in (1, 2, 4, 8):
             for tc in (64, 128, 256):
-                _lib.check(lib.tvz_scene_set_tuning(U, tc))
-                sad, _, _, _ = _gpu_all(frames)
-                assert (sad == o_sad).all(), (U, tc)
+                for nt in (0, 1):
+                    _lib.check(lib.tvz_scene_set_tuning(U, tc, nt))
+                    sad, _, _, _ = _gpu_all(frames)
+                    assert (sad == o_sad).all(), (U, tc, nt)
     finally:
-        _lib.check(lib.tvz_scene_set_tuning(4, 128))
+        _lib.check(lib.tvz_scene_set_tuning(0, 0, 1))
 
 
 def test_bad_arguments_raise():

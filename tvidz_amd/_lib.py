@@ -45,7 +45,7 @@ SIGNATURES = {
     "tvz_topk": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                            C.c_void_p, C.c_void_p]),
     # not part of the stable ABI (kernel-shape A/B knob)
-    "tvz_scene_set_tuning": (C.c_int, [C.c_int, C.c_int]),
+    "tvz_scene_set_tuning": (C.c_int, [C.c_int, C.c_int, C.c_int]),
 }
 
 _lock = threading.Lock()

@@ -26,8 +26,9 @@ constexpr int kBlock = 256;           // 4 waves
 constexpr int kWavesPerBlock = kBlock / kWave;
 
 struct Tuning {
-    int U = 4;     // 16-byte loads per lane per frame on the flat path (1,2,4,8)
-    int tc = 128;  // frames per time chunk (multiple of 64)
+    int U = 0;     // 16-byte loads per lane per frame on the flat path (1,2,4,8); 0 = auto
+    int tc = 0;    // frames per time chunk (multiple of 64); 0 = auto
+    int nt = 1;    // non-temporal loads on the flat path (+8..12 % on MI355X, profiles/r1_tune_scene.txt)
 };
 Tuning g_tune;
 
@@ -73,7 +74,19 @@ struct Stash {
     }
 };
 
-template <int U>
+template <bool NT>
+__device__ __forceinline__ uint4 load16(const uint4 *p) {
+    if constexpr (NT) {
+        // streamed once: non-temporal hint keeps the frames from displacing L2/MALL lines
+        using v4 = __attribute__((ext_vector_type(4))) unsigned int;
+        const v4 v = __builtin_nontemporal_load(reinterpret_cast<const v4 *>(p));
+        return make_uint4(v.x, v.y, v.z, v.w);
+    } else {
+        return *p;
+    }
+}
+
+template <int U, bool NT>
 __global__ __launch_bounds__(kBlock) void luma_sad_flat_kernel(
     const uint8_t *__restrict__ luma, const uint8_t *__restrict__ prev0, int64_t T,
     int64_t frame_stride, int64_t n16, int32_t n_strips, int32_t tc, int32_t t_first,
@@ -99,21 +112,13 @@ __global__ __launch_bounds__(kBlock) void luma_sad_flat_kernel(
     const uint4 *pc = reinterpret_cast<const uint4 *>(luma + t0 * frame_stride);
     uint4 prev[U], cur[U], nxt[U];
 #pragma unroll
-    for (int u = 0; u < U; ++u) prev[u] = pp[idx[u]];
+    for (int u = 0; u < U; ++u) prev[u] = load16<NT>(pp + idx[u]);
 #pragma unroll
-    for (int u = 0; u < U; ++u) cur[u] = pc[idx[u]];
+    for (int u = 0; u < U; ++u) cur[u] = load16<NT>(pc + idx[u]);
 
     uint32_t *row = partial + (int64_t)strip * Tpad;
     Stash stash;
-    for (int64_t t = t0; t < t1; ++t) {
-        if (t + 1 < t1) {  // wave-uniform: keep the next frame's strip in flight
-            const uint4 *pn = reinterpret_cast<const uint4 *>(luma + (t + 1) * frame_stride);
-#pragma unroll
-            for (int u = 0; u < U; ++u) nxt[u] = pn[idx[u]];
-        } else {
-#pragma unroll
-            for (int u = 0; u < U; ++u) nxt[u] = cur[u];
-        }
+    auto score = [&](int64_t t) {
         uint32_t acc = 0;
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -123,12 +128,21 @@ __global__ __launch_bounds__(kBlock) void luma_sad_flat_kernel(
         const uint32_t total = wave_sum_u32(acc);
         stash.put(lane, t, total);
         stash.maybe_flush(lane, t, t0, t1 - 1, row);
+    };
+    // steady state: the next frame's strip is always in flight while this one is reduced
+    // (no branch around the loads, so the compiler waits with a counted vmcnt, not vmcnt(0))
+    for (int64_t t = t0; t < t1 - 1; ++t) {
+        const uint4 *pn = reinterpret_cast<const uint4 *>(luma + (t + 1) * frame_stride);
+#pragma unroll
+        for (int u = 0; u < U; ++u) nxt[u] = load16<NT>(pn + idx[u]);
+        score(t);
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             prev[u] = cur[u];
             cur[u] = nxt[u];
         }
     }
+    score(t1 - 1);
 }
 
 // 4-byte granules, arbitrary row stride / alignment.  granule g -> row g / gpr, x = 4*(g % gpr)
@@ -309,14 +323,31 @@ bool flat_ok(const void *p, int64_t fs, int64_t rs, int32_t H, int32_t W) {
            (reinterpret_cast<uintptr_t>(p) % 16) == 0;
 }
 
+// Shape choice for the flat kernel: the widest strip / longest time chunk that still gives the
+// chip >= 16 waves per CU (U=8 runs at 4 waves per SIMD).  Big batches (10k x 1080p) get
+// U=8, tc=256 (6.8 TB/s measured); micro-batches fall back to narrower strips so that all 256
+// CUs have work.
+void auto_shape(int64_t T, int64_t n16, int &U, int &tc) {
+    static const int cand[][2] = {{8, 256}, {8, 128}, {8, 64}, {4, 64}, {2, 64}, {1, 64}};
+    const int64_t want = 256 * 16;
+    for (auto &c : cand) {
+        U = c[0];
+        tc = c[1];
+        if (tvz::ceil_div(n16, (int64_t)kWave * U) * tvz::ceil_div(T, tc) >= want) return;
+    }
+}
+
 Plan make_plan(bool flat, int64_t T, int32_t H, int32_t W) {
     Plan p{};
     p.flat = flat;
-    p.tc = g_tune.tc;
+    p.tc = g_tune.tc ? g_tune.tc : 128;
     p.Tpad = tvz::round_up(T > 0 ? T : 1, 64);
     if (flat) {
-        p.U = g_tune.U;
         p.n16 = (int64_t)H * W / 16;
+        int aU = 4, atc = 128;
+        auto_shape(T > 0 ? T : 1, p.n16, aU, atc);
+        p.U = g_tune.U ? g_tune.U : aU;
+        p.tc = g_tune.tc ? g_tune.tc : atc;
         p.n_strips = (int32_t)tvz::ceil_div(p.n16, (int64_t)kWave * p.U);
     } else {
         p.U = kGenericU;
@@ -346,9 +377,17 @@ int launch_sad(const uint8_t *d_luma, const uint8_t *d_prev0, int64_t T, int32_t
         return tvz::fail(TVZ_ERR_UNSUPPORTED, "batch of %lld frames needs more than 65535 time chunks",
                          (long long)T);
     if (p.flat) {
-#define TVZ_FLAT(UU)                                                                            \
-    hipLaunchKernelGGL(luma_sad_flat_kernel<UU>, grid, dim3(kBlock), 0, st, d_luma, d_prev0, T, \
-                       fs, p.n16, p.n_strips, p.tc, t_first, partial, p.Tpad)
+#define TVZ_FLAT(UU)                                                                           \
+    do {                                                                                       \
+        if (g_tune.nt)                                                                         \
+            hipLaunchKernelGGL((luma_sad_flat_kernel<UU, true>), grid, dim3(kBlock), 0, st,    \
+                               d_luma, d_prev0, T, fs, p.n16, p.n_strips, p.tc, t_first,       \
+                               partial, p.Tpad);                                               \
+        else                                                                                   \
+            hipLaunchKernelGGL((luma_sad_flat_kernel<UU, false>), grid, dim3(kBlock), 0, st,   \
+                               d_luma, d_prev0, T, fs, p.n16, p.n_strips, p.tc, t_first,       \
+                               partial, p.Tpad);                                               \
+    } while (0)
         switch (p.U) {
             case 1: TVZ_FLAT(1); break;
             case 2: TVZ_FLAT(2); break;
@@ -378,17 +417,19 @@ SelectParams make_sp(int32_t H, int32_t W, int32_t bitdepth, double thr, double 
 }  // namespace
 
 // Not part of the stable ABI: kernel-shape knobs for A/B runs inside one process.
-TVZ_EXPORT int tvz_scene_set_tuning(int U, int tc) {
-    TVZ_REQUIRE(U == 1 || U == 2 || U == 4 || U == 8, "U must be 1, 2, 4 or 8");
-    TVZ_REQUIRE(tc >= 64 && tc % 64 == 0, "tc must be a positive multiple of 64");
+TVZ_EXPORT int tvz_scene_set_tuning(int U, int tc, int nt) {
+    TVZ_REQUIRE(U == 0 || U == 1 || U == 2 || U == 4 || U == 8, "U must be 0 (auto), 1, 2, 4 or 8");
+    TVZ_REQUIRE(tc >= 0 && tc % 64 == 0, "tc must be 0 (auto) or a positive multiple of 64");
     g_tune.U = U;
     g_tune.tc = tc;
+    g_tune.nt = nt ? 1 : 0;
     return TVZ_OK;
 }
 
 TVZ_EXPORT size_t tvz_scene_workspace_bytes(int64_t T, int32_t H, int32_t W) {
     if (T < 0 || H <= 0 || W <= 0) return 0;
-    const size_t a = plan_bytes(make_plan(true, T, H, W));
+    // worst case over every shape the launcher may pick: U=1 strips on the flat path
+    const size_t a = (size_t)tvz::ceil_div((int64_t)H * W / 16 + 1, kWave) * (size_t)tvz::round_up(T > 0 ? T : 1, 64) * sizeof(uint32_t);
     const size_t b = plan_bytes(make_plan(false, T, H, W));
     return (a > b ? a : b) + 256;
 }
