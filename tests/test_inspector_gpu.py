@@ -1,0 +1,128 @@
+"""GPU end-to-end: Y4M clips -> feeder -> HIP scene kernels -> HIP corpus match -> verdicts,
+checked against the oracle's replay of the reference loop (inspector/app.py:228-255).
+BASELINE.json configs[0] shape: 10 s 480p30 clips, one a cut-shifted copy of the other."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle
+from tvidz_amd import db as tdb
+from tvidz_amd import feeder, inspector as insp, scene, synth
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+H, W, T = 480, 854, 300
+
+
+def _clip(seed, cut_frames):
+    """300 frames with cuts exactly at cut_frames (flat scenes + noise)."""
+    rng = np.random.default_rng(seed)
+    levels = [40, 120, 200, 75, 160, 230, 30, 110]
+    out = np.empty((T, H, W), dtype=np.uint8)
+    bounds = [0] + list(cut_frames) + [T]
+    base_rng = np.random.default_rng(99)
+    texture = base_rng.integers(-6, 7, size=(H, W))
+    for i in range(len(bounds) - 1):
+        for t in range(bounds[i], bounds[i + 1]):
+            out[t] = np.clip(levels[i] + texture + rng.integers(-2, 3, size=(H, W)), 0, 255)
+    return out
+
+
+def _oracle_cuts(luma, tb=(1, 30)):
+    sad = oracle.luma_sad(luma)
+    sel, _, _, _ = oracle.scene_select(sad, luma.shape[1], luma.shape[2], 0.3)
+    return [oracle.pts_time_value(int(i), tb[0], tb[1], 0) for i in np.flatnonzero(sel)]
+
+
+@pytest.fixture()
+def rig(tmp_path):
+    store = tdb.Store(f"sqlite:///{tmp_path}/tvidz.db", device=0)   # file DB: one connection per thread
+    files = {}
+
+    def source(bucket, key, filename, unique_id):
+        return feeder.Y4MReader(files[key]), None
+
+    ins = insp.Inspector(store, device=DEV, frame_source=source, batch=64)
+    yield ins, store, files, tmp_path
+    store.close()
+
+
+def test_feeder_delivers_every_frame(tmp_path):
+    luma = _clip(1, [50, 120])
+    p = str(tmp_path / "a.y4m")
+    feeder.write_y4m(p, luma, chroma="420jpeg")
+    got = []
+    for base, d in feeder.FrameFeeder(feeder.Y4MReader(p), batch=64, device=DEV):
+        assert base == sum(x.shape[0] for x in got)
+        got.append(d.cpu().numpy().copy())
+    assert (np.concatenate(got) == luma).all()
+
+
+def test_config0_two_clips_and_a_copy(rig):
+    ins, store, files, tmp = rig
+    cuts_a = [45, 100, 150, 210, 260]
+    a = _clip(1, cuts_a)
+    b = _clip(2, [c + 7 for c in cuts_a])          # cut-shifted copy
+    for name, luma in (("1700000001-a.y4m", a), ("1700000002-b.y4m", b), ("1700000003-a_copy.y4m", a)):
+        files[name] = str(tmp / name)
+        feeder.write_y4m(files[name], luma)
+    exp_a, exp_b = _oracle_cuts(a), _oracle_cuts(b)
+    assert len(exp_a) == 5 and len(exp_b) == 5
+    assert [round(x * 30) for x in exp_a] == cuts_a
+
+    ra = ins.analyze_file("videos", "1700000001-a.y4m")
+    assert ra["status"] == "done" and ra["scene_cuts"] == exp_a and ra["duplicates"] == []
+    assert ra["total_cuts"] == 5 and ra["progress"] == 1.0
+    assert ra["original_filename"] == "1700000001-a.y4m" and ra["clean_filename"] == "a.y4m"
+
+    # the cut-shifted copy has NO exact timestamp in common: not a duplicate for the reference
+    rb = ins.analyze_file("videos", "1700000002-b.y4m")
+    assert rb["status"] == "done" and rb["scene_cuts"] == exp_b and rb["duplicates"] == []
+
+    # the exact copy is detected at its 2nd cut and analysis stops there (app.py:238-255)
+    rc = ins.analyze_file("videos", "1700000003-a_copy.y4m")
+    assert rc["status"] == "done" and rc["duplicates"] == ["a.y4m"]
+    assert rc["scene_cuts"] == exp_a[:2] and rc["total_cuts"] == 2
+
+    # same verdicts from the oracle's replay of the reference loop
+    corpus = []
+    for vid, cuts in ((1, exp_a), (2, exp_b), (3, exp_a)):
+        scene_ts, dup_ids = oracle.streaming_verdict_py(cuts, corpus, vid, 2)
+        assert {1: (exp_a, []), 2: (exp_b, []), 3: (exp_a[:2], [1])}[vid] == (scene_ts, dup_ids)
+    vids = store.list_videos()
+    assert [v["filename"] for v in vids] == ["a.y4m", "b.y4m", "a_copy.y4m"]
+    assert vids[2]["duplicates"] == [vids[0]["id"]] and vids[2]["timestamps"] == exp_a[:2]
+    assert ins.result_for("1700000003-a_copy.y4m")["duplicates"] == ["a.y4m"]
+
+
+def test_sse_reports_done_record(rig):
+    ins, store, files, tmp = rig
+    files["c.y4m"] = str(tmp / "c.y4m")
+    feeder.write_y4m(files["c.y4m"], _clip(3, [30, 90]))
+    app = insp.create_app(ins, sse_period=0.01)
+    c = app.test_client()
+    ev = {"Records": [{"s3": {"bucket": {"name": "videos"}, "object": {"key": "c.y4m"}}}]}
+    assert c.post("/notify", json=ev).get_json() == {"status": "Analysis started", "file": "c.y4m"}
+    body = c.get("/status/stream/c.y4m").get_data(as_text=True)
+    events = [json.loads(l[6:]) for l in body.split("\n\n") if l.startswith("data: ")]
+    assert events[-1]["status"] == "done" and events[-1]["scene_cuts"] == [1.0, 3.0]
+    assert events[-1]["duplicates"] == []
+
+
+def test_concurrent_uploads(rig):
+    ins, store, files, tmp = rig
+    names = []
+    for i in range(6):
+        n = f"17000000{i:02d}-v{i % 3}.y4m"       # three distinct contents, each uploaded twice
+        files[n] = str(tmp / n)
+        feeder.write_y4m(files[n], _clip(10 + i % 3, [40 + 11 * (i % 3), 140, 222 + (i % 3)]))
+        names.append(n)
+    futs = [ins.submit("videos", n) for n in names[:3]]
+    [f.result(timeout=120) for f in futs]
+    futs = [ins.submit("videos", n) for n in names[3:]]
+    res = [f.result(timeout=120) for f in futs]
+    assert all(r["status"] == "done" for r in res)
+    assert [r["duplicates"] for r in res] == [["v0.y4m"], ["v1.y4m"], ["v2.y4m"]]

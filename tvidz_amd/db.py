@@ -1,0 +1,230 @@
+"""Drop-in for the reference's `db` module (inspector/db.py), same names and call shapes:
+
+    from tvidz_amd.db import (add_video, add_timestamps, update_duplicates, find_duplicates,
+                              get_video_by_filename, get_video_by_id)          # app.py:10
+
+What stays the same: the `videos` / `video_timestamps` schema (db.py:12-27, byte-compatible
+column names and types on Postgres), the upsert rule of add_timestamps (db.py:52-62), the
+signature and result shape of find_duplicates (db.py:76: list of (video_id, match_count)).
+
+What changes: find_duplicates no longer fetches the whole table and loops in Python
+(db.py:83-91).  The table is mirrored once into HBM (tvz_corpus), add_timestamps also upserts the
+device row, and the match runs in the HIP kernel of csrc/tvz_match.hip.  Results are sorted by
+video_id (the reference's order is unspecified: no ORDER BY at db.py:83).
+
+Unlike the reference there is no import-time connection/DDL (db.py:8,30): call init() — or let
+the first use do it from POSTGRES_URL (db.py:7), default unchanged.
+"""
+from __future__ import annotations
+
+import os
+import threading
+from datetime import datetime
+from typing import List, Optional, Sequence, Tuple
+
+from sqlalchemy import JSON, Column, DateTime, Float, ForeignKey, Integer, String, create_engine
+from sqlalchemy.dialects.postgresql import ARRAY as PG_ARRAY
+from sqlalchemy.orm import declarative_base, relationship, sessionmaker
+from sqlalchemy.pool import StaticPool
+
+DEFAULT_URL = "postgresql://tvidz:tvidz@postgres:5432/tvidz"   # db.py:7
+
+Base = declarative_base()
+
+
+class Video(Base):                                              # db.py:12-20
+    __tablename__ = "videos"
+    id = Column(Integer, primary_key=True)
+    filename = Column(String, nullable=False)
+    upload_time = Column(DateTime, default=datetime.utcnow)
+    thumbnail_path = Column(String)
+    duplicates = Column(PG_ARRAY(Integer).with_variant(JSON, "sqlite"), default=list)
+    timestamps = relationship("VideoTimestamps", back_populates="video", uselist=False)
+
+
+class VideoTimestamps(Base):                                    # db.py:22-27
+    __tablename__ = "video_timestamps"
+    id = Column(Integer, primary_key=True)
+    video_id = Column(Integer, ForeignKey("videos.id"))
+    timestamps = Column(PG_ARRAY(Float).with_variant(JSON, "sqlite"), nullable=False)
+    video = relationship("Video", back_populates="timestamps")
+
+
+class Store:
+    """SQL persistence (same schema as the reference) + the device corpus that mirrors
+    `video_timestamps`.  Thread-safe: one short session per call, like the reference."""
+
+    def __init__(self, url: Optional[str] = None, device: int = 0, corpus=None):
+        self.url = url or os.environ.get("POSTGRES_URL", DEFAULT_URL)
+        kw = {}
+        if self.url.startswith("sqlite") and (":memory:" in self.url or self.url in ("sqlite://", "sqlite:///")):
+            kw = dict(connect_args={"check_same_thread": False}, poolclass=StaticPool)
+        elif self.url.startswith("sqlite"):
+            kw = dict(connect_args={"timeout": 30})
+        self.engine = create_engine(self.url, **kw)
+        self.SessionLocal = sessionmaker(bind=self.engine)
+        Base.metadata.create_all(self.engine)                   # db.py:30
+        if corpus is None:
+            from .corpus import DeviceCorpus                    # HIP-only: raises without libtvz.so
+            corpus = DeviceCorpus(device)
+        self.corpus = corpus
+        self._write_lock = threading.Lock()
+        self.reload_corpus()
+
+    # -- device mirror -------------------------------------------------------
+    def reload_corpus(self) -> int:
+        """Bulk load: the one `SELECT * FROM video_timestamps` the reference runs per call."""
+        session = self.SessionLocal()
+        try:
+            rows = session.query(VideoTimestamps).order_by(VideoTimestamps.id).all()
+            data = [(int(r.video_id), [float(x) for x in (r.timestamps or [])]) for r in rows
+                    if r.video_id is not None]
+        finally:
+            session.close()
+        self.corpus.upload(data)
+        return len(data)
+
+    # -- reference API -------------------------------------------------------
+    def add_video(self, filename, thumbnail_path=None):         # db.py:32-41
+        session = self.SessionLocal()
+        try:
+            video = Video(filename=filename, thumbnail_path=thumbnail_path)
+            session.add(video)
+            session.commit()
+            session.refresh(video)
+            session.expunge(video)
+            return video
+        finally:
+            session.close()
+
+    def add_timestamps(self, video_id, timestamps):             # db.py:43-64
+        ts = [float(x) for x in timestamps]
+        with self._write_lock:                                  # keep SQL row and HBM row in step
+            session = self.SessionLocal()
+            try:
+                ts_row = (session.query(VideoTimestamps).filter_by(video_id=video_id)
+                          .order_by(VideoTimestamps.id).first())
+                if ts_row:
+                    ts_row.timestamps = ts
+                else:
+                    session.add(VideoTimestamps(video_id=video_id, timestamps=ts))
+                session.commit()
+            finally:
+                session.close()
+            self.corpus.upsert(int(video_id), ts)
+
+    def update_duplicates(self, video_id, duplicate_ids):       # db.py:66-74
+        session = self.SessionLocal()
+        try:
+            video = session.query(Video).filter_by(id=video_id).first()
+            if video:
+                video.duplicates = [int(d) for d in duplicate_ids]
+                session.commit()
+        finally:
+            session.close()
+
+    def find_duplicates(self, new_timestamps, min_match=5) -> List[Tuple[int, int]]:   # db.py:76-94
+        return self.corpus.find_duplicates(new_timestamps, min_match)
+
+    def find_duplicates_kth(self, new_timestamps, min_match=5, exclude_id=-1):
+        """(video_id, match_count, kth): kth = index of the min_match-th matching query element;
+        one call replaces the per-prefix loop of app.py:231-255 (see include/tvz.h)."""
+        return self.corpus.find_duplicates(new_timestamps, min_match, exclude_id=exclude_id,
+                                           with_kth=True)
+
+    def get_video_by_id(self, video_id):                        # db.py:96-102
+        session = self.SessionLocal()
+        try:
+            v = session.query(Video).filter_by(id=video_id).first()
+            if v is not None:
+                session.expunge(v)
+            return v
+        finally:
+            session.close()
+
+    def get_video_by_filename(self, filename):                  # db.py:104-109
+        session = self.SessionLocal()
+        try:
+            v = session.query(Video).filter_by(filename=filename).first()
+            if v is not None:
+                session.expunge(v)
+            return v
+        finally:
+            session.close()
+
+    def clear(self):                                            # app.py:325-333
+        with self._write_lock:
+            session = self.SessionLocal()
+            try:
+                session.query(VideoTimestamps).delete()
+                session.query(Video).delete()
+                session.commit()
+            finally:
+                session.close()
+            self.corpus.clear()
+
+    def list_videos(self):                                      # app.py:347-366
+        session = self.SessionLocal()
+        try:
+            out = []
+            for video in session.query(Video).order_by(Video.id).all():
+                ts = (session.query(VideoTimestamps).filter_by(video_id=video.id)
+                      .order_by(VideoTimestamps.id).first())
+                out.append({"id": video.id, "filename": video.filename,
+                            "upload_time": video.upload_time.isoformat() if video.upload_time else None,
+                            "duplicates": video.duplicates,
+                            "timestamps": ts.timestamps if ts else []})
+            return out
+        finally:
+            session.close()
+
+    def close(self):
+        self.corpus.close()
+        self.engine.dispose()
+
+
+# ---- module-level functions, as the reference exports them (app.py:10) --------------------
+_default: Optional[Store] = None
+_default_lock = threading.Lock()
+
+
+def init(url: Optional[str] = None, device: int = 0, corpus=None) -> Store:
+    global _default
+    with _default_lock:
+        if _default is not None:
+            _default.close()
+        _default = Store(url, device, corpus)
+        return _default
+
+
+def store() -> Store:
+    global _default
+    if _default is None:
+        with _default_lock:
+            if _default is None:
+                _default = Store()
+    return _default
+
+
+def add_video(filename, thumbnail_path=None):
+    return store().add_video(filename, thumbnail_path)
+
+
+def add_timestamps(video_id, timestamps):
+    return store().add_timestamps(video_id, timestamps)
+
+
+def update_duplicates(video_id, duplicate_ids):
+    return store().update_duplicates(video_id, duplicate_ids)
+
+
+def find_duplicates(new_timestamps, min_match=5):
+    return store().find_duplicates(new_timestamps, min_match)
+
+
+def get_video_by_id(video_id):
+    return store().get_video_by_id(video_id)
+
+
+def get_video_by_filename(filename):
+    return store().get_video_by_filename(filename)

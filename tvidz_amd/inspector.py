@@ -1,0 +1,326 @@
+"""Analysis driver + HTTP/SSE surface — restatement of /root/reference/inspector/app.py around the
+GPU kernels (the reference's own loop cannot be kept: its scene scorer is a child process).
+
+Kept from the reference, citation by citation:
+  * key/filename hygiene and the unique analysis key            app.py:122-136
+  * result record {status, scene_cuts, progress, total_cuts, duplicates, original_filename,
+    clean_filename[, error]}                                    app.py:153-161, 294-302, 307-315
+  * consecutive-duplicate drop of cut timestamps                app.py:231
+  * persist the growing prefix, match with min_match=2, drop self, stop at the FIRST hit,
+    store duplicate ids, report duplicate filenames             app.py:234-255
+  * routes: POST /notify, GET /status/<f>, GET+OPTIONS /status/stream/<f> (SSE, emit on change,
+    0.2 s tick, stop at done/error), /build-info, /admin/clear-db, /debug/*   app.py:23-115, 324-415
+  * CORS headers on every response                              app.py:15-21
+
+Changed on purpose (documented in DESIGN.md): frames are scored in micro-batches on the GPU and
+every batch issues ONE match whose `kth` output reproduces the per-prefix loop; `progress` is
+true frame progress when the frame count is known (the reference's `n:` parse never succeeds,
+SURVEY.md §3.3); uploads run on a bounded worker pool instead of one unbounded thread each; the
+SQS poller (app.py:417-480) is out of scope (no compute).
+"""
+from __future__ import annotations
+
+import json
+import os
+import threading
+import time
+import uuid
+from concurrent.futures import ThreadPoolExecutor
+from typing import Callable, Dict, List, Optional
+
+import torch
+
+from . import scene
+from .feeder import FFmpegReader, FrameFeeder, Y4MReader
+
+KTH_NEVER = 0x7FFFFFFF
+
+
+def split_filenames(key: str):
+    """app.py:122-130: last path component, and the name without the `<digits>-` upload prefix."""
+    filename = key.split("/")[-1] if key and "/" in key else key or "unknown_file"
+    if not filename:
+        filename = "unknown_file"
+    original_filename = filename
+    if "-" in filename and filename.split("-")[0].isdigit():
+        original_filename = "-".join(filename.split("-")[1:])
+    return filename, original_filename
+
+
+def open_reader(path: str):
+    with open(path, "rb") as f:
+        magic = f.read(9)
+    return Y4MReader(path) if magic == b"YUV4MPEG2" else FFmpegReader(path)
+
+
+def s3_frame_source(bucket: str, key: str, filename: str, unique_id: str):
+    """app.py:163-200: fetch the object from LocalStack with 5 retries, then open a decoder."""
+    import requests
+    s3_url = f"http://localstack:4566/{bucket}/{key}"
+    local_path = f"/tmp/{unique_id}_{filename}"
+    last = None
+    for attempt in range(5):
+        try:
+            r = requests.get(s3_url, stream=True)
+            with open(local_path, "wb") as f:
+                for chunk in r.iter_content(chunk_size=1 << 20):
+                    f.write(chunk)
+            if not os.path.exists(local_path) or not local_path.startswith("/tmp/"):
+                raise Exception(f"Invalid or unsafe file path: {local_path}")
+            return open_reader(local_path), local_path
+        except Exception as e:
+            last = e
+            if attempt < 4:
+                time.sleep(1)
+    raise Exception(f"File download incomplete or corrupt after 5 attempts: {last}")
+
+
+class Inspector:
+    def __init__(self, store, device: str = "cuda:0", frame_source: Optional[Callable] = None,
+                 threshold: float = scene.DEFAULT_THRESHOLD, min_match: int = 2,
+                 pts_policy: str = scene.PTS_POLICY_G6, batch: int = 256, max_workers: int = 16):
+        self.store = store
+        self.device = torch.device(device)
+        self.frame_source = frame_source or s3_frame_source
+        self.threshold = threshold
+        self.min_match = min_match          # app.py:235
+        self.pts_policy = pts_policy
+        self.batch = batch
+        self.analysis_results: Dict[str, dict] = {}     # app.py:28
+        self.analysis_lock = threading.Lock()           # app.py:29
+        self.pool = ThreadPoolExecutor(max_workers=max_workers, thread_name_prefix="analyze")
+
+    # ------------------------------------------------------------------ driver
+    def submit(self, bucket: str, key: str):
+        return self.pool.submit(self.analyze_file, bucket, key)
+
+    def analyze_file(self, bucket: str, key: str) -> dict:
+        filename, original_filename = split_filenames(key)
+        unique_id = f"{int(time.time())}_{uuid.uuid4().hex[:8]}"           # app.py:134
+        analysis_key = f"{unique_id}_{filename}"                           # app.py:136
+        with self.analysis_lock:
+            self.analysis_results.pop(analysis_key, None)
+        video = self.store.add_video(original_filename)                    # app.py:150
+        video_id = video.id
+        self._set(analysis_key, {"status": "analyzing", "scene_cuts": [], "progress": 0.0,
+                                 "total_cuts": 0, "duplicates": [], "original_filename": filename,
+                                 "clean_filename": original_filename})
+        local_path = None
+        reader = None
+        try:
+            reader, local_path = self.frame_source(bucket, key, filename, unique_id)
+            scene_timestamps, dups_to_report = self._run(analysis_key, video_id, reader)
+            result = {"status": "done", "scene_cuts": scene_timestamps, "progress": 1.0,
+                      "total_cuts": len(scene_timestamps),
+                      "duplicates": list(set(dups_to_report)) if dups_to_report else [],
+                      "original_filename": filename, "clean_filename": original_filename}
+            self._set(analysis_key, result)                                # app.py:294-302
+        except Exception as e:                                             # app.py:303-315
+            with self.analysis_lock:
+                existing = self.analysis_results.get(analysis_key, {}).get("duplicates", [])
+                result = {"status": "error", "error": str(e), "progress": 0.0, "total_cuts": 0,
+                          "duplicates": existing, "original_filename": filename,
+                          "clean_filename": original_filename}
+                self.analysis_results[analysis_key] = result
+        finally:                                                           # app.py:316-322
+            if reader is not None:
+                try:
+                    reader.close()
+                except Exception:
+                    pass
+            if local_path and os.path.exists(local_path):
+                try:
+                    os.remove(local_path)
+                except Exception:
+                    pass
+        return result
+
+    def _set(self, analysis_key: str, value: dict) -> None:
+        with self.analysis_lock:
+            self.analysis_results[analysis_key] = value
+
+    def _run(self, analysis_key: str, video_id: int, reader):
+        """GPU restatement of the hot loop app.py:216-291."""
+        time_base = reader.time_base
+        total_frames = getattr(reader, "total_frames", 0) or 0
+        scorer = scene.SceneScorer(reader.H, reader.W, self.batch, self.device, self.threshold)
+        feeder = FrameFeeder(reader, self.batch, self.device)
+        scene_timestamps: List[float] = []
+        dups_to_report: List[str] = []
+        frames_done = 0
+        for base, d_frames in feeder:
+            _, _, _, sel = scorer.score_batch(d_frames)
+            scorer.remember_tail(d_frames)
+            idx = torch.nonzero(sel, as_tuple=False).flatten().cpu().tolist()
+            frames_done = base + d_frames.shape[0]
+            grew = False
+            for i in idx:
+                ts = scene.pts_time_value(base + i, time_base, self.pts_policy)    # app.py:230
+                if not scene_timestamps or ts != scene_timestamps[-1]:              # app.py:231
+                    scene_timestamps.append(ts)
+                    grew = True
+            if grew:
+                # one match over the whole current list; kth tells on which prefix the
+                # reference's per-cut loop (app.py:234-238) would have stopped
+                hits = self.store.find_duplicates_kth(scene_timestamps, self.min_match,
+                                                      exclude_id=video_id)            # :235-237
+                hits = [h for h in hits if h[2] < KTH_NEVER]
+                if hits:
+                    kstar = min(h[2] for h in hits)
+                    dup_ids = [h[0] for h in hits if h[2] == kstar]
+                    scene_timestamps = scene_timestamps[:max(kstar, 0) + 1]
+                    self.store.add_timestamps(video_id, scene_timestamps)             # :234
+                    self.store.update_duplicates(video_id, dup_ids)                   # :239
+                    for dup_id in dup_ids:                                            # :241-245
+                        dup_video = self.store.get_video_by_id(dup_id)
+                        if dup_video:
+                            dups_to_report.append(dup_video.filename)
+                    self._progress(analysis_key, scene_timestamps, frames_done, total_frames,
+                                   dups_to_report)
+                    feeder.close()                                                    # :249-255
+                    break
+                self.store.add_timestamps(video_id, scene_timestamps)                 # :234
+            self._progress(analysis_key, scene_timestamps, frames_done, total_frames, dups_to_report)
+        return scene_timestamps, dups_to_report
+
+    def _progress(self, analysis_key, scene_timestamps, frames_done, total_frames, dups_to_report):
+        if total_frames > 0 and frames_done > 0:                           # app.py:259-260
+            progress = min(frames_done / total_frames, 1.0)
+        elif scene_timestamps:                                             # app.py:261-264
+            estimated_duration = max(scene_timestamps) + 10
+            progress = min(len(scene_timestamps) * 10 / estimated_duration, 1.0)
+        else:
+            progress = 0.0
+        with self.analysis_lock:                                           # app.py:276-282
+            rec = self.analysis_results[analysis_key]
+            rec["progress"] = progress
+            rec["scene_cuts"] = list(scene_timestamps)
+            if dups_to_report:
+                rec["duplicates"] = list(set(dups_to_report))
+
+    # ------------------------------------------------------------------ lookup
+    def result_for(self, filename: str) -> Optional[dict]:
+        """app.py:72-84: exact key first, then by original_filename."""
+        with self.analysis_lock:
+            if filename in self.analysis_results:
+                return dict(self.analysis_results[filename])
+            for _, data in self.analysis_results.items():
+                if isinstance(data, dict) and data.get("original_filename") == filename:
+                    return dict(data)
+        return None
+
+
+def create_app(inspector: Inspector, sse_period: float = 0.2):
+    """Flask app with the reference's routes and JSON shapes (app.py:12-115, 324-415)."""
+    from flask import Flask, Response, jsonify, request
+
+    app = Flask(__name__)
+
+    def add_cors_headers(response):                                        # app.py:15-19
+        response.headers["Access-Control-Allow-Origin"] = "*"
+        response.headers["Access-Control-Allow-Methods"] = "GET, POST, OPTIONS"
+        response.headers["Access-Control-Allow-Headers"] = "Content-Type"
+        return response
+
+    app.after_request(add_cors_headers)
+
+    @app.route("/status/stream/<filename>", methods=["OPTIONS"])          # app.py:23-25
+    def status_stream_options(filename):
+        return add_cors_headers(Response())
+
+    @app.route("/notify", methods=["POST"])                               # app.py:31-44
+    def notify():
+        data = request.get_json(silent=True)
+        try:
+            record = data["Records"][0]
+            bucket = record["s3"]["bucket"]["name"]
+            key = record["s3"]["object"]["key"]
+        except Exception as e:
+            return jsonify({"error": "Invalid event format", "details": str(e)}), 400
+        inspector.submit(bucket, key)
+        return jsonify({"status": "Analysis started", "file": key})
+
+    @app.route("/status/<filename>", methods=["GET"])                     # app.py:46-62
+    def status(filename):
+        result = inspector.result_for(filename)
+        if not result:
+            return jsonify({"status": "pending"})
+        return jsonify(result)
+
+    @app.route("/status/stream/<filename>")                               # app.py:64-115
+    def status_stream(filename):
+        def event_stream():
+            last = None
+            while True:
+                result = inspector.result_for(filename)
+                if not result:
+                    cur = ("pending", 0.0, 0, 0)
+                else:
+                    cur = (result.get("status"), result.get("progress", 0.0),
+                           len(result.get("scene_cuts", [])), len(result.get("duplicates", [])))
+                if cur != last:
+                    last = cur
+                    data = result if result else {"status": "pending"}
+                    yield f"data: {json.dumps(data)}\n\n"
+                    if cur[0] in ("done", "error"):
+                        break
+                time.sleep(sse_period)
+        return add_cors_headers(Response(event_stream(), mimetype="text/event-stream"))
+
+    @app.route("/admin/clear-db", methods=["POST"])                       # app.py:325-333
+    def clear_db():
+        inspector.store.clear()
+        return jsonify({"status": "cleared"})
+
+    @app.route("/build-info", methods=["GET"])                            # app.py:335-345
+    def build_info():
+        return jsonify({"inspector": {"build_date": os.environ.get("BUILD_DATE", "unknown"),
+                                      "build_time": os.environ.get("BUILD_TIME", "unknown"),
+                                      "git_commit": os.environ.get("GIT_COMMIT", "unknown"),
+                                      "service": "inspector"}})
+
+    @app.route("/debug/videos", methods=["GET"])                          # app.py:347-366
+    def debug_videos():
+        vids = inspector.store.list_videos()
+        return jsonify({"videos": vids, "count": len(vids)})
+
+    @app.route("/debug/create-test-video", methods=["POST"])              # app.py:368-384
+    def create_test_video():
+        body = request.get_json(silent=True) or {}
+        test_filename = body.get("filename", "test_video.mp4")
+        test_timestamps = body.get("timestamps", [1.2, 5.7, 12.3, 18.9, 25.1])
+        try:
+            video = inspector.store.add_video(test_filename)
+            inspector.store.add_timestamps(video.id, test_timestamps)
+            return jsonify({"status": "created", "video_id": video.id, "filename": test_filename,
+                            "timestamps": test_timestamps})
+        except Exception as e:
+            return jsonify({"error": str(e)}), 500
+
+    @app.route("/debug/analysis-results", methods=["GET"])                # app.py:386-393
+    def debug_analysis_results():
+        with inspector.analysis_lock:
+            return jsonify({"analysis_results": inspector.analysis_results,
+                            "count": len(inspector.analysis_results)})
+
+    @app.route("/debug/test-duplicate", methods=["POST"])                 # app.py:395-415
+    def test_duplicate_scenario():
+        first_video = inspector.store.add_video("test.mp4")
+        inspector.store.add_timestamps(first_video.id, [1.2, 5.7, 12.3, 18.9])
+        second_filename = f"{int(time.time() * 1000)}-test.mp4"
+        dups = inspector.store.find_duplicates([1.2, 5.7, 12.3, 18.9], min_match=2)
+        return jsonify({"first_video_id": first_video.id, "second_filename": second_filename,
+                        "duplicates_found": dups,
+                        "message": f"Created test video, then tested duplicate detection for {second_filename}"})
+
+    return app
+
+
+def main():  # pragma: no cover - service entry point (app.py:482-484)
+    from . import db
+    inspector = Inspector(db.store())
+    create_app(inspector).run(host="0.0.0.0", port=5000, threaded=True)
+
+
+if __name__ == "__main__":  # pragma: no cover
+    main()

@@ -75,11 +75,12 @@ class ShardedMatcher:
         if self.world == 1:
             return local, n
         Q = local.shape[0]
-        gathered = torch.empty((self.world, Q, self.k, 3), dtype=torch.int32, device=local.device)
+        # dim-0 concatenation is the layout both RCCL and gloo accept for all_gather_into_tensor
+        gathered = torch.empty((self.world * Q, self.k, 3), dtype=torch.int32, device=local.device)
         dist.all_gather_into_tensor(gathered, local.contiguous(), group=self.group)
         totals = n.clone()
         dist.all_reduce(totals, op=dist.ReduceOp.SUM, group=self.group)
-        return self.backend.topk(gathered, None, self.k), totals
+        return self.backend.topk(gathered.view(self.world, Q, self.k, 3), None, self.k), totals
 
 
 def verdicts_from_topk(merged: np.ndarray):
