@@ -40,7 +40,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
         return SO
     cmd = [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared",
            "-fvisibility=hidden", "-Wall", "-Wno-unused-function", f"-I{INCLUDE}", f"-I{CSRC}",
-           "-o", SO + ".tmp"] + [os.path.join(CSRC, s) for s in SOURCES]
+           "-o", SO + ".tmp"] + os.environ.get("TVZ_CXXFLAGS", "").split() + \
+          [os.path.join(CSRC, s) for s in SOURCES]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)

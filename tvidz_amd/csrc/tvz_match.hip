@@ -10,14 +10,17 @@
 //   keys    = arena of canonical float64 bit patterns (int64): per row sorted, unique,
 //             NaN dropped, -0.0 folded to +0.0; every row starts 16-byte aligned.
 //
-// Kernel ts_match_kernel: grid = (row chunks, Q).  A 256-thread block builds query q's
-//   hash set (open addressing, key -> multiplicity) in LDS once, then sweeps its chunk
-//   of rows: a 16-lane group owns one row at a time, streams its keys with 16-byte loads
-//   (row bytes are read once per (query, row) pair: 8*L_c bytes), probes the LDS table,
-//   reduces the count with 4 row-DPP adds.  Only hits (rare) take the slow path that
-//   recovers the index of the min_match-th hit by binary-searching the sorted row per
-//   query position, and append (video_id, count, kth) to the query's hit list.
-//   HBM/L2-bound integer work: no MFMA.
+// Kernel ts_match_tile_kernel: grid = (row chunks, query tiles).  A 1024-thread block builds ONE
+//   hash table in LDS for a tile of up to 16 queries (open addressing on the canonical key; each
+//   key heads a chain of (query-in-tile, position) entries, so query multiplicity is exact), then
+//   sweeps its chunk of rows: a 16-lane group owns one row at a time, streams its keys with
+//   16-byte loads (up to 4 in flight per lane) and probes the table ONCE per key for all queries
+//   of the tile - the Q-tile plays the role a GEMM tile plays: every corpus byte loaded is reused
+//   16 times on chip.  A chain hit bumps the (group, query) counter and the two smallest matching
+//   positions with LDS atomics; after the row, lane q of the group emits query q's hit
+//   (video_id, count, kth).  kth = min_match-th smallest matching position: taken from the two
+//   tracked minima for min_match <= 2 (the driver's case), by ts_kth_fixup_kernel (binary search of
+//   the sorted row per query position) for min_match > 2.  Integer/LDS-bound: no MFMA.
 // Kernel ts_topk_kernel: per query bitonic selection of the k best hits ordered by
 //   (kth, video_id, count) over one or several (all-gathered) hit lists.
 #include <algorithm>
@@ -35,8 +38,7 @@ constexpr int kBlock = 256;
 constexpr int kGroup = 16;                  // lanes per corpus row
 constexpr int kGroupsPerBlock = kBlock / kGroup;
 constexpr int64_t kEmpty = 0x7ff8dead00000000LL;  // a NaN pattern: never a canonical key
-constexpr int kMaxSlots = 8192;             // 8192 * 12 B = 96 KiB of LDS
-constexpr int kMaxQueryLen = kMaxSlots / 2;
+constexpr int kMaxQueryLen = 4096;          // one maximal query fills the tile table to load 0.5
 
 struct Row {
     int64_t off;
@@ -64,127 +66,277 @@ __device__ __forceinline__ uint32_t hash_key(int64_t k, int shift) {
     return x >> shift;
 }
 
-template <int CTRL>
-__device__ __forceinline__ int dpp_row(int v) {
-    return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true);
+// ---- query tile: up to 16 queries share ONE hash table in LDS -----------------------------
+// One probe of a corpus key serves every query of the tile, and each corpus row is read once
+// per tile instead of once per query.
+//   slots   : 16384 x u32 = (16-bit tag << 16) | (head entry index); 0xffffffff = empty.
+//             Probed two at a time (one aligned ds_read_b64); load factor <= 0.25, so a probe
+//             almost never needs a second read - what matters on a 64-lane wave is the LONGEST
+//             probe of the wave, not the average.
+//   entries : one per query element of the tile: full canonical key (verification) and
+//             (position, query-in-tile, next entry with the same slot).  Query multiplicity is
+//             therefore exact: every occurrence is its own entry.
+constexpr int kTileBlock = 1024;                      // 16 waves, 64 row groups
+constexpr int kTileGroups = kTileBlock / kGroup;
+constexpr int kTileQ = kGroup;                        // lane <-> query mapping at emission
+constexpr int kTileSlots = 16384;
+constexpr int kTilePairs = kTileSlots / 2;
+constexpr int kTileMaxEntries = 4096;                 // load factor <= 0.25
+constexpr uint32_t kEnd = 0xffffu;
+constexpr uint32_t kFree = 0xffffffffu;
+constexpr uint32_t kInf = 0xffffffffu;
+static_assert(kTileMaxEntries == kMaxQueryLen, "a single maximal query must fit one tile");
+constexpr int kRing = 128;                            // per-wave slow-path ring (entries)
+constexpr size_t kTileLds = (size_t)kTileSlots * 4 + (size_t)kTileMaxEntries * 8 +
+                            (size_t)kTileMaxEntries * 4 + (size_t)kTileGroups * kTileQ * 3 * 4 +
+                            (size_t)(kTileBlock / 64) * kRing * 12;
+
+struct PairState {  // per (row group, query of the tile), lives in LDS
+    uint32_t cnt, m1, m2;   // hits, smallest and second smallest matching query position
+};
+
+// pair index (13 bits) and tag (16 bits, never 0xffff) from one mix of the key.  Only full-rate
+// VALU ops: v_mul_u32_u24 instead of the quarter-rate v_mul_lo_u32.  Quality only affects speed
+// (every tag match is verified against the full key).
+__device__ __forceinline__ void hash_pair_tag(int64_t k, uint32_t &pair, uint32_t &tag) {
+    const uint32_t lo = (uint32_t)k, hi = (uint32_t)((uint64_t)k >> 32);
+    uint32_t x = lo ^ (hi + (hi << 3)) ^ (hi >> 9);
+    x ^= x >> 15;
+    const uint32_t a = __umul24(x, 0x9E3779u);           // low 24 bits of x
+    const uint32_t b = __umul24(x >> 8, 0x85EBCBu);      // high 24 bits of x
+    const uint32_t y = a ^ (b << 3) ^ (b >> 11);
+    pair = (y >> 11) & (uint32_t)(kTilePairs - 1);
+    tag = (y ^ (a >> 7)) & 0xffffu;
+    if (tag == 0xffffu) tag = 0;
+}
+static_assert((1 << 13) == kTilePairs, "pair bits must match kTilePairs");
+
+// one matching (query, position) entry: count it and keep the two smallest positions
+__device__ __forceinline__ void account(PairState *gst, uint32_t ent) {
+    PairState *st = gst + ((ent >> 12) & 15u);
+    const uint32_t pos = ent & 0xfffu;
+    atomicAdd(&st->cnt, 1u);
+    const uint32_t old = atomicMin(&st->m1, pos);
+    atomicMin(&st->m2, old > pos ? old : pos);
 }
 
-// all-reduce sum over the 16 lanes of a DPP row (all 16 lanes must be active)
-__device__ __forceinline__ int group_sum16(int v) {
-    v += dpp_row<0xB1>(v);   // quad_perm [1,0,3,2]
-    v += dpp_row<0x4E>(v);   // quad_perm [2,3,0,1]
-    v += dpp_row<0x141>(v);  // row_half_mirror
-    v += dpp_row<0x140>(v);  // row_mirror
-    return v;
-}
-
-__device__ __forceinline__ int probe(const int64_t *tab, const int32_t *mult, uint32_t mask,
-                                     int shift, int64_t k) {
-    uint32_t h = hash_key(k, shift);
-    while (true) {
-        const int64_t t = tab[h];
-        if (t == k) return mult[h];
-        if (t == kEmpty) return 0;
-        h = (h + 1) & mask;
-    }
-}
-
-__global__ __launch_bounds__(kBlock) void ts_match_kernel(
+__global__ __launch_bounds__(kTileBlock) void ts_match_tile_kernel(
     const Row *__restrict__ rows, int64_t n_rows, const int64_t *__restrict__ keys,
-    const double *__restrict__ queries, const int64_t *__restrict__ q_offsets, int32_t min_match,
-    const int32_t *__restrict__ exclude_ids, int32_t cap, int32_t *__restrict__ hits,
-    int32_t *__restrict__ hits_n, int32_t slots, int32_t rows_per_block) {
+    const double *__restrict__ queries, const int64_t *__restrict__ q_offsets, int32_t Q,
+    int32_t nq_tile, int32_t min_match, const int32_t *__restrict__ exclude_ids, int32_t cap,
+    int32_t *__restrict__ hits, int32_t *__restrict__ hits_n, int32_t rows_per_block) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    int64_t *tab = reinterpret_cast<int64_t *>(smem);
-    int32_t *mult = reinterpret_cast<int32_t *>(smem + (size_t)slots * 8);
-    const uint32_t mask = (uint32_t)slots - 1;
-    const int shift = 32 - (31 - __builtin_clz(slots));  // 32 - log2(slots)
+    uint32_t *slots = reinterpret_cast<uint32_t *>(smem);
+    int64_t *ekey = reinterpret_cast<int64_t *>(smem + (size_t)kTileSlots * 4);
+    uint32_t *epack = reinterpret_cast<uint32_t *>(ekey + kTileMaxEntries);
+    PairState *state = reinterpret_cast<PairState *>(epack + kTileMaxEntries);
+    __shared__ int64_t s_qoff[kTileQ + 1];
 
-    const int q = blockIdx.y;
-    const int64_t qo = q_offsets[q];
-    const int32_t qlen = (int32_t)(q_offsets[q + 1] - qo);
-    const double *qv = queries + qo;
-
-    for (int i = threadIdx.x; i < slots; i += kBlock) {
-        tab[i] = kEmpty;
-        mult[i] = 0;
-    }
+    const int q0 = blockIdx.y * nq_tile;
+    const int nq = (Q - q0 < nq_tile) ? Q - q0 : nq_tile;
+    if (threadIdx.x <= nq) s_qoff[threadIdx.x] = q_offsets[q0 + threadIdx.x];
+    for (int i = threadIdx.x; i < kTileSlots; i += kTileBlock) slots[i] = kFree;
+    for (int i = threadIdx.x; i < kTileGroups * kTileQ; i += kTileBlock) state[i] = PairState{0, kInf, kInf};
     __syncthreads();
-    for (int i = threadIdx.x; i < qlen; i += kBlock) {
+    const int64_t qbase = s_qoff[0];
+    int total = (int)(s_qoff[nq] - qbase);
+    if (total > kTileMaxEntries) total = kTileMaxEntries;  // host guarantees this never trims
+    for (int e = threadIdx.x; e < total; e += kTileBlock) {
+        int ql = 0;
+        while (ql + 1 < nq && s_qoff[ql + 1] - qbase <= e) ++ql;
+        const uint32_t pos = (uint32_t)(e - (int)(s_qoff[ql] - qbase));
         int64_t k;
-        if (!canon_key(qv[i], k)) continue;
-        uint32_t h = hash_key(k, shift);
+        if (!canon_key(queries[qbase + e], k)) continue;   // NaN never matches
+        ekey[e] = k;
+        uint32_t pair, tag;
+        hash_pair_tag(k, pair, tag);
+        // first slot of the probe sequence that is free or already carries this tag
+        uint32_t s = pair * 2, prev = kEnd;
         while (true) {
-            const unsigned long long old =
-                atomicCAS(reinterpret_cast<unsigned long long *>(&tab[h]),
-                          (unsigned long long)kEmpty, (unsigned long long)k);
-            if (old == (unsigned long long)kEmpty || old == (unsigned long long)k) {
-                atomicAdd(&mult[h], 1);
+            uint32_t w = slots[s];
+            if (w == kFree) {
+                w = atomicCAS(&slots[s], kFree, (tag << 16) | (uint32_t)e);
+                if (w == kFree) break;                      // claimed an empty slot
+            }
+            if ((w >> 16) == tag) {                         // push on this tag's chain
+                uint32_t seen = w;
+                while (true) {
+                    const uint32_t old = atomicCAS(&slots[s], seen, (seen & 0xffff0000u) | (uint32_t)e);
+                    if (old == seen) break;
+                    seen = old;
+                }
+                prev = seen & 0xffffu;
                 break;
             }
-            h = (h + 1) & mask;
+            s = (s + 1) & (kTileSlots - 1);
         }
+        epack[e] = pos | ((uint32_t)ql << 12) | (prev << 16);
     }
     __syncthreads();
 
     const int gl = threadIdx.x & (kGroup - 1);
     const int g = threadIdx.x / kGroup;
-    const int gshift = (threadIdx.x & 63) & ~(kGroup - 1);  // bit position of this group in a ballot
-    const int32_t excl = exclude_ids ? exclude_ids[q] : -1;
+    PairState *gst = state + g * kTileQ;
+    const bool my_q = gl < nq;
+    const int32_t excl = (exclude_ids && my_q) ? exclude_ids[q0 + gl] : -1;
     const bool use_excl = exclude_ids != nullptr;
     const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
     int64_t r1 = r0 + rows_per_block;
     if (r1 > n_rows) r1 = n_rows;
+    const uint2 *pairs = reinterpret_cast<const uint2 *>(slots);
 
-    for (int64_t r = r0 + g; r < r1; r += kGroupsPerBlock) {
-        const Row row = rows[r];
-        if (use_excl && row.vid == excl) continue;  // group-uniform
-        const int64_t *rk = keys + row.off;
-        int cnt = 0;
-        for (int i = gl * 2; i < row.len; i += kGroup * 2) {
-            const longlong2 kk = *reinterpret_cast<const longlong2 *>(rk + i);  // 16 B, aligned
-            cnt += probe(tab, mult, mask, shift, kk.x);
-            if (i + 1 < row.len) cnt += probe(tab, mult, mask, shift, kk.y);
+    // ---- sweep -------------------------------------------------------------------------------
+    // SIMT rule that shapes this loop: an event that is rare per LANE (a corpus key that is in
+    // the tile, ~6 % on the synthetic corpora; a displaced key) still happens in almost every
+    // 64-lane wave-instruction, so handling it inline costs every probe the full slow path.
+    // Instead the per-key fast path is branch-free (hash, one aligned 8-byte LDS read of the home
+    // slot pair, tag compares) and lanes that need more push (key, pair|tag|group) into a per-wave
+    // LDS ring with a ballot/mbcnt compaction; whenever 64 entries are pending the whole wave
+    // drains them with every lane busy on the exact probe + chain verification + accounting.
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const uint32_t gw = (threadIdx.x >> 4) & 3u;                 // group within the wave
+    int64_t *qk = reinterpret_cast<int64_t *>(state + kTileGroups * kTileQ) + wave * kRing;
+    uint32_t *qm = reinterpret_cast<uint32_t *>(reinterpret_cast<int64_t *>(state + kTileGroups * kTileQ) +
+                                                (kTileBlock / 64) * kRing) + wave * kRing;
+    PairState *wst = state + wave * 4 * kTileQ;                   // the wave's 4 groups
+    uint32_t qhead = 0, qtail = 0;                                // wave-uniform
+
+    auto drain = [&](uint32_t n) {                                // n <= 64 pending entries
+        if ((uint32_t)lane < n) {
+            const uint32_t idx = (qhead + lane) & (kRing - 1);
+            const int64_t k = qk[idx];
+            const uint32_t m = qm[idx];
+            const uint32_t tag = m & 0xffffu;
+            uint32_t pair = (m >> 16) & (uint32_t)(kTilePairs - 1);
+            PairState *st = wst + (m >> 29) * kTileQ;
+            uint32_t e = kEnd;
+            while (true) {      // first slot of the probe sequence that is free or carries the tag
+                const uint2 w = pairs[pair];
+                if ((w.x >> 16) == tag) { e = w.x & 0xffffu; break; }
+                if (w.x == kFree) break;
+                if ((w.y >> 16) == tag) { e = w.y & 0xffffu; break; }
+                if (w.y == kFree) break;
+                pair = (pair + 1) & (uint32_t)(kTilePairs - 1);
+            }
+            while (e != kEnd) {  // every (query, position) entry of that slot; verify the full key
+                const uint32_t ent = epack[e];
+                if (ekey[e] == k) account(st, ent);
+                e = ent >> 16;
+            }
         }
-        const int total = group_sum16(cnt);
-        if (total < min_match) continue;  // group-uniform; the common case
+        qhead += n;
+    };
 
-        // ---- hit: recover the query index of the min_match-th hit ----
-        int kth = -1;
-        if (min_match > 0) {
-            kth = TVZ_KTH_NEVER;
-            int running = 0;
-            for (int base = 0; base < qlen && kth == TVZ_KTH_NEVER; base += kGroup) {
-                const int i = base + gl;
-                bool hit = false;
-                int64_t k;
-                if (i < qlen && canon_key(qv[i], k)) {
-                    int lo = 0, hi = row.len;
-                    while (lo < hi) {
-                        const int mid = (lo + hi) >> 1;
-                        if (rk[mid] < k) lo = mid + 1; else hi = mid;
+    const int64_t rw0 = r0 + (int64_t)wave * 4;                   // first row of the wave's groups
+    for (int64_t rr = rw0; rr < r1; rr += kTileGroups) {          // wave-uniform trip count
+        const int64_t r = rr + gw;
+        const bool live = r < r1;
+        Row row = Row{0, 0, -1};
+        if (live) row = rows[r];
+        const int64_t *rk = keys + row.off + gl * 2;
+        const int nmine = row.len - gl * 2;                       // keys at or after this lane's first
+        longlong2 v0 = make_longlong2(0, 0), v1 = v0;
+        if (nmine > 0) v0 = *reinterpret_cast<const longlong2 *>(rk);
+        if (nmine > kGroup * 2) v1 = *reinterpret_cast<const longlong2 *>(rk + kGroup * 2);
+        for (int i = 0; __ballot(i < nmine) != 0ull; i += 2 * kGroup * 2) {
+            const int64_t kk[4] = {v0.x, v0.y, v1.x, v1.y};
+            const int in = i + 2 * kGroup * 2;                    // next step's loads, in flight
+            if (in < nmine) v0 = *reinterpret_cast<const longlong2 *>(rk + in);
+            if (in + kGroup * 2 < nmine) v1 = *reinterpret_cast<const longlong2 *>(rk + in + kGroup * 2);
+            uint32_t pr[4], tg[4];
+            uint2 w[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                hash_pair_tag(kk[j], pr[j], tg[j]);
+                w[j] = pairs[pr[j]];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const bool valid = i + (j / 2) * kGroup * 2 + (j & 1) < nmine;
+                // needs the slow path: tag present in the home pair, or the pair is full
+                const bool slow = valid & (((w[j].x >> 16) == tg[j]) | (w[j].y != kFree));
+                const unsigned long long bal = __ballot(slow);
+                if (bal) {                                        // wave-uniform
+                    const uint32_t ofs = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32),
+                                         __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+                    if (slow) {
+                        const uint32_t idx = (qtail + ofs) & (kRing - 1);
+                        qk[idx] = kk[j];
+                        qm[idx] = tg[j] | (pr[j] << 16) | (gw << 29);
                     }
-                    hit = lo < row.len && rk[lo] == k;
+                    qtail += (uint32_t)__popcll(bal);
+                    if (qtail - qhead >= 64u) drain(64u);
                 }
-                const uint32_t m16 = (uint32_t)(__ballot(hit) >> gshift) & 0xffffu;
-                const int c = __popc(m16);
-                if (running + c >= min_match) {
-                    uint32_t m = m16;
-                    for (int need = min_match - running; need > 1; --need) m &= m - 1;
-                    kth = base + (__ffs(m) - 1);
-                }
-                running += c;
             }
         }
-        if (gl == 0) {
-            const int slot = atomicAdd(&hits_n[q], 1);
-            if (slot < cap) {
-                int32_t *h = hits + ((int64_t)q * cap + slot) * 3;
-                h[0] = row.vid;
-                h[1] = total;
-                h[2] = kth;
+        if (qtail != qhead) drain(qtail - qhead);                 // row boundary: settle the counts
+        // lane q of the group owns query q of the tile (LDS ops of a wave complete in order)
+        if (my_q & live) {
+            const PairState st = gst[gl];
+            if (st.cnt) gst[gl] = PairState{0, kInf, kInf};
+            if ((int64_t)st.cnt >= (int64_t)min_match && !(use_excl && row.vid == excl)) {
+                int32_t kth;
+                if (min_match <= 0) kth = -1;
+                else if (min_match == 1) kth = (int32_t)st.m1;
+                else if (min_match == 2) kth = (int32_t)st.m2;
+                else kth = -2 - (int32_t)r;          // resolved by ts_kth_fixup_kernel
+                const int slot = atomicAdd(&hits_n[q0 + gl], 1);
+                if (slot < cap) {
+                    int32_t *h = hits + ((int64_t)(q0 + gl) * cap + slot) * 3;
+                    h[0] = row.vid;
+                    h[1] = (int32_t)st.cnt;
+                    h[2] = kth;
+                }
             }
         }
+    }
+}
+
+// kth for min_match > 2: per stored hit, walk the query in order and binary-search the row.
+__global__ __launch_bounds__(kBlock) void ts_kth_fixup_kernel(
+    const Row *__restrict__ rows, const int64_t *__restrict__ keys,
+    const double *__restrict__ queries, const int64_t *__restrict__ q_offsets, int32_t min_match,
+    int32_t cap, int32_t *__restrict__ hits, const int32_t *__restrict__ hits_n) {
+    const int q = blockIdx.x;
+    const int gl = threadIdx.x & (kGroup - 1);
+    const int g = threadIdx.x / kGroup;
+    const int gshift = (threadIdx.x & 63) & ~(kGroup - 1);
+    int n = hits_n[q];
+    if (n > cap) n = cap;
+    const int64_t qo = q_offsets[q];
+    const int32_t qlen = (int32_t)(q_offsets[q + 1] - qo);
+    const double *qv = queries + qo;
+    for (int j = g; j < n; j += kGroupsPerBlock) {
+        int32_t *h = hits + ((int64_t)q * cap + j) * 3;
+        const int32_t code = h[2];
+        if (code > -2) continue;
+        const Row row = rows[-2 - code];
+        const int64_t *rk = keys + row.off;
+        int kth = TVZ_KTH_NEVER;
+        int running = 0;
+        for (int base = 0; base < qlen && kth == TVZ_KTH_NEVER; base += kGroup) {
+            const int i = base + gl;
+            bool hit = false;
+            int64_t k;
+            if (i < qlen && canon_key(qv[i], k)) {
+                int lo = 0, hi = row.len;
+                while (lo < hi) {
+                    const int mid = (lo + hi) >> 1;
+                    if (rk[mid] < k) lo = mid + 1; else hi = mid;
+                }
+                hit = lo < row.len && rk[lo] == k;
+            }
+            const uint32_t m16 = (uint32_t)(__ballot(hit) >> gshift) & 0xffffu;
+            const int c = __popc(m16);
+            if (running + c >= min_match) {
+                uint32_t m = m16;
+                for (int need = min_match - running; need > 1; --need) m &= m - 1;
+                kth = base + (__ffs(m) - 1);
+            }
+            running += c;
+        }
+        if (gl == 0) h[2] = kth;
     }
 }
 
@@ -397,20 +549,29 @@ int launch_match(tvz_corpus *c, const double *d_queries, const int64_t *d_q_offs
     TVZ_HIP(hipMemsetAsync(d_hits_n, 0, (size_t)Q * sizeof(int32_t), st));
     const int64_t n_rows = (int64_t)c->h_rows.size();
     if (n_rows == 0 || Q == 0) return TVZ_OK;
-    int slots = 64;
-    while (slots < 4 * max_query_len && slots < kMaxSlots) slots <<= 1;
-    while (slots < 2 * max_query_len) slots <<= 1;
-    const size_t lds = (size_t)slots * 12;
-    // enough blocks to fill 256 CUs several times over, but >= 4 rows per 16-lane group
-    int64_t want_chunks = std::max<int64_t>(1, 8192 / Q);
-    int64_t rpb = tvz::ceil_div(n_rows, want_chunks);
-    rpb = std::max<int64_t>(rpb, 4 * kGroupsPerBlock);
-    rpb = tvz::round_up(rpb, kGroupsPerBlock);
-    const int64_t chunks = tvz::ceil_div(n_rows, rpb);
-    hipLaunchKernelGGL(ts_match_kernel, dim3((unsigned)chunks, (unsigned)Q), dim3(kBlock), lds, st,
-                       c->rows.p, n_rows, c->keys.p, d_queries, d_q_offsets, min_match,
-                       d_exclude_ids, cap, d_hits, d_hits_n, slots, (int32_t)rpb);
+    // queries per tile: as many as keep the shared table at load <= 0.5 (at most 16)
+    int nq = max_query_len > 0 ? kTileMaxEntries / max_query_len : kTileQ;
+    nq = std::max(1, std::min(nq, kTileQ));
+    const int64_t tiles = tvz::ceil_div(Q, nq);
+    // one 1024-thread block per CU (LDS): aim at just under two full rounds of 256 blocks (a
+    // third, mostly empty round costs a whole block time), but >= 8 rows per 16-lane group so
+    // that building the tile's table (per block) stays a small part of the block's life
+    int64_t chunks = std::max<int64_t>(1, 512 / tiles);
+    chunks = std::min(chunks, std::max<int64_t>(1, n_rows / (8 * kTileGroups)));
+    const int64_t rpb = tvz::round_up(tvz::ceil_div(n_rows, chunks), kTileGroups);
+    chunks = tvz::ceil_div(n_rows, rpb);
+    if (tiles > 65535)
+        return tvz::fail(TVZ_ERR_UNSUPPORTED, "too many query tiles (%lld)", (long long)tiles);
+    hipLaunchKernelGGL(ts_match_tile_kernel, dim3((unsigned)chunks, (unsigned)tiles),
+                       dim3(kTileBlock), kTileLds, st, c->rows.p, n_rows, c->keys.p, d_queries,
+                       d_q_offsets, Q, nq, min_match, d_exclude_ids, cap, d_hits, d_hits_n,
+                       (int32_t)rpb);
     TVZ_HIP(hipGetLastError());
+    if (min_match > 2) {
+        hipLaunchKernelGGL(ts_kth_fixup_kernel, dim3((unsigned)Q), dim3(kBlock), 0, st, c->rows.p,
+                           c->keys.p, d_queries, d_q_offsets, min_match, cap, d_hits, d_hits_n);
+        TVZ_HIP(hipGetLastError());
+    }
     return TVZ_OK;
 }
 
@@ -460,8 +621,8 @@ TVZ_EXPORT int tvz_corpus_create(tvz_corpus **out, int device) {
     c->device = device;
     for (int i = 0; i < tvz_corpus::kEvents; ++i)
         TVZ_HIP(hipEventCreateWithFlags(&c->events[i], hipEventDisableTiming));
-    TVZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(ts_match_kernel),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, kMaxSlots * 12));
+    TVZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(ts_match_tile_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)kTileLds));
     if (int rc = upload_all(c)) { delete c; return rc; }
     *out = c;
     return TVZ_OK;
