@@ -17,6 +17,8 @@
 //   the get_scene_score epilogue (mafd, diff, float32 clip, threshold).
 // Kernel 1g luma_sad_generic_kernel   same structure on 4-byte granules for padded
 //   rows / unaligned planes (slower, identical results).
+#include <algorithm>
+
 #include "tvz_common.h"
 
 namespace {
@@ -323,18 +325,17 @@ bool flat_ok(const void *p, int64_t fs, int64_t rs, int32_t H, int32_t W) {
            (reinterpret_cast<uintptr_t>(p) % 16) == 0;
 }
 
-// Shape choice for the flat kernel: the widest strip / longest time chunk that still gives the
-// chip >= 16 waves per CU (U=8 runs at 4 waves per SIMD).  Big batches (10k x 1080p) get
-// U=8, tc=256 (6.8 TB/s measured); micro-batches fall back to narrower strips so that all 256
-// CUs have work.
+// Shape choice for the flat kernel, from the sweeps in profiles/r1_microbatch_*.txt: the widest
+// strip (U=8, 8 KiB per wave and frame) wins at every batch size and resolution; the time chunk
+// is sized so that the launch has about 1,000 waves (4 per CU) - fewer, longer serial walks beat
+// more, shorter ones until the halo re-read (1/tc) stops mattering - and is capped at 256 frames.
 void auto_shape(int64_t T, int64_t n16, int &U, int &tc) {
-    static const int cand[][2] = {{8, 256}, {8, 128}, {8, 64}, {4, 64}, {2, 64}, {1, 64}};
-    const int64_t want = 256 * 16;
-    for (auto &c : cand) {
-        U = c[0];
-        tc = c[1];
-        if (tvz::ceil_div(n16, (int64_t)kWave * U) * tvz::ceil_div(T, tc) >= want) return;
-    }
+    U = 8;
+    const int64_t strips = tvz::ceil_div(n16, (int64_t)kWave * U);
+    const int64_t chunks = std::max<int64_t>(1, 1024 / std::max<int64_t>(1, strips));
+    const int64_t want = tvz::ceil_div(T, chunks);
+    tc = 8;
+    while (tc < 256 && tc < want) tc *= 2;
 }
 
 Plan make_plan(bool flat, int64_t T, int32_t H, int32_t W) {
@@ -419,7 +420,8 @@ SelectParams make_sp(int32_t H, int32_t W, int32_t bitdepth, double thr, double 
 // Not part of the stable ABI: kernel-shape knobs for A/B runs inside one process.
 TVZ_EXPORT int tvz_scene_set_tuning(int U, int tc, int nt) {
     TVZ_REQUIRE(U == 0 || U == 1 || U == 2 || U == 4 || U == 8, "U must be 0 (auto), 1, 2, 4 or 8");
-    TVZ_REQUIRE(tc >= 0 && tc % 64 == 0, "tc must be 0 (auto) or a positive multiple of 64");
+    TVZ_REQUIRE(tc == 0 || tc == 8 || tc == 16 || tc == 32 || (tc > 0 && tc % 64 == 0),
+                "tc must be 0 (auto), 8, 16, 32 or a positive multiple of 64");
     g_tune.U = U;
     g_tune.tc = tc;
     g_tune.nt = nt ? 1 : 0;
