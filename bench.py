@@ -158,14 +158,16 @@ def bench_match(args, rank, world, dev):
     return {"value": pairs / wall, "unit": "pairs/s", "corpus_videos": C, "queries_per_batch": Q,
             "mean_cuts_per_video": round(mean_len, 1), "min_match": 2, "steps": args.match_steps,
             "ms_per_batch": wall * 1e3 / args.match_steps,
-            "collective": "all_gather [Q,64,3] int32 + all_reduce [Q] per batch" if world > 1 else "none",
+            "collective": "one all_gather of [Q,65,3] int32 per batch (top-64 + hit totals)" if world > 1 else "none",
             "queries_with_hits": n_dups,
             "find_duplicates_latency_ms_q1": round(float(np.median(lat)) * 1e3, 3),
             "roofline": {"bound": "hbm", "achieved": pairs * bytes_per_pair / wall / 1e9 / world,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": pairs * bytes_per_pair / wall / 1e9 / world / HBM_PEAK_GBS,
                          "traffic": None,
-                         "note": "nominal 8*L+8 B per pair per GPU; with Q-batching the corpus is re-read from L2/MALL, not HBM"}}
+                         "note": "nominal 8*L+8 B per pair per GPU (SURVEY 8d). A 16-query tile shares each corpus "
+                                 "byte on chip, so real HBM traffic is ~1/16 of nominal and frac can exceed 1: the "
+                                 "kernel is LDS/issue-bound, not HBM-bound"}}
 
 
 def pmc_traffic(kernel: str, T: int):

@@ -138,7 +138,7 @@ int tvz_corpus_stats(tvz_corpus *c, int64_t *n_rows, int64_t *n_keys, int64_t *a
  *   d_exclude_ids : int32[Q] or NULL
  *   d_hits      : int32[Q][cap][3] out;  d_hits_n : int32[Q] out = number of
  *                 hits found (may exceed cap; only the first cap are stored)
- *   max_query_len : upper bound on any query's length (sizes the LDS table) */
+ *   max_query_len : upper bound on any query's length (<= 4095; sizes the query tile) */
 int tvz_match(tvz_corpus *c, const double *d_queries, const int64_t *d_q_offsets,
               int32_t Q, int32_t max_query_len, int32_t min_match,
               const int32_t *d_exclude_ids, int32_t cap,
@@ -159,6 +159,16 @@ int tvz_find_duplicates(tvz_corpus *c, const double *h_query, int64_t n, int32_t
  *   d_topk  : int32[Q][k][3] out, padded with (-1, 0, TVZ_KTH_NEVER). */
 int tvz_topk(const int32_t *d_lists, const int32_t *d_lists_n, int32_t n_lists, int32_t Q,
              int32_t cap, int32_t k, int32_t *d_topk, void *hip_stream);
+
+/* Sharded form (one process per GPU): each rank reduces its local hit lists to
+ *   d_out : int32[Q][k+1][3] = its k best hits + a row (-1, n_local_hits, TVZ_KTH_NEVER),
+ * the ranks all-gather those blocks (RCCL), and every rank merges
+ *   d_gathered : int32[n_ranks][Q][k+1][3]  ->  d_topk int32[Q][k][3], d_totals int32[Q]
+ * (d_totals = hits over all shards; > k means the merged list is truncated). */
+int tvz_topk_shard(const int32_t *d_hits, const int32_t *d_hits_n, int32_t Q, int32_t cap,
+                   int32_t k, int32_t *d_out, void *hip_stream);
+int tvz_topk_merge(const int32_t *d_gathered, int32_t n_ranks, int32_t Q, int32_t k,
+                   int32_t *d_topk, int32_t *d_totals, void *hip_stream);
 
 #ifdef __cplusplus
 }

@@ -123,8 +123,8 @@ def test_ragged_rows_and_long_queries(dc):
         rows.append((v + 10, np.round(rng.uniform(0, 500, L), 2).tolist()))
     dc.upload(rows)
     ids, offs, keys = tc.rows_to_csr(rows)
-    queries = [np.round(rng.uniform(0, 500, n), 2) for n in (1, 16, 17, 300, 1500, 4096)]
-    for mm in (1, 2, 4):
+    queries = [np.round(rng.uniform(0, 500, n), 2) for n in (1, 16, 17, 300, 1500, 4095)]
+    for mm in (1, 2, 4, 5, 6, 9):
         _check_batch(dc, ids, offs, keys, queries, mm)
 
 
@@ -233,3 +233,40 @@ def test_config3_size_round_trip_property(dc):
         cnt, kth = oracle.match_kth_csr(row, offs, keys, 2)
         exp = sorted((int(ids[i]), int(cnt[i]), int(kth[i])) for i in range(5000) if cnt[i] >= 2)
         assert dc.find_duplicates(row, 2, with_kth=True) == exp
+
+
+def test_sharded_pipeline_on_one_gpu(dc):
+    """The N-rank data path (shard -> match -> topk_shard -> [all-gather] -> topk_merge) with the
+    real HIP backend, the ranks being R corpus handles on this one GPU; the gather is a stack."""
+    from tvidz_amd import sharded
+    C, Q, k, mm = 3000, 12, 16, 2
+    ids, offs, keys = synth.synth_timestamp_corpus(C, seed=31, mean_len=60, dup_frac=0.03)
+    queries = synth.synth_queries(ids, offs, keys, Q, seed=4, mean_len=60)
+    d_q, d_off, max_len = tc.pack_queries(queries, DEV)
+    excl = torch.tensor([int(ids[(5 * i) % C]) for i in range(Q)], dtype=torch.int32, device=DEV)
+    for R in (1, 3, 8):
+        blocks = []
+        for r in range(R):
+            s_ids, s_offs, s_keys = sharded.shard_csr(ids, offs, keys, r, R)
+            shard = tc.DeviceCorpus(0)
+            shard.upload_csr(s_ids, s_offs, s_keys)
+            hits, n = shard.match(d_q, d_off, max_len, mm, 64, d_exclude_ids=excl)
+            blocks.append(tc.topk_shard(hits, n, k))
+            torch.cuda.synchronize()
+            shard.close()
+        merged, totals = tc.topk_merge(torch.stack(blocks).contiguous(), k)
+        merged, totals = merged.cpu().numpy(), totals.cpu().numpy()
+        for qi, q in enumerate(queries):
+            cnt, kth = oracle.match_kth_csr(q, offs, keys, mm)
+            rows = [(int(ids[c]), int(cnt[c]), int(kth[c])) for c in range(C)
+                    if cnt[c] >= mm and ids[c] != int(excl[qi])]
+            assert int(totals[qi]) == len(rows)
+            exp = sorted(rows, key=lambda h: (h[2], h[0], h[1]))[:k]
+            exp += [(-1, 0, NEVER)] * (k - len(exp))
+            assert [tuple(int(x) for x in r) for r in merged[qi]] == exp, (R, qi)
+        v = sharded.verdicts_from_topk(merged)
+        for qi, q in enumerate(queries):
+            cnt, kth = oracle.match_kth_csr(q, offs, keys, mm)
+            kstar, dup = oracle.verdict_from_kth(ids, kth, self_id=int(excl[qi]))
+            if not v[qi][2]:
+                assert (v[qi][0], v[qi][1]) == (kstar, dup)

@@ -41,21 +41,31 @@ class OracleBackend:
                 hits[qi, j] = torch.tensor(r, dtype=torch.int32)
         return hits, n
 
-    def topk(self, lists, lists_n, k):
-        if lists.dim() == 3:
-            lists = lists.unsqueeze(0)
-            lists_n = lists_n.unsqueeze(0) if lists_n is not None else None
-        R, Q, cap, _ = lists.shape
+    @staticmethod
+    def _best(ent, k):
+        ent = sorted(ent, key=lambda h: (h[2], h[0], h[1]))[:k]
+        return ent + [(-1, 0, NEVER)] * (k - len(ent))
+
+    def topk_shard(self, hits, hits_n, k):
+        Q, cap, _ = hits.shape
+        out = torch.empty((Q, k + 1, 3), dtype=torch.int32)
+        for q in range(Q):
+            m = min(int(hits_n[q]), cap)
+            ent = [tuple(int(x) for x in e) for e in hits[q, :m]]
+            out[q] = torch.tensor(self._best(ent, k) + [(-1, int(hits_n[q]), NEVER)], dtype=torch.int32)
+        return out
+
+    def topk_merge(self, gathered, k):
+        R, Q, k1, _ = gathered.shape
         out = torch.empty((Q, k, 3), dtype=torch.int32)
+        totals = torch.zeros(Q, dtype=torch.int32)
         for q in range(Q):
             ent = []
             for r in range(R):
-                m = cap if lists_n is None else min(int(lists_n[r, q]), cap)
-                ent += [tuple(int(x) for x in e) for e in lists[r, q, :m] if int(e[0]) >= 0]
-            ent = sorted(ent, key=lambda h: (h[2], h[0], h[1]))[:k]
-            ent += [(-1, 0, NEVER)] * (k - len(ent))
-            out[q] = torch.tensor(ent, dtype=torch.int32)
-        return out
+                ent += [tuple(int(x) for x in e) for e in gathered[r, q, :k] if int(e[0]) >= 0]
+                totals[q] += int(gathered[r, q, k, 1])
+            out[q] = torch.tensor(self._best(ent, k), dtype=torch.int32)
+        return out, totals
 
 
 def _expected(ids, offs, keys, queries, mm, k, excl=None):

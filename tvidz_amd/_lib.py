@@ -44,6 +44,10 @@ SIGNATURES = {
                                       C.POINTER(C.c_int64)]),
     "tvz_topk": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                            C.c_void_p, C.c_void_p]),
+    "tvz_topk_shard": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
+                                 C.c_void_p]),
+    "tvz_topk_merge": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
+                                 C.c_void_p]),
     # not part of the stable ABI (kernel-shape A/B knob)
     "tvz_scene_set_tuning": (C.c_int, [C.c_int, C.c_int, C.c_int]),
 }

@@ -146,6 +146,32 @@ def topk(lists: torch.Tensor, lists_n: Optional[torch.Tensor], k: int,
     return out
 
 
+def topk_shard(hits: torch.Tensor, hits_n: torch.Tensor, k: int,
+               stream: Optional[torch.cuda.Stream] = None) -> torch.Tensor:
+    """Local lists -> int32 [Q,k+1,3]: the k best + a (-1, n_hits, NEVER) totals row."""
+    Q, cap, _ = hits.shape
+    out = torch.empty((Q, k + 1, 3), dtype=torch.int32, device=hits.device)
+    s = stream if stream is not None else torch.cuda.current_stream(hits.device)
+    with torch.cuda.device(hits.device):
+        _lib.check(_lib.load().tvz_topk_shard(hits.data_ptr(), hits_n.data_ptr(), Q, cap, k,
+                                              out.data_ptr(), s.cuda_stream))
+    return out
+
+
+def topk_merge(gathered: torch.Tensor, k: int, stream: Optional[torch.cuda.Stream] = None):
+    """All-gathered int32 [R,Q,k+1,3] -> (merged int32 [Q,k,3], totals int32 [Q])."""
+    R, Q, k1, _ = gathered.shape
+    if k1 != k + 1 or not gathered.is_contiguous():
+        raise RuntimeError("gathered must be contiguous [R,Q,k+1,3]")
+    out = torch.empty((Q, k, 3), dtype=torch.int32, device=gathered.device)
+    totals = torch.empty(Q, dtype=torch.int32, device=gathered.device)
+    s = stream if stream is not None else torch.cuda.current_stream(gathered.device)
+    with torch.cuda.device(gathered.device):
+        _lib.check(_lib.load().tvz_topk_merge(gathered.data_ptr(), R, Q, k, out.data_ptr(),
+                                              totals.data_ptr(), s.cuda_stream))
+    return out, totals
+
+
 def pack_queries(queries: Sequence[Sequence[float]], device) -> Tuple[torch.Tensor, torch.Tensor, int]:
     """Host lists -> (float64 keys, int64 offsets, max_len) on `device`."""
     lens = np.fromiter((len(q) for q in queries), dtype=np.int64, count=len(queries))

@@ -18,9 +18,9 @@
 //   of the tile - the Q-tile plays the role a GEMM tile plays: every corpus byte loaded is reused
 //   16 times on chip.  A chain hit bumps the (group, query) counter and the two smallest matching
 //   positions with LDS atomics; after the row, lane q of the group emits query q's hit
-//   (video_id, count, kth).  kth = min_match-th smallest matching position: taken from the two
-//   tracked minima for min_match <= 2 (the driver's case), by ts_kth_fixup_kernel (binary search of
-//   the sorted row per query position) for min_match > 2.  Integer/LDS-bound: no MFMA.
+//   (video_id, count, kth).  kth = min_match-th smallest matching position: read from the five
+//   tracked minima for min_match <= 5 (the reference's default 5 and the driver's 2), by ts_kth_fixup_kernel (binary search of
+//   the sorted row per query position) for min_match > 5.  Integer/LDS-bound: no MFMA.
 // Kernel ts_topk_kernel: per query bitonic selection of the k best hits ordered by
 //   (kth, video_id, count) over one or several (all-gathered) hit lists.
 #include <algorithm>
@@ -38,7 +38,7 @@ constexpr int kBlock = 256;
 constexpr int kGroup = 16;                  // lanes per corpus row
 constexpr int kGroupsPerBlock = kBlock / kGroup;
 constexpr int64_t kEmpty = 0x7ff8dead00000000LL;  // a NaN pattern: never a canonical key
-constexpr int kMaxQueryLen = 4096;          // one maximal query fills the tile table to load 0.5
+constexpr int kMaxQueryLen = 4095;          // positions 0..4094 fit 12 bits with 0xfff as "none"
 
 struct Row {
     int64_t off;
@@ -84,16 +84,34 @@ constexpr int kTilePairs = kTileSlots / 2;
 constexpr int kTileMaxEntries = 4096;                 // load factor <= 0.25
 constexpr uint32_t kEnd = 0xffffu;
 constexpr uint32_t kFree = 0xffffffffu;
-constexpr uint32_t kInf = 0xffffffffu;
-static_assert(kTileMaxEntries == kMaxQueryLen, "a single maximal query must fit one tile");
+static_assert(kTileMaxEntries >= kMaxQueryLen, "a single maximal query must fit one tile");
 constexpr int kRing = 128;                            // per-wave slow-path ring (entries)
 constexpr size_t kTileLds = (size_t)kTileSlots * 4 + (size_t)kTileMaxEntries * 8 +
                             (size_t)kTileMaxEntries * 4 + (size_t)kTileGroups * kTileQ * 3 * 4 +
                             (size_t)(kTileBlock / 64) * kRing * 12;
 
-struct PairState {  // per (row group, query of the tile), lives in LDS
-    uint32_t cnt, m1, m2;   // hits, smallest and second smallest matching query position
-};
+// Per (row group, query of the tile) state in LDS: a hit counter and the FIVE smallest matching
+// query positions, packed as 5 x 12 bits (ascending from bit 0, 0xfff = none) in one 64-bit word
+// updated with a CAS loop.  kth for min_match <= 5 (the reference's default and the driver's 2)
+// is read straight from it.
+constexpr int kTop = 5;
+constexpr unsigned long long kTopNone = 0x0fffffffffffffffULL;   // 5 fields of 0xfff
+
+__device__ __forceinline__ unsigned long long top5_insert(unsigned long long p, uint32_t x) {
+    uint32_t a[kTop];
+#pragma unroll
+    for (int i = 0; i < kTop; ++i) a[i] = (uint32_t)(p >> (12 * i)) & 0xfffu;
+#pragma unroll
+    for (int i = 0; i < kTop; ++i) {      // insertion network: keep the smaller, carry the larger
+        const uint32_t lo = a[i] < x ? a[i] : x;
+        x = a[i] < x ? x : a[i];
+        a[i] = lo;
+    }
+    unsigned long long r = 0;
+#pragma unroll
+    for (int i = 0; i < kTop; ++i) r |= (unsigned long long)a[i] << (12 * i);
+    return r;
+}
 
 // pair index (13 bits) and tag (16 bits, never 0xffff) from one mix of the key.  Only full-rate
 // VALU ops: v_mul_u32_u24 instead of the quarter-rate v_mul_lo_u32.  Quality only affects speed
@@ -112,14 +130,29 @@ __device__ __forceinline__ void hash_pair_tag(int64_t k, uint32_t &pair, uint32_
 static_assert((1 << 13) == kTilePairs, "pair bits must match kTilePairs");
 
 // one matching (query, position) entry: count it and keep the two smallest positions
-__device__ __forceinline__ void account(PairState *gst, uint32_t ent) {
-    PairState *st = gst + ((ent >> 12) & 15u);
+// TOP5 = false (min_match <= 2, the streaming driver's case): the 8-byte word holds the smallest
+// and second smallest position as two u32 updated with two LDS atomicMin (7 % faster).
+template <bool TOP5>
+__device__ __forceinline__ void account(uint32_t *cnt, unsigned long long *top, uint32_t ent) {
+    const uint32_t q = (ent >> 12) & 15u;
     const uint32_t pos = ent & 0xfffu;
-    atomicAdd(&st->cnt, 1u);
-    const uint32_t old = atomicMin(&st->m1, pos);
-    atomicMin(&st->m2, old > pos ? old : pos);
+    atomicAdd(&cnt[q], 1u);
+    if constexpr (!TOP5) {
+        uint32_t *m = reinterpret_cast<uint32_t *>(&top[q]);
+        const uint32_t old = atomicMin(&m[0], pos);
+        atomicMin(&m[1], old > pos ? old : pos);   // the larger of two distinct hits: >= 2nd smallest
+        return;
+    }
+    unsigned long long seen = top[q];
+    while (true) {
+        if (((uint32_t)(seen >> (12 * (kTop - 1))) & 0xfffu) <= pos) break;   // not among the 5 smallest
+        const unsigned long long old = atomicCAS(&top[q], seen, top5_insert(seen, pos));
+        if (old == seen) break;
+        seen = old;
+    }
 }
 
+template <bool TOP5>
 __global__ __launch_bounds__(kTileBlock) void ts_match_tile_kernel(
     const Row *__restrict__ rows, int64_t n_rows, const int64_t *__restrict__ keys,
     const double *__restrict__ queries, const int64_t *__restrict__ q_offsets, int32_t Q,
@@ -129,14 +162,18 @@ __global__ __launch_bounds__(kTileBlock) void ts_match_tile_kernel(
     uint32_t *slots = reinterpret_cast<uint32_t *>(smem);
     int64_t *ekey = reinterpret_cast<int64_t *>(smem + (size_t)kTileSlots * 4);
     uint32_t *epack = reinterpret_cast<uint32_t *>(ekey + kTileMaxEntries);
-    PairState *state = reinterpret_cast<PairState *>(epack + kTileMaxEntries);
+    unsigned long long *top = reinterpret_cast<unsigned long long *>(epack + kTileMaxEntries);
+    uint32_t *cnt = reinterpret_cast<uint32_t *>(top + kTileGroups * kTileQ);
     __shared__ int64_t s_qoff[kTileQ + 1];
 
     const int q0 = blockIdx.y * nq_tile;
     const int nq = (Q - q0 < nq_tile) ? Q - q0 : nq_tile;
     if (threadIdx.x <= nq) s_qoff[threadIdx.x] = q_offsets[q0 + threadIdx.x];
     for (int i = threadIdx.x; i < kTileSlots; i += kTileBlock) slots[i] = kFree;
-    for (int i = threadIdx.x; i < kTileGroups * kTileQ; i += kTileBlock) state[i] = PairState{0, kInf, kInf};
+    for (int i = threadIdx.x; i < kTileGroups * kTileQ; i += kTileBlock) {
+        top[i] = TOP5 ? kTopNone : ~0ULL;
+        cnt[i] = 0;
+    }
     __syncthreads();
     const int64_t qbase = s_qoff[0];
     int total = (int)(s_qoff[nq] - qbase);
@@ -176,7 +213,8 @@ __global__ __launch_bounds__(kTileBlock) void ts_match_tile_kernel(
 
     const int gl = threadIdx.x & (kGroup - 1);
     const int g = threadIdx.x / kGroup;
-    PairState *gst = state + g * kTileQ;
+    uint32_t *gcnt = cnt + g * kTileQ;
+    unsigned long long *gtop = top + g * kTileQ;
     const bool my_q = gl < nq;
     const int32_t excl = (exclude_ids && my_q) ? exclude_ids[q0 + gl] : -1;
     const bool use_excl = exclude_ids != nullptr;
@@ -196,10 +234,11 @@ __global__ __launch_bounds__(kTileBlock) void ts_match_tile_kernel(
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const uint32_t gw = (threadIdx.x >> 4) & 3u;                 // group within the wave
-    int64_t *qk = reinterpret_cast<int64_t *>(state + kTileGroups * kTileQ) + wave * kRing;
-    uint32_t *qm = reinterpret_cast<uint32_t *>(reinterpret_cast<int64_t *>(state + kTileGroups * kTileQ) +
-                                                (kTileBlock / 64) * kRing) + wave * kRing;
-    PairState *wst = state + wave * 4 * kTileQ;                   // the wave's 4 groups
+    int64_t *qbase_k = reinterpret_cast<int64_t *>(cnt + kTileGroups * kTileQ);
+    int64_t *qk = qbase_k + wave * kRing;
+    uint32_t *qm = reinterpret_cast<uint32_t *>(qbase_k + (kTileBlock / 64) * kRing) + wave * kRing;
+    uint32_t *wcnt = cnt + wave * 4 * kTileQ;                     // the wave's 4 groups
+    unsigned long long *wtop = top + wave * 4 * kTileQ;
     uint32_t qhead = 0, qtail = 0;                                // wave-uniform
 
     auto drain = [&](uint32_t n) {                                // n <= 64 pending entries
@@ -209,7 +248,8 @@ __global__ __launch_bounds__(kTileBlock) void ts_match_tile_kernel(
             const uint32_t m = qm[idx];
             const uint32_t tag = m & 0xffffu;
             uint32_t pair = (m >> 16) & (uint32_t)(kTilePairs - 1);
-            PairState *st = wst + (m >> 29) * kTileQ;
+            uint32_t *scnt = wcnt + (m >> 29) * kTileQ;
+            unsigned long long *stop = wtop + (m >> 29) * kTileQ;
             uint32_t e = kEnd;
             while (true) {      // first slot of the probe sequence that is free or carries the tag
                 const uint2 w = pairs[pair];
@@ -221,7 +261,7 @@ __global__ __launch_bounds__(kTileBlock) void ts_match_tile_kernel(
             }
             while (e != kEnd) {  // every (query, position) entry of that slot; verify the full key
                 const uint32_t ent = epack[e];
-                if (ekey[e] == k) account(st, ent);
+                if (ekey[e] == k) account<TOP5>(scnt, stop, ent);
                 e = ent >> 16;
             }
         }
@@ -273,19 +313,23 @@ __global__ __launch_bounds__(kTileBlock) void ts_match_tile_kernel(
         if (qtail != qhead) drain(qtail - qhead);                 // row boundary: settle the counts
         // lane q of the group owns query q of the tile (LDS ops of a wave complete in order)
         if (my_q & live) {
-            const PairState st = gst[gl];
-            if (st.cnt) gst[gl] = PairState{0, kInf, kInf};
-            if ((int64_t)st.cnt >= (int64_t)min_match && !(use_excl && row.vid == excl)) {
+            const uint32_t c = gcnt[gl];
+            const unsigned long long t5 = gtop[gl];
+            if (c) {
+                gcnt[gl] = 0;
+                gtop[gl] = TOP5 ? kTopNone : ~0ULL;
+            }
+            if ((int64_t)c >= (int64_t)min_match && !(use_excl && row.vid == excl)) {
                 int32_t kth;
                 if (min_match <= 0) kth = -1;
-                else if (min_match == 1) kth = (int32_t)st.m1;
-                else if (min_match == 2) kth = (int32_t)st.m2;
+                else if (!TOP5) kth = (int32_t)(uint32_t)(min_match == 1 ? t5 : t5 >> 32);
+                else if (min_match <= kTop) kth = (int32_t)((t5 >> (12 * (min_match - 1))) & 0xfffu);
                 else kth = -2 - (int32_t)r;          // resolved by ts_kth_fixup_kernel
                 const int slot = atomicAdd(&hits_n[q0 + gl], 1);
                 if (slot < cap) {
                     int32_t *h = hits + ((int64_t)(q0 + gl) * cap + slot) * 3;
                     h[0] = row.vid;
-                    h[1] = (int32_t)st.cnt;
+                    h[1] = (int32_t)c;
                     h[2] = kth;
                 }
             }
@@ -293,7 +337,7 @@ __global__ __launch_bounds__(kTileBlock) void ts_match_tile_kernel(
     }
 }
 
-// kth for min_match > 2: per stored hit, walk the query in order and binary-search the row.
+// kth for min_match > 5: per stored hit, walk the query in order and binary-search the row.
 __global__ __launch_bounds__(kBlock) void ts_kth_fixup_kernel(
     const Row *__restrict__ rows, const int64_t *__restrict__ keys,
     const double *__restrict__ queries, const int64_t *__restrict__ q_offsets, int32_t min_match,
@@ -371,11 +415,16 @@ __device__ void bitonic_sort(uint64_t *key, int32_t *cnt, int n /* power of two 
 __global__ __launch_bounds__(kBlock) void ts_topk_kernel(const int32_t *__restrict__ lists,
                                                          const int32_t *__restrict__ lists_n,
                                                          int32_t n_lists, int32_t Q, int32_t cap,
-                                                         int32_t k, int32_t *__restrict__ topk) {
+                                                         int32_t k, int32_t *__restrict__ topk,
+                                                         int32_t mode, int32_t *__restrict__ totals) {
+    // mode 0: plain.  mode 1 (shard side): the output has k+1 rows per query, row k carries the
+    // true number of hits as (-1, n, NEVER) so one all-gather moves lists and totals together.
+    // mode 2 (merge side): every input list ends with such a row; it is summed into totals[q].
     __shared__ uint64_t key[kSortCap];
     __shared__ int32_t cnt[kSortCap];
     const int q = blockIdx.x;
     int pos = 0;  // block-uniform fill level
+    long long total = 0;
     auto sort_and_keep = [&]() {
         int P = 2;
         while (P < pos) P <<= 1;
@@ -385,8 +434,13 @@ __global__ __launch_bounds__(kBlock) void ts_topk_kernel(const int32_t *__restri
     };
     for (int l = 0; l < n_lists; ++l) {
         int n = lists_n ? lists_n[(int64_t)l * Q + q] : cap;
-        if (n > cap) n = cap;
         const int32_t *src = lists + ((int64_t)l * Q + q) * (int64_t)cap * 3;
+        if (mode == 1) total += n;
+        if (n > cap) n = cap;
+        if (mode == 2) {
+            n = cap - 1;
+            total += src[(cap - 1) * 3 + 1];
+        }
         int j = 0;
         while (j < n) {
             int m = n - j;
@@ -404,8 +458,18 @@ __global__ __launch_bounds__(kBlock) void ts_topk_kernel(const int32_t *__restri
     }
     __syncthreads();
     sort_and_keep();
+    const int orows = (mode == 1) ? k + 1 : k;
+    if (threadIdx.x == 0) {
+        const int32_t t = total > 0x7fffffffLL ? 0x7fffffff : (int32_t)total;
+        if (mode == 1) {
+            int32_t *o = topk + ((int64_t)q * orows + k) * 3;
+            o[0] = -1; o[1] = t; o[2] = TVZ_KTH_NEVER;
+        } else if (mode == 2 && totals) {
+            totals[q] = t;
+        }
+    }
     for (int i = threadIdx.x; i < k; i += kBlock) {
-        int32_t *o = topk + ((int64_t)q * k + i) * 3;
+        int32_t *o = topk + ((int64_t)q * orows + i) * 3;
         const uint64_t kk = (i < pos) ? key[i] : ~0ULL;
         if (kk == ~0ULL) {
             o[0] = -1; o[1] = 0; o[2] = TVZ_KTH_NEVER;
@@ -562,12 +626,18 @@ int launch_match(tvz_corpus *c, const double *d_queries, const int64_t *d_q_offs
     chunks = tvz::ceil_div(n_rows, rpb);
     if (tiles > 65535)
         return tvz::fail(TVZ_ERR_UNSUPPORTED, "too many query tiles (%lld)", (long long)tiles);
-    hipLaunchKernelGGL(ts_match_tile_kernel, dim3((unsigned)chunks, (unsigned)tiles),
-                       dim3(kTileBlock), kTileLds, st, c->rows.p, n_rows, c->keys.p, d_queries,
-                       d_q_offsets, Q, nq, min_match, d_exclude_ids, cap, d_hits, d_hits_n,
-                       (int32_t)rpb);
+    if (min_match <= 2)
+        hipLaunchKernelGGL(ts_match_tile_kernel<false>, dim3((unsigned)chunks, (unsigned)tiles),
+                           dim3(kTileBlock), kTileLds, st, c->rows.p, n_rows, c->keys.p, d_queries,
+                           d_q_offsets, Q, nq, min_match, d_exclude_ids, cap, d_hits, d_hits_n,
+                           (int32_t)rpb);
+    else
+        hipLaunchKernelGGL(ts_match_tile_kernel<true>, dim3((unsigned)chunks, (unsigned)tiles),
+                           dim3(kTileBlock), kTileLds, st, c->rows.p, n_rows, c->keys.p, d_queries,
+                           d_q_offsets, Q, nq, min_match, d_exclude_ids, cap, d_hits, d_hits_n,
+                           (int32_t)rpb);
     TVZ_HIP(hipGetLastError());
-    if (min_match > 2) {
+    if (min_match > kTop) {
         hipLaunchKernelGGL(ts_kth_fixup_kernel, dim3((unsigned)Q), dim3(kBlock), 0, st, c->rows.p,
                            c->keys.p, d_queries, d_q_offsets, min_match, cap, d_hits, d_hits_n);
         TVZ_HIP(hipGetLastError());
@@ -621,7 +691,9 @@ TVZ_EXPORT int tvz_corpus_create(tvz_corpus **out, int device) {
     c->device = device;
     for (int i = 0; i < tvz_corpus::kEvents; ++i)
         TVZ_HIP(hipEventCreateWithFlags(&c->events[i], hipEventDisableTiming));
-    TVZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(ts_match_tile_kernel),
+    TVZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(ts_match_tile_kernel<false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)kTileLds));
+    TVZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(ts_match_tile_kernel<true>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)kTileLds));
     if (int rc = upload_all(c)) { delete c; return rc; }
     *out = c;
@@ -831,7 +903,33 @@ TVZ_EXPORT int tvz_topk(const int32_t *d_lists, const int32_t *d_lists_n, int32_
     TVZ_REQUIRE((d_lists || cap == 0) && d_topk, "NULL argument");
     hipLaunchKernelGGL(ts_topk_kernel, dim3((unsigned)Q), dim3(kBlock), 0,
                        reinterpret_cast<hipStream_t>(hip_stream), d_lists, d_lists_n, n_lists, Q,
-                       cap, k, d_topk);
+                       cap, k, d_topk, 0, nullptr);
+    TVZ_HIP(hipGetLastError());
+    return TVZ_OK;
+}
+
+TVZ_EXPORT int tvz_topk_shard(const int32_t *d_hits, const int32_t *d_hits_n, int32_t Q,
+                              int32_t cap, int32_t k, int32_t *d_out, void *hip_stream) {
+    TVZ_REQUIRE(Q >= 0 && cap >= 0, "bad list shape");
+    TVZ_REQUIRE(k >= 1 && k <= kSortCap / 2, "k=%d out of range [1, %d]", k, kSortCap / 2);
+    if (Q == 0) return TVZ_OK;
+    TVZ_REQUIRE((d_hits || cap == 0) && d_hits_n && d_out, "NULL argument");
+    hipLaunchKernelGGL(ts_topk_kernel, dim3((unsigned)Q), dim3(kBlock), 0,
+                       reinterpret_cast<hipStream_t>(hip_stream), d_hits, d_hits_n, 1, Q, cap, k,
+                       d_out, 1, nullptr);
+    TVZ_HIP(hipGetLastError());
+    return TVZ_OK;
+}
+
+TVZ_EXPORT int tvz_topk_merge(const int32_t *d_gathered, int32_t n_ranks, int32_t Q, int32_t k,
+                              int32_t *d_topk, int32_t *d_totals, void *hip_stream) {
+    TVZ_REQUIRE(n_ranks >= 1 && Q >= 0, "bad list shape");
+    TVZ_REQUIRE(k >= 1 && k <= kSortCap / 2, "k=%d out of range [1, %d]", k, kSortCap / 2);
+    if (Q == 0) return TVZ_OK;
+    TVZ_REQUIRE(d_gathered && d_topk, "NULL argument");
+    hipLaunchKernelGGL(ts_topk_kernel, dim3((unsigned)Q), dim3(kBlock), 0,
+                       reinterpret_cast<hipStream_t>(hip_stream), d_gathered, nullptr, n_ranks, Q,
+                       k + 1, k, d_topk, 2, d_totals);
     TVZ_HIP(hipGetLastError());
     return TVZ_OK;
 }

@@ -3,7 +3,7 @@
 The candidate axis shards naturally: rows are independent.  Each rank (one process per GPU)
 holds a contiguous range of the `video_timestamps` rows balanced by key count, queries are
 replicated (tiny), every rank runs the local match + per-shard top-k, and ONE all-gather of
-[Q, k] int32 triples (RCCL over xGMI; <= 768 B per query per rank, latency-bound) is followed by
+[Q, k+1] int32 triples (the extra row carries the shard's hit total) (RCCL over xGMI; <= 768 B per query per rank, latency-bound) is followed by
 the same k-way merge on every rank.  There is no other collective on the data path.
 
 The reference has no counterpart (it scans one Postgres table in one Python process,
@@ -40,7 +40,7 @@ def shard_csr(ids: np.ndarray, offsets: np.ndarray, keys: np.ndarray, rank: int,
 
 
 class HipBackend:
-    """The product backend: DeviceCorpus.match + tvz_topk on this rank's GPU."""
+    """The product backend: DeviceCorpus.match + the top-k kernels on this rank's GPU."""
 
     def __init__(self, corpus):
         from . import corpus as tc
@@ -50,12 +50,16 @@ class HipBackend:
     def match(self, d_q, d_off, max_len, min_match, cap, d_excl):
         return self.corpus.match(d_q, d_off, max_len, min_match, cap, d_exclude_ids=d_excl)
 
-    def topk(self, lists, lists_n, k):
-        return self._tc.topk(lists, lists_n, k)
+    def topk_shard(self, hits, hits_n, k):
+        return self._tc.topk_shard(hits, hits_n, k)
+
+    def topk_merge(self, gathered, k):
+        return self._tc.topk_merge(gathered, k)
 
 
 class ShardedMatcher:
-    """rank-local shard + all-gather of per-shard top-k + identical merge on every rank."""
+    """rank-local shard + ONE all-gather of per-shard top-k (+ hit totals) + identical merge on
+    every rank."""
 
     def __init__(self, backend, k: int = 64, cap: int = 1024, group=None):
         self.backend = backend
@@ -71,16 +75,16 @@ class ShardedMatcher:
         every rank.  total_hits > k means the list was truncated to the k best."""
         hits, n = self.backend.match(d_queries, d_q_offsets, max_query_len, min_match, self.cap,
                                      d_exclude_ids)
-        local = self.backend.topk(hits, n, self.k)
-        if self.world == 1:
-            return local, n
+        local = self.backend.topk_shard(hits, n, self.k)            # [Q, k+1, 3]
         Q = local.shape[0]
-        # dim-0 concatenation is the layout both RCCL and gloo accept for all_gather_into_tensor
-        gathered = torch.empty((self.world * Q, self.k, 3), dtype=torch.int32, device=local.device)
-        dist.all_gather_into_tensor(gathered, local.contiguous(), group=self.group)
-        totals = n.clone()
-        dist.all_reduce(totals, op=dist.ReduceOp.SUM, group=self.group)
-        return self.backend.topk(gathered.view(self.world, Q, self.k, 3), None, self.k), totals
+        if self.world == 1:
+            gathered = local.view(1, Q, self.k + 1, 3)
+        else:
+            # dim-0 concatenation is the layout both RCCL and gloo accept for all_gather_into_tensor
+            flat = torch.empty((self.world * Q, self.k + 1, 3), dtype=torch.int32, device=local.device)
+            dist.all_gather_into_tensor(flat, local.contiguous(), group=self.group)
+            gathered = flat.view(self.world, Q, self.k + 1, 3)
+        return self.backend.topk_merge(gathered, self.k)
 
 
 def verdicts_from_topk(merged: np.ndarray):
