@@ -170,6 +170,19 @@ int tvz_topk_shard(const int32_t *d_hits, const int32_t *d_hits_n, int32_t Q, in
 int tvz_topk_merge(const int32_t *d_gathered, int32_t n_ranks, int32_t Q, int32_t k,
                    int32_t *d_topk, int32_t *d_totals, void *hip_stream);
 
+/* ------------------------------------------------------------------------
+ * Opt-in alignment score.  NOT the reference's verdict: db.py:79 matches
+ * exactly; README.md:291 ("0.1 s tolerance") and north_star's "alignment/Jaccard" describe a
+ * shift/tolerance-aware comparison, which this reports ALONGSIDE the exact one.  For one query
+ * against every corpus row, every (query_i, row_j) difference votes into bins of width eps over
+ * [-max_offset, +max_offset] (bin = floor(diff/eps + 0.5)):
+ *   d_out : int32[n_rows][5] = (video_id, row_len, best_bin, votes_in_best_bin, votes_in_bin_0)
+ * best_bin ties: smaller |bin| first, then the negative one.  A cut-shifted copy shows as
+ * votes ~ min(n, row_len) at best_bin = shift/eps; tolerant Jaccard = v / (n + row_len - v).
+ * Needs 2*round(max_offset/eps)+1 <= 4096 bins. */
+int tvz_align(tvz_corpus *c, const double *d_query, int32_t n, double eps, double max_offset,
+              int32_t *d_out, void *hip_stream);
+
 #ifdef __cplusplus
 }
 #endif

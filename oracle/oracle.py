@@ -243,3 +243,31 @@ def verdict_from_kth(ids: np.ndarray, kth: np.ndarray, self_id: int = -1):
         return None, []
     kstar = int(kth[mask].min())
     return kstar, sorted(int(v) for v in ids[mask & (kth == kstar)])
+
+
+def align_py(corpus, query, eps=0.1, max_offset=60.0):
+    """Restatement of tvz_align (an opt-in extra with no reference counterpart): difference
+    histogram per row, best bin with ties to the smaller |bin| then the negative one.
+    Rows are treated as sets (sorted unique, NaN dropped), as the device corpus stores them."""
+    import math
+    B = int(math.floor(max_offset / eps + 0.5))
+    out = []
+    q = np.asarray([x for x in query], dtype=np.float64)
+    q = q[~np.isnan(q)]
+    for vid, ts in corpus:
+        c = np.asarray(ts, dtype=np.float64)
+        c = np.unique(c[~np.isnan(c)] + 0.0)
+        hist = np.zeros(2 * B + 1, dtype=np.int64)
+        if len(c) and len(q):
+            d = np.floor((c[:, None] - q[None, :]) / eps + 0.5)
+            d = d[(d >= -B) & (d <= B)].astype(np.int64)
+            np.add.at(hist, d + B, 1)
+        best_key, best_bin = -1, 0
+        for b in range(2 * B + 1):
+            bn = b - B
+            order = 2 * abs(bn) + (1 if bn > 0 else 0)
+            key = (int(hist[b]) << 14) | (16383 - order)
+            if key > best_key:
+                best_key, best_bin = key, bn
+        out.append((int(vid), int(len(c)), int(best_bin), int(hist[best_bin + B]), int(hist[B])))
+    return out

@@ -270,3 +270,88 @@ def test_sharded_pipeline_on_one_gpu(dc):
             kstar, dup = oracle.verdict_from_kth(ids, kth, self_id=int(excl[qi]))
             if not v[qi][2]:
                 assert (v[qi][0], v[qi][1]) == (kstar, dup)
+
+
+def test_opt_in_alignment_score_detects_a_cut_shifted_copy(dc):
+    """tvz_align is an extra (no reference counterpart): checked against its own restatement,
+    and on the configs[0] situation the exact matcher rejects (a cut-shifted copy)."""
+    rng = np.random.default_rng(12)
+    base = np.sort(np.round(rng.uniform(0, 300, 40), 4))
+    rows = [(1, base.tolist()), (2, (base + 7 / 30).tolist()), (3, np.sort(rng.uniform(0, 300, 35)).tolist()),
+            (4, []), (5, (base[:20] - 2.5).tolist() + [float("nan")]), (6, [5.0, 5.0, 5.0])]
+    dc.upload(rows)
+    for eps, mo in ((0.1, 10.0), (1 / 30, 5.0), (0.5, 60.0)):
+        got = [tuple(int(x) for x in r) for r in dc.align(base, eps=eps, max_offset=mo)]
+        assert got == oracle.align_py(rows, base, eps, mo), (eps, mo)
+    res = {r[0]: r for r in dc.align(base, eps=1 / 30, max_offset=5.0)}
+    assert res[1][2] == 0 and res[1][3] == 40                 # itself: no shift, all cuts
+    assert res[2][2] == 7 and res[2][3] >= 38                 # shifted by 7 frames: found
+    assert dc.find_duplicates(base, 2) == [(1, 40)]           # exact verdict unchanged: only itself
+    assert res[3][3] <= 6 and res[4][3] == 0
+    jacc = res[2][3] / (len(base) + res[2][1] - res[2][3])
+    assert jacc > 0.9
+
+
+def test_property_random_small_corpora_special_values(dc):
+    """Seeded property test: tiny key alphabets force heavy collisions, multiplicities, duplicate
+    video ids, special values; every (min_match, exclude) combination must equal the oracle."""
+    rng = np.random.default_rng(2025)
+    alphabet = np.array([0.0, -0.0, 1.0, 1.5, 2.0, 1e-300, 5e-324, 1e300, np.inf, -np.inf, np.nan,
+                         12.3457, 12.3456, 123.457, 0.1 + 0.2, 0.3, -7.25, 4503599627370497.0])
+    for trial in range(25):
+        C = int(rng.integers(1, 40))
+        rows = []
+        for c in range(C):
+            L = int(rng.integers(0, 12))
+            rows.append((int(rng.integers(1, 15)), alphabet[rng.integers(0, len(alphabet), L)].tolist()))
+        dc.upload(rows)
+        ids, offs, keys = tc.rows_to_csr(rows)
+        Q = int(rng.integers(1, 20))
+        queries = [alphabet[rng.integers(0, len(alphabet), int(rng.integers(0, 25)))] for _ in range(Q)]
+        for mm in (-1, 0, 1, 2, 3, 5, 6, 7):
+            excl = [int(rng.integers(1, 15)) for _ in range(Q)] if trial % 2 else None
+            _check_batch(dc, ids, offs, keys, queries, mm, excl=excl)
+        q0 = queries[0]
+        assert dc.find_duplicates(q0, 1) == sorted(oracle.find_duplicates_c(rows, q0.tolist(), 1))
+
+
+def test_upserts_concurrent_with_matches(dc):
+    """app.py:234-235 from many upload threads: add_timestamps (upsert) races find_duplicates; every
+    answer must be consistent with SOME prefix state of the mutating rows (never garbage)."""
+    import threading
+    ids, offs, keys = synth.synth_timestamp_corpus(800, seed=6, mean_len=40)
+    dc.upload_csr(ids, offs, keys)
+    base = keys[offs[3]:offs[4]].copy()                     # row of video ids[3]
+    stop = threading.Event()
+    errs = []
+
+    def writer(vid):
+        try:
+            prefix = []
+            for i in range(300):
+                prefix.append(1000.0 * (vid - 90000) + 1e6 + i * 0.5)
+                dc.upsert(vid, prefix)
+        except Exception as e:  # pragma: no cover
+            errs.append(e)
+
+    def reader():
+        try:
+            while not stop.is_set():
+                got = dict(dc.find_duplicates(base, 2))
+                assert got.get(int(ids[3])) == len(base)    # the static row is always found intact
+                for v in (90001, 90002, 90003):
+                    b = 1000.0 * (v - 90000) + 1e6
+                    got2 = dict(dc.find_duplicates([b, b + 0.5, b + 1.0], 1))
+                    assert set(got2) <= {v} and got2.get(v, 0) in (0, 1, 2, 3)
+        except Exception as e:  # pragma: no cover
+            errs.append(e)
+
+    rd = [threading.Thread(target=reader) for _ in range(3)]
+    wr = [threading.Thread(target=writer, args=(v,)) for v in (90001, 90002, 90003)]
+    [t.start() for t in rd + wr]
+    [t.join() for t in wr]
+    stop.set()
+    [t.join() for t in rd]
+    assert not errs, errs
+    for v in (90001, 90002, 90003):
+        assert dc.find_duplicates([1000.0 * (v - 90000) + 1e6 + 0.5 * i for i in range(300)], 300) == [(v, 300)]

@@ -48,6 +48,8 @@ SIGNATURES = {
                                  C.c_void_p]),
     "tvz_topk_merge": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
                                  C.c_void_p]),
+    "tvz_align": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_double, C.c_double, C.c_void_p,
+                            C.c_void_p]),
     # not part of the stable ABI (kernel-shape A/B knob)
     "tvz_scene_set_tuning": (C.c_int, [C.c_int, C.c_int, C.c_int]),
 }

@@ -103,6 +103,18 @@ class DeviceCorpus:
             return [(int(ids[i]), int(cnt[i]), int(kth[i])) for i in range(m)]
         return [(int(ids[i]), int(cnt[i])) for i in range(m)]
 
+    # ---- opt-in alignment score (never the verdict; see include/tvz.h tvz_align) ----
+    def align(self, timestamps: Sequence[float], eps: float = 0.1, max_offset: float = 60.0):
+        """-> int32 array [n_rows,5]: (video_id, row_len, best_bin, votes, votes_at_zero_shift)."""
+        n_rows = self.stats()[0]
+        dev = torch.device("cuda", self.device)
+        q = torch.as_tensor(np.asarray(timestamps, dtype=np.float64)).to(dev)
+        out = torch.empty((max(n_rows, 1), 5), dtype=torch.int32, device=dev)
+        _lib.check(self.lib.tvz_align(self._h, q.data_ptr() if q.numel() else None, q.numel(),
+                                      float(eps), float(max_offset), out.data_ptr(),
+                                      torch.cuda.current_stream(dev).cuda_stream))
+        return out[:n_rows].cpu().numpy()
+
     # ---- batched, device resident ----
     def match(self, d_queries: torch.Tensor, d_q_offsets: torch.Tensor, max_query_len: int,
               min_match: int, cap: int, d_exclude_ids: Optional[torch.Tensor] = None,
