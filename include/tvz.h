@@ -91,6 +91,17 @@ int tvz_scene_scores_u8(const uint8_t *d_luma, int64_t T, int32_t H, int32_t W,
                         uint8_t *d_selected, void *d_workspace, size_t workspace_bytes,
                         void *hip_stream);
 
+/* The same for 9..16-bit luma stored as uint16 (yuv420p10 etc.): ffmpeg's ff_scene_sad16_c sums
+ * |a-b| over uint16 samples and get_scene_score divides mafd by 2^(bitdepth-8).  Strides are in
+ * BYTES.  d_prev_frame: tightly packed H*W uint16. */
+int tvz_scene_scores_u16(const uint16_t *d_luma, int64_t T, int32_t H, int32_t W,
+                         int64_t frame_stride_bytes, int64_t row_stride_bytes,
+                         const uint16_t *d_prev_frame, double prev_mafd_in,
+                         int32_t bitdepth, double threshold,
+                         uint64_t *d_sad_out, double *d_mafd, double *d_score,
+                         uint8_t *d_selected, void *d_workspace, size_t workspace_bytes,
+                         void *hip_stream);
+
 /* ------------------------------------------------------------------------
  * Timestamp corpus   — device image of the `video_timestamps` table
  * (inspector/db.py:21-27): one row = (video_id, float8[] timestamps).

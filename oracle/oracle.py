@@ -54,6 +54,8 @@ def lib() -> ctypes.CDLL:
         c = ctypes
         L.orc_luma_sad_u8.argtypes = [c.c_void_p, c.c_int64, c.c_int32, c.c_int32,
                                       c.c_int64, c.c_int64, c.c_void_p]
+        L.orc_luma_sad_u16.argtypes = [c.c_void_p, c.c_int64, c.c_int32, c.c_int32,
+                                       c.c_int64, c.c_int64, c.c_void_p]
         L.orc_luma_sad_u8_range.argtypes = [c.c_void_p, c.c_int64, c.c_int64, c.c_int32,
                                             c.c_int32, c.c_int64, c.c_int64, c.c_void_p]
         L.orc_scene_select.argtypes = [c.c_void_p, c.c_int64, c.c_int32, c.c_int32, c.c_int32,
@@ -83,12 +85,13 @@ def _p(a: np.ndarray) -> ctypes.c_void_p:
 # ---------------------------------------------------------------- scene score
 
 def luma_sad(luma: np.ndarray) -> np.ndarray:
-    """uint8[T,H,W] (any strides with contiguous pixels in a row) -> uint64[T]; sad[0]=0."""
-    assert luma.dtype == np.uint8 and luma.ndim == 3 and luma.strides[2] == 1
+    """uint8 or uint16 [T,H,W] (any strides with contiguous pixels in a row) -> uint64[T]; sad[0]=0."""
+    assert luma.dtype in (np.uint8, np.uint16) and luma.ndim == 3 and luma.strides[2] == luma.itemsize
     T, H, W = luma.shape
     out = np.zeros(T, dtype=np.uint64)
     if T:
-        lib().orc_luma_sad_u8(_p(luma), T, H, W, luma.strides[0], luma.strides[1], _p(out))
+        fn = lib().orc_luma_sad_u8 if luma.dtype == np.uint8 else lib().orc_luma_sad_u16
+        fn(_p(luma), T, H, W, luma.strides[0], luma.strides[1], _p(out))
     return out
 
 

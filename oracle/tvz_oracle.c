@@ -82,6 +82,27 @@ ORC_API int orc_luma_sad_u8(const uint8_t *luma, int64_t T, int32_t H, int32_t W
     return 0;
 }
 
+/* scene_sad.c ff_scene_sad16_c: the same over uint16 samples (bitdepth 9..16); strides in BYTES. */
+ORC_API int orc_luma_sad_u16(const uint16_t *luma, int64_t T, int32_t H, int32_t W,
+                             int64_t frame_stride, int64_t row_stride, uint64_t *sad_out)
+{
+    if (T <= 0) return 0;
+    sad_out[0] = 0;
+    for (int64_t t = 1; t < T; t++) {
+        const uint8_t *cur = (const uint8_t *)luma + t * frame_stride;
+        const uint8_t *prv = cur - frame_stride;
+        uint64_t sad = 0;
+        for (int32_t y = 0; y < H; y++) {
+            const uint16_t *a = (const uint16_t *)(prv + (int64_t)y * row_stride);
+            const uint16_t *b = (const uint16_t *)(cur + (int64_t)y * row_stride);
+            for (int32_t x = 0; x < W; x++)
+                sad += (uint64_t)abs((int)a[x] - (int)b[x]);
+        }
+        sad_out[t] = sad;
+    }
+    return 0;
+}
+
 /* multi-threaded helper for the CPU baseline leg: frames [t0,t1) only */
 ORC_API int orc_luma_sad_u8_range(const uint8_t *luma, int64_t t0, int64_t t1,
                                   int32_t H, int32_t W, int64_t frame_stride,

@@ -185,3 +185,43 @@ def test_full_size_property_linearity_of_sad():
     assert sad.tolist() == [0, 7 * H * W, 7 * H * W, 31 * H * W, 0]
     assert mafd.tolist() == [0.0, 7.0, 7.0, 31.0, 0.0]
     assert sel.tolist() == [0, 0, 0, 0, 0]   # |31-7| = 24 <= 30: not a cut
+
+
+@pytest.mark.parametrize("shape,bitdepth", [((20, 270, 480), 10), ((9, 33, 51), 10), ((6, 1080, 1920), 10),
+                                            ((12, 64, 64), 12), ((5, 17, 3), 16), ((70, 48, 80), 16)])
+def test_16bit_luma_matches_oracle(shape, bitdepth):
+    """yuv420p10-style planes: ffmpeg's ff_scene_sad16_c + mafd / 2^(bitdepth-8)."""
+    rng = np.random.default_rng(shape[0] * 31 + bitdepth)
+    f = rng.integers(0, 1 << bitdepth, size=shape, dtype=np.uint16)
+    f[3:] = np.clip(f[3:].astype(np.int64) // 5 + (600 if bitdepth == 10 else 9000), 0, (1 << bitdepth) - 1).astype(np.uint16)
+    T, H, W = shape
+    sc = scene.SceneScorer(H, W, T, DEV, 0.3, bitdepth=bitdepth)
+    d = torch.from_numpy(f.view(np.int16)).to(DEV)
+    sad, mafd, score, sel = sc.score_batch(d)
+    torch.cuda.synchronize()
+    o_sad = oracle.luma_sad(f)
+    o_sel, o_score, o_mafd, _ = oracle.scene_select(o_sad, H, W, 0.3, bitdepth=bitdepth)
+    assert (sad.cpu().numpy().view(np.uint64) == o_sad).all()
+    assert (mafd.cpu().numpy() == o_mafd).all() and (score.cpu().numpy() == o_score).all()
+    assert (sel.cpu().numpy() == o_sel).all()
+    # chunked == whole, through the carried previous frame
+    sc2 = scene.SceneScorer(H, W, 4, DEV, 0.3, bitdepth=bitdepth)
+    sels = []
+    for s0 in range(0, T, 4):
+        part = d[s0:s0 + 4]
+        _, _, _, s_ = sc2.score_batch(part)
+        sc2.remember_tail(part)
+        sels.append(s_.cpu().numpy().copy())
+    assert (np.concatenate(sels) == o_sel).all()
+
+
+def test_16bit_padded_rows_generic_path():
+    rng = np.random.default_rng(8)
+    big = rng.integers(0, 1024, size=(7, 40, 70), dtype=np.uint16)
+    d_big = torch.from_numpy(big.view(np.int16)).to(DEV)
+    view = d_big[:, 3:33, 5:58]                      # padded rows, 2-byte aligned only
+    sc = scene.SceneScorer(30, 53, 7, DEV, 0.3, bitdepth=10)
+    sad, _, _, sel = sc.score_batch(view)
+    torch.cuda.synchronize()
+    o_sad = oracle.luma_sad(big[:, 3:33, 5:58])
+    assert (sad.cpu().numpy().view(np.uint64) == o_sad).all()

@@ -29,6 +29,10 @@ SIGNATURES = {
                                       C.c_int64, C.c_void_p, C.c_double, C.c_int32, C.c_double,
                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                       C.c_size_t, C.c_void_p]),
+    "tvz_scene_scores_u16": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int64,
+                                       C.c_int64, C.c_void_p, C.c_double, C.c_int32, C.c_double,
+                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                       C.c_size_t, C.c_void_p]),
     "tvz_corpus_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int]),
     "tvz_corpus_destroy": (C.c_int, [C.c_void_p]),
     "tvz_corpus_upload": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,

@@ -51,11 +51,20 @@ __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
     return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
 
+// S16 = false: 8-bit samples, v_sad_u8 (4 per dword).  S16 = true: 9..16-bit samples stored as
+// uint16 (ffmpeg's ff_scene_sad16_c), v_sad_u16 (2 per dword).
+template <bool S16>
+__device__ __forceinline__ uint32_t sad_dword(uint32_t a, uint32_t b, uint32_t acc) {
+    if constexpr (S16) return __builtin_amdgcn_sad_u16(a, b, acc);
+    else return __builtin_amdgcn_sad_u8(a, b, acc);
+}
+
+template <bool S16>
 __device__ __forceinline__ uint32_t sad16(const uint4 &a, const uint4 &b, uint32_t acc) {
-    acc = __builtin_amdgcn_sad_u8(a.x, b.x, acc);
-    acc = __builtin_amdgcn_sad_u8(a.y, b.y, acc);
-    acc = __builtin_amdgcn_sad_u8(a.z, b.z, acc);
-    acc = __builtin_amdgcn_sad_u8(a.w, b.w, acc);
+    acc = sad_dword<S16>(a.x, b.x, acc);
+    acc = sad_dword<S16>(a.y, b.y, acc);
+    acc = sad_dword<S16>(a.z, b.z, acc);
+    acc = sad_dword<S16>(a.w, b.w, acc);
     return acc;
 }
 
@@ -88,7 +97,7 @@ __device__ __forceinline__ uint4 load16(const uint4 *p) {
     }
 }
 
-template <int U, bool NT>
+template <int U, bool NT, bool S16>
 __global__ __launch_bounds__(kBlock) void luma_sad_flat_kernel(
     const uint8_t *__restrict__ luma, const uint8_t *__restrict__ prev0, int64_t T,
     int64_t frame_stride, int64_t n16, int32_t n_strips, int32_t tc, int32_t t_first,
@@ -124,7 +133,7 @@ __global__ __launch_bounds__(kBlock) void luma_sad_flat_kernel(
         uint32_t acc = 0;
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const uint32_t a = sad16(cur[u], prev[u], acc);
+            const uint32_t a = sad16<S16>(cur[u], prev[u], acc);
             acc = ok[u] ? a : acc;
         }
         const uint32_t total = wave_sum_u32(acc);
@@ -158,10 +167,10 @@ __device__ __forceinline__ uint32_t load_granule(const uint8_t *p, int nb) {
     return v;
 }
 
-template <int U>
+template <int U, bool S16>
 __global__ __launch_bounds__(kBlock) void luma_sad_generic_kernel(
     const uint8_t *__restrict__ luma, const uint8_t *__restrict__ prev0, int64_t T,
-    int64_t frame_stride, int64_t row_stride, int32_t H, int32_t W, int32_t gpr, int64_t n_gran,
+    int64_t frame_stride, int64_t row_stride, int32_t H, int32_t W /* row BYTES */, int32_t gpr, int64_t n_gran,
     int32_t n_strips, int32_t tc, int32_t t_first, uint32_t *__restrict__ partial, int64_t Tpad) {
     const int lane = threadIdx.x & 63;
     const int strip = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
@@ -201,7 +210,7 @@ __global__ __launch_bounds__(kBlock) void luma_sad_generic_kernel(
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             cur[u] = load_granule(pc + off[u], nb[u]);
-            acc = __builtin_amdgcn_sad_u8(cur[u], prev[u], acc);
+            acc = sad_dword<S16>(cur[u], prev[u], acc);
             prev[u] = cur[u];
         }
         const uint32_t total = wave_sum_u32(acc);
@@ -320,8 +329,8 @@ struct Plan {
 
 constexpr int kGenericU = 8;
 
-bool flat_ok(const void *p, int64_t fs, int64_t rs, int32_t H, int32_t W) {
-    return rs == W && ((int64_t)H * W) % 16 == 0 && fs % 16 == 0 &&
+bool flat_ok(const void *p, int64_t fs, int64_t rs, int32_t H, int32_t W, int bps) {
+    return rs == (int64_t)W * bps && ((int64_t)H * W * bps) % 16 == 0 && fs % 16 == 0 &&
            (reinterpret_cast<uintptr_t>(p) % 16) == 0;
 }
 
@@ -338,13 +347,13 @@ void auto_shape(int64_t T, int64_t n16, int &U, int &tc) {
     while (tc < 256 && tc < want) tc *= 2;
 }
 
-Plan make_plan(bool flat, int64_t T, int32_t H, int32_t W) {
+Plan make_plan(bool flat, int64_t T, int32_t H, int32_t W, int bps) {
     Plan p{};
     p.flat = flat;
     p.tc = g_tune.tc ? g_tune.tc : 128;
     p.Tpad = tvz::round_up(T > 0 ? T : 1, 64);
     if (flat) {
-        p.n16 = (int64_t)H * W / 16;
+        p.n16 = (int64_t)H * W * bps / 16;
         int aU = 4, atc = 128;
         auto_shape(T > 0 ? T : 1, p.n16, aU, atc);
         p.U = g_tune.U ? g_tune.U : aU;
@@ -352,7 +361,7 @@ Plan make_plan(bool flat, int64_t T, int32_t H, int32_t W) {
         p.n_strips = (int32_t)tvz::ceil_div(p.n16, (int64_t)kWave * p.U);
     } else {
         p.U = kGenericU;
-        p.gpr = (W + 3) / 4;
+        p.gpr = (W * bps + 3) / 4;
         p.n_gran = (int64_t)H * p.gpr;
         p.n_strips = (int32_t)tvz::ceil_div(p.n_gran, (int64_t)kWave * p.U);
     }
@@ -370,7 +379,7 @@ int check_dims(int64_t T, int32_t H, int32_t W) {
 }
 
 int launch_sad(const uint8_t *d_luma, const uint8_t *d_prev0, int64_t T, int32_t H, int32_t W,
-               int64_t fs, int64_t rs, const Plan &p, uint32_t *partial, hipStream_t st) {
+               int64_t fs, int64_t rs, const Plan &p, uint32_t *partial, int bps, hipStream_t st) {
     const int32_t t_first = d_prev0 ? 0 : 1;
     if (T <= t_first) return TVZ_OK;
     dim3 grid((unsigned)tvz::ceil_div(p.n_strips, kWavesPerBlock), (unsigned)tvz::ceil_div(T, p.tc));
@@ -378,16 +387,13 @@ int launch_sad(const uint8_t *d_luma, const uint8_t *d_prev0, int64_t T, int32_t
         return tvz::fail(TVZ_ERR_UNSUPPORTED, "batch of %lld frames needs more than 65535 time chunks",
                          (long long)T);
     if (p.flat) {
+#define TVZ_FLAT_(UU, NTV, S16V)                                                               \
+    hipLaunchKernelGGL((luma_sad_flat_kernel<UU, NTV, S16V>), grid, dim3(kBlock), 0, st, d_luma,   \
+                       d_prev0, T, fs, p.n16, p.n_strips, p.tc, t_first, partial, p.Tpad)
 #define TVZ_FLAT(UU)                                                                           \
     do {                                                                                       \
-        if (g_tune.nt)                                                                         \
-            hipLaunchKernelGGL((luma_sad_flat_kernel<UU, true>), grid, dim3(kBlock), 0, st,    \
-                               d_luma, d_prev0, T, fs, p.n16, p.n_strips, p.tc, t_first,       \
-                               partial, p.Tpad);                                               \
-        else                                                                                   \
-            hipLaunchKernelGGL((luma_sad_flat_kernel<UU, false>), grid, dim3(kBlock), 0, st,   \
-                               d_luma, d_prev0, T, fs, p.n16, p.n_strips, p.tc, t_first,       \
-                               partial, p.Tpad);                                               \
+        if (bps == 2) { if (g_tune.nt) TVZ_FLAT_(UU, true, true); else TVZ_FLAT_(UU, false, true); }   \
+        else          { if (g_tune.nt) TVZ_FLAT_(UU, true, false); else TVZ_FLAT_(UU, false, false); } \
     } while (0)
         switch (p.U) {
             case 1: TVZ_FLAT(1); break;
@@ -397,10 +403,16 @@ int launch_sad(const uint8_t *d_luma, const uint8_t *d_prev0, int64_t T, int32_t
             default: return tvz::fail(TVZ_ERR_INVALID, "unsupported U=%d", p.U);
         }
 #undef TVZ_FLAT
+#undef TVZ_FLAT_
     } else {
-        hipLaunchKernelGGL(luma_sad_generic_kernel<kGenericU>, grid, dim3(kBlock), 0, st, d_luma,
-                           d_prev0, T, fs, rs, H, W, p.gpr, p.n_gran, p.n_strips, p.tc, t_first,
-                           partial, p.Tpad);
+        if (bps == 2)
+            hipLaunchKernelGGL((luma_sad_generic_kernel<kGenericU, true>), grid, dim3(kBlock), 0, st,
+                               d_luma, d_prev0, T, fs, rs, H, W * 2, p.gpr, p.n_gran, p.n_strips,
+                               p.tc, t_first, partial, p.Tpad);
+        else
+            hipLaunchKernelGGL((luma_sad_generic_kernel<kGenericU, false>), grid, dim3(kBlock), 0, st,
+                               d_luma, d_prev0, T, fs, rs, H, W, p.gpr, p.n_gran, p.n_strips, p.tc,
+                               t_first, partial, p.Tpad);
     }
     TVZ_HIP(hipGetLastError());
     return TVZ_OK;
@@ -431,30 +443,39 @@ TVZ_EXPORT int tvz_scene_set_tuning(int U, int tc, int nt) {
 TVZ_EXPORT size_t tvz_scene_workspace_bytes(int64_t T, int32_t H, int32_t W) {
     if (T < 0 || H <= 0 || W <= 0) return 0;
     // worst case over every shape the launcher may pick: U=1 strips on the flat path
-    const size_t a = (size_t)tvz::ceil_div((int64_t)H * W / 16 + 1, kWave) * (size_t)tvz::round_up(T > 0 ? T : 1, 64) * sizeof(uint32_t);
-    const size_t b = plan_bytes(make_plan(false, T, H, W));
+    // (16-bit samples double the plane: sized for them so one workspace serves both depths)
+    const size_t a = (size_t)tvz::ceil_div((int64_t)H * W * 2 / 16 + 1, kWave) * (size_t)tvz::round_up(T > 0 ? T : 1, 64) * sizeof(uint32_t);
+    const size_t b = plan_bytes(make_plan(false, T, H, W, 2));
     return (a > b ? a : b) + 256;
 }
 
-TVZ_EXPORT int tvz_scene_scores_u8(const uint8_t *d_luma, int64_t T, int32_t H, int32_t W,
-                                   int64_t frame_stride_bytes, int64_t row_stride_bytes,
-                                   const uint8_t *d_prev_frame, double prev_mafd_in,
-                                   int32_t bitdepth, double threshold, uint64_t *d_sad_out,
-                                   double *d_mafd, double *d_score, uint8_t *d_selected,
-                                   void *d_workspace, size_t workspace_bytes, void *hip_stream) {
+namespace {
+int scene_scores_impl(const uint8_t *d_luma, int bps, int64_t T, int32_t H, int32_t W,
+                      int64_t frame_stride_bytes, int64_t row_stride_bytes,
+                      const uint8_t *d_prev_frame, double prev_mafd_in, int32_t bitdepth,
+                      double threshold, uint64_t *d_sad_out, double *d_mafd, double *d_score,
+                      uint8_t *d_selected, void *d_workspace, size_t workspace_bytes,
+                      void *hip_stream) {
     if (int rc = check_dims(T, H, W)) return rc;
     if (T == 0) return TVZ_OK;
     TVZ_REQUIRE(d_luma != nullptr, "d_luma is NULL");
-    TVZ_REQUIRE(row_stride_bytes >= W, "row stride %lld < W %d", (long long)row_stride_bytes, W);
-    TVZ_REQUIRE(frame_stride_bytes >= (int64_t)(H - 1) * row_stride_bytes + W || T == 1,
+    TVZ_REQUIRE(row_stride_bytes >= (int64_t)W * bps, "row stride %lld < %d bytes",
+                (long long)row_stride_bytes, W * bps);
+    TVZ_REQUIRE(frame_stride_bytes >= (int64_t)(H - 1) * row_stride_bytes + (int64_t)W * bps || T == 1,
                 "frame stride %lld smaller than a plane", (long long)frame_stride_bytes);
-    TVZ_REQUIRE(bitdepth == 8, "only 8-bit luma is supported (bitdepth=%d)", bitdepth);
+    if (bps == 1) TVZ_REQUIRE(bitdepth == 8, "8-bit entry point called with bitdepth=%d", bitdepth);
+    else {
+        TVZ_REQUIRE(bitdepth > 8 && bitdepth <= 16, "16-bit entry point needs 9 <= bitdepth <= 16 (got %d)", bitdepth);
+        TVZ_REQUIRE(row_stride_bytes % 2 == 0 && frame_stride_bytes % 2 == 0 &&
+                        reinterpret_cast<uintptr_t>(d_luma) % 2 == 0,
+                    "16-bit planes must be 2-byte aligned");
+    }
     TVZ_REQUIRE(d_sad_out || d_selected || d_score || d_mafd, "nothing to compute: every output is NULL");
     TVZ_REQUIRE(d_workspace != nullptr, "d_workspace is NULL");
     hipStream_t st = reinterpret_cast<hipStream_t>(hip_stream);
-    bool flat = flat_ok(d_luma, frame_stride_bytes, row_stride_bytes, H, W);
+    bool flat = flat_ok(d_luma, frame_stride_bytes, row_stride_bytes, H, W, bps);
     if (d_prev_frame && (reinterpret_cast<uintptr_t>(d_prev_frame) % 16) != 0) flat = false;
-    const Plan p = make_plan(flat, T, H, W);
+    const Plan p = make_plan(flat, T, H, W, bps);
     uintptr_t ws = (reinterpret_cast<uintptr_t>(d_workspace) + 255) & ~(uintptr_t)255;
     const size_t lost = ws - reinterpret_cast<uintptr_t>(d_workspace);
     if (workspace_bytes < lost + plan_bytes(p))
@@ -462,7 +483,7 @@ TVZ_EXPORT int tvz_scene_scores_u8(const uint8_t *d_luma, int64_t T, int32_t H, 
                          lost + plan_bytes(p));
     uint32_t *partial = reinterpret_cast<uint32_t *>(ws);
     if (int rc = launch_sad(d_luma, d_prev_frame, T, H, W, frame_stride_bytes, row_stride_bytes, p,
-                            partial, st))
+                            partial, bps, st))
         return rc;
     const SelectParams sp = make_sp(H, W, bitdepth, threshold, prev_mafd_in);
     hipLaunchKernelGGL(scene_finalize_kernel, dim3((unsigned)tvz::ceil_div(T, kFinT)),
@@ -470,6 +491,31 @@ TVZ_EXPORT int tvz_scene_scores_u8(const uint8_t *d_luma, int64_t T, int32_t H, 
                        d_prev_frame ? 0 : 1, sp, d_sad_out, d_mafd, d_score, d_selected);
     TVZ_HIP(hipGetLastError());
     return TVZ_OK;
+}
+}  // namespace
+
+TVZ_EXPORT int tvz_scene_scores_u8(const uint8_t *d_luma, int64_t T, int32_t H, int32_t W,
+                                   int64_t frame_stride_bytes, int64_t row_stride_bytes,
+                                   const uint8_t *d_prev_frame, double prev_mafd_in,
+                                   int32_t bitdepth, double threshold, uint64_t *d_sad_out,
+                                   double *d_mafd, double *d_score, uint8_t *d_selected,
+                                   void *d_workspace, size_t workspace_bytes, void *hip_stream) {
+    return scene_scores_impl(d_luma, 1, T, H, W, frame_stride_bytes, row_stride_bytes, d_prev_frame,
+                             prev_mafd_in, bitdepth, threshold, d_sad_out, d_mafd, d_score,
+                             d_selected, d_workspace, workspace_bytes, hip_stream);
+}
+
+TVZ_EXPORT int tvz_scene_scores_u16(const uint16_t *d_luma, int64_t T, int32_t H, int32_t W,
+                                    int64_t frame_stride_bytes, int64_t row_stride_bytes,
+                                    const uint16_t *d_prev_frame, double prev_mafd_in,
+                                    int32_t bitdepth, double threshold, uint64_t *d_sad_out,
+                                    double *d_mafd, double *d_score, uint8_t *d_selected,
+                                    void *d_workspace, size_t workspace_bytes, void *hip_stream) {
+    return scene_scores_impl(reinterpret_cast<const uint8_t *>(d_luma), 2, T, H, W,
+                             frame_stride_bytes, row_stride_bytes,
+                             reinterpret_cast<const uint8_t *>(d_prev_frame), prev_mafd_in, bitdepth,
+                             threshold, d_sad_out, d_mafd, d_score, d_selected, d_workspace,
+                             workspace_bytes, hip_stream);
 }
 
 TVZ_EXPORT int tvz_luma_sad_u8(const uint8_t *d_luma, int64_t T, int32_t H, int32_t W,

@@ -74,8 +74,14 @@ class SceneScorer:
     stream scored in chunks gives the same scores as one scored whole."""
 
     def __init__(self, H: int, W: int, max_batch: int, device: Union[str, torch.device] = "cuda:0",
-                 threshold: float = DEFAULT_THRESHOLD, keep_scores: bool = True):
+                 threshold: float = DEFAULT_THRESHOLD, keep_scores: bool = True, bitdepth: int = 8):
+        """bitdepth 8: uint8 frames.  bitdepth 9..16 (yuv420p10 ...): samples in 16-bit words,
+        passed as torch.int16 or torch.uint16 tensors (bit patterns of uint16)."""
         self.lib = _lib.load()
+        self.bitdepth = int(bitdepth)
+        if not 8 <= self.bitdepth <= 16:
+            raise RuntimeError(f"bitdepth {bitdepth} out of range 8..16")
+        self.dtype = torch.uint8 if self.bitdepth == 8 else torch.int16
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise RuntimeError("SceneScorer needs a GPU device (there is no CPU fallback)")
@@ -88,7 +94,7 @@ class SceneScorer:
             self.selected = torch.empty(self.max_batch, dtype=torch.uint8, device=self.device)
             self.score = torch.empty(self.max_batch, dtype=torch.float64, device=self.device) if keep_scores else None
             self.mafd = torch.empty(self.max_batch, dtype=torch.float64, device=self.device)
-            self.prev_frame = torch.empty((self.H, self.W), dtype=torch.uint8, device=self.device)
+            self.prev_frame = torch.empty((self.H, self.W), dtype=self.dtype, device=self.device)
         self.have_prev = False
         self.prev_mafd = 0.0
 
@@ -97,8 +103,10 @@ class SceneScorer:
         self.prev_mafd = 0.0
 
     def _check(self, frames: torch.Tensor) -> None:
-        if frames.dtype != torch.uint8 or frames.dim() != 3 or frames.device != self.device:
-            raise RuntimeError(f"frames must be a uint8 [T,H,W] tensor on {self.device}")
+        ok_dtype = frames.dtype == torch.uint8 if self.bitdepth == 8 else frames.element_size() == 2
+        if not ok_dtype or frames.dim() != 3 or frames.device != self.device:
+            raise RuntimeError(f"frames must be a {'uint8' if self.bitdepth == 8 else '16-bit'} "
+                               f"[T,H,W] tensor on {self.device}")
         if frames.shape[1] != self.H or frames.shape[2] != self.W:
             raise RuntimeError(f"frames are {tuple(frames.shape[1:])}, scorer is {(self.H, self.W)}")
         if frames.shape[0] > self.max_batch:
@@ -117,10 +125,12 @@ class SceneScorer:
         if T == 0:
             return self.sad[:0], self.mafd[:0], (self.score[:0] if self.score is not None else None), self.selected[:0]
         use_prev = carry and self.have_prev
-        rc = self.lib.tvz_scene_scores_u8(
-            frames.data_ptr(), T, self.H, self.W, frames.stride(0), frames.stride(1),
+        es = frames.element_size()
+        fn = self.lib.tvz_scene_scores_u8 if self.bitdepth == 8 else self.lib.tvz_scene_scores_u16
+        rc = fn(
+            frames.data_ptr(), T, self.H, self.W, frames.stride(0) * es, frames.stride(1) * es,
             self.prev_frame.data_ptr() if use_prev else None,
-            self.prev_mafd if use_prev else 0.0, 8, self.threshold,
+            self.prev_mafd if use_prev else 0.0, self.bitdepth, self.threshold,
             self.sad.data_ptr(), self.mafd.data_ptr(),
             self.score.data_ptr() if self.score is not None else None,
             self.selected.data_ptr(), self.workspace.data_ptr(), self.ws_bytes, _stream_ptr(stream))
@@ -133,7 +143,7 @@ class SceneScorer:
         T = int(frames.shape[0])
         if T == 0:
             return
-        self.prev_frame.copy_(frames[T - 1])
+        self.prev_frame.copy_(frames[T - 1].view(self.dtype) if frames.dtype != self.dtype else frames[T - 1])
         # an unscored first frame reports mafd 0 == ffmpeg's zero-initialised prev_mafd
         self.prev_mafd = float(self.mafd[T - 1].item())
         self.have_prev = True
