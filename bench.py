@@ -62,13 +62,13 @@ def parse():
 
 def barrier_sync(world):
     torch.cuda.synchronize()
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
     torch.cuda.synchronize()
 
 
 def max_over_ranks(x: float, world: int, dev) -> float:
-    if world == 1:
+    if not dist.is_initialized():
         return x
     t = torch.tensor([x], dtype=torch.float64, device=dev)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -132,7 +132,8 @@ def bench_match(args, rank, world, dev):
     dc = tc.DeviceCorpus(dev.index)
     dc.upload_csr(s_ids, s_offs, s_keys)
     d_q, d_off, max_len = tc.pack_queries(queries, dev)
-    sm = sharded.ShardedMatcher(sharded.HipBackend(dc), k=64, cap=1024)
+    sm = sharded.ShardedMatcher(sharded.HipBackend(dc), k=64, cap=1024,
+                                always_collective=dist.is_initialized())
     for _ in range(3):
         merged, totals = sm.match_topk(d_q, d_off, max_len, 2)
     barrier_sync(world)
@@ -158,7 +159,7 @@ def bench_match(args, rank, world, dev):
     return {"value": pairs / wall, "unit": "pairs/s", "corpus_videos": C, "queries_per_batch": Q,
             "mean_cuts_per_video": round(mean_len, 1), "min_match": 2, "steps": args.match_steps,
             "ms_per_batch": wall * 1e3 / args.match_steps,
-            "collective": "one all_gather of [Q,65,3] int32 per batch (top-64 + hit totals)" if world > 1 else "none",
+            "collective": "one all_gather of [Q,65,3] int32 per batch (top-64 + hit totals)" if sm.collective else "none",
             "queries_with_hits": n_dups,
             "find_duplicates_latency_ms_q1": round(float(np.median(lat)) * 1e3, 3),
             "roofline": {"bound": "hbm", "achieved": pairs * bytes_per_pair / wall / 1e9 / world,
@@ -197,7 +198,8 @@ def main():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    launched = "RANK" in os.environ and "MASTER_ADDR" in os.environ   # under torch.distributed.run
+    if world > 1 or launched:
         dist.init_process_group("nccl", device_id=dev)
     _lib.load()
 
@@ -238,7 +240,7 @@ def main():
     if not args.no_match:
         m = bench_match(args, rank, world, dev)
         out["match"] = m
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:

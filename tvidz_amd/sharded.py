@@ -61,13 +61,17 @@ class ShardedMatcher:
     """rank-local shard + ONE all-gather of per-shard top-k (+ hit totals) + identical merge on
     every rank."""
 
-    def __init__(self, backend, k: int = 64, cap: int = 1024, group=None):
+    def __init__(self, backend, k: int = 64, cap: int = 1024, group=None,
+                 always_collective: bool = False):
         self.backend = backend
         self.k = int(k)
         self.cap = max(int(cap), self.k)
         self.group = group
-        self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
-        self.rank = dist.get_rank(group) if self.world > 1 else 0
+        inited = dist.is_available() and dist.is_initialized()
+        self.world = dist.get_world_size(group) if inited else 1
+        self.rank = dist.get_rank(group) if inited else 0
+        # run the all-gather even in a 1-rank group (used to rehearse the RCCL path on one GPU)
+        self.collective = self.world > 1 or (always_collective and inited)
 
     def match_topk(self, d_queries: torch.Tensor, d_q_offsets: torch.Tensor, max_query_len: int,
                    min_match: int, d_exclude_ids: Optional[torch.Tensor] = None):
@@ -77,7 +81,7 @@ class ShardedMatcher:
                                      d_exclude_ids)
         local = self.backend.topk_shard(hits, n, self.k)            # [Q, k+1, 3]
         Q = local.shape[0]
-        if self.world == 1:
+        if not self.collective:
             gathered = local.view(1, Q, self.k + 1, 3)
         else:
             # dim-0 concatenation is the layout both RCCL and gloo accept for all_gather_into_tensor
