@@ -1,0 +1,59 @@
+#!/usr/bin/env python3
+"""End-to-end service throughput proxy for BASELINE.json configs[4] (concurrent uploads through the
+driver): N distinct synthetic 1080p clips as mono Y4M files in RAM -> Inspector.submit (Y4M reader
+-> pinned ring -> H2D -> HIP scene kernels -> HIP corpus match per micro-batch -> SQL upserts).
+No decoder in the loop (the host-side ffmpeg decode is outside the hot path); PCIe-inclusive.
+   python profiles/e2e_service.py [n_uploads] [frames_per_clip] [workers]"""
+import json
+import os
+import shutil
+import sys
+import tempfile
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from tvidz_amd import db as tdb, feeder, inspector as insp, synth  # noqa: E402
+
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+T = int(sys.argv[2]) if len(sys.argv) > 2 else 512
+WORKERS = int(sys.argv[3]) if len(sys.argv) > 3 else 8
+BATCH = int(sys.argv[4]) if len(sys.argv) > 4 else 256
+H, W = 1080, 1920
+root = "/dev/shm" if os.path.isdir("/dev/shm") and shutil.disk_usage("/dev/shm").free > (N * T * H * W * 1.2) else None
+tmp = tempfile.mkdtemp(prefix="tvz_e2e_", dir=root)
+try:
+    files = {}
+    for i in range(N):
+        frames, _ = synth.synth_luma(T, H, W, device="cuda:0", seed=100 + i, min_scene=20, max_scene=90)
+        name = f"17000000{i:02d}-clip{i}.y4m"
+        files[name] = os.path.join(tmp, name)
+        feeder.write_y4m(files[name], frames.cpu().numpy(), fps=(30, 1), chroma="mono")
+        del frames
+    store = tdb.Store(f"sqlite:///{tmp}/tvidz.db", device=0)
+    ids, offs, keys = synth.synth_timestamp_corpus(5000, seed=1)
+    store.corpus.upload_csr(ids + 100000, offs, keys)     # a 5k-video corpus to match against
+
+    def source(bucket, key, filename, unique_id):
+        return feeder.Y4MReader(files[key]), None
+
+    ins = insp.Inspector(store, device="cuda:0", frame_source=source, batch=BATCH, max_workers=WORKERS)
+    # warm-up pass: a long-running service has its pinned/device slots cached by the allocators
+    [f.result() for f in [ins.submit("videos", k) for k in files]]
+    store.clear()
+    store.corpus.upload_csr(ids + 100000, offs, keys)
+    t0 = time.perf_counter()
+    futs = [ins.submit("videos", k) for k in files]
+    res = [f.result() for f in futs]
+    dt = time.perf_counter() - t0
+    assert all(r["status"] == "done" for r in res), [r.get("error") for r in res]
+    frames_done = sum(round(r["scene_cuts"][-1] * 30) if r["duplicates"] else T for r in res)
+    print(json.dumps({"uploads": N, "frames_per_clip": T, "workers": WORKERS, "batch": BATCH, "wall_s": round(dt, 3),
+                      "frames_per_s": round(N * T / dt), "GBps_luma": round(N * T * H * W / dt / 1e9, 2),
+                      "cuts": [r["total_cuts"] for r in res], "dups": [len(r["duplicates"]) for r in res],
+                      "tmp": "shm" if root else "disk"}))
+    store.close()
+finally:
+    shutil.rmtree(tmp, ignore_errors=True)

@@ -183,7 +183,9 @@ class FrameFeeder:
         self.batch = int(batch)
         self.device = torch.device(device)
         self.n_slots = n_slots
-        self.pinned = [torch.empty((self.batch, self.H, self.W), dtype=torch.uint8).pin_memory()
+        # straight from torch's caching host allocator: freed slots of a finished upload are reused
+        # by the next one (a .pin_memory() copy would page-lock ~0.5 GB per slot every time)
+        self.pinned = [torch.empty((self.batch, self.H, self.W), dtype=torch.uint8, pin_memory=True)
                        for _ in range(n_slots)]
         self.dev = [torch.empty((self.batch, self.H, self.W), dtype=torch.uint8, device=self.device)
                     for _ in range(n_slots)]
