@@ -113,19 +113,17 @@ __device__ __forceinline__ unsigned long long top5_insert(unsigned long long p, 
     return r;
 }
 
-// pair index (13 bits) and tag (16 bits, never 0xffff) from one mix of the key.  Only full-rate
-// VALU ops: v_mul_u32_u24 instead of the quarter-rate v_mul_lo_u32.  Quality only affects speed
-// (every tag match is verified against the full key).
+// pair index (13 bits) and tag (16 bits) from one mix of the key: 9 full-rate VALU ops (one
+// v_mul_u32_u24, no quarter-rate v_mul_lo_u32).  Quality only affects speed: every tag match is
+// verified against the full key.  A tag of 0xffff may "match" a free slot's upper half; the slow
+// path then finds an empty chain (head 0xffff = kEnd), which is the right answer.
 __device__ __forceinline__ void hash_pair_tag(int64_t k, uint32_t &pair, uint32_t &tag) {
     const uint32_t lo = (uint32_t)k, hi = (uint32_t)((uint64_t)k >> 32);
     uint32_t x = lo ^ (hi + (hi << 3)) ^ (hi >> 9);
-    x ^= x >> 15;
-    const uint32_t a = __umul24(x, 0x9E3779u);           // low 24 bits of x
-    const uint32_t b = __umul24(x >> 8, 0x85EBCBu);      // high 24 bits of x
-    const uint32_t y = a ^ (b << 3) ^ (b >> 11);
-    pair = (y >> 11) & (uint32_t)(kTilePairs - 1);
-    tag = (y ^ (a >> 7)) & 0xffffu;
-    if (tag == 0xffffu) tag = 0;
+    x ^= x >> 20;                                   // fold the bits v_mul_u32_u24 ignores
+    const uint32_t y = __umul24(x, 0x9E3779u);
+    pair = y >> (32 - 13);
+    tag = (y >> 3) & 0xffffu;
 }
 static_assert((1 << 13) == kTilePairs, "pair bits must match kTilePairs");
 
@@ -234,6 +232,7 @@ __global__ __launch_bounds__(kTileBlock) void ts_match_tile_kernel(
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const uint32_t gw = (threadIdx.x >> 4) & 3u;                 // group within the wave
+    const uint32_t gwbits = gw << 29;
     int64_t *qbase_k = reinterpret_cast<int64_t *>(cnt + kTileGroups * kTileQ);
     int64_t *qk = qbase_k + wave * kRing;
     uint32_t *qm = reinterpret_cast<uint32_t *>(qbase_k + (kTileBlock / 64) * kRing) + wave * kRing;
@@ -303,7 +302,7 @@ __global__ __launch_bounds__(kTileBlock) void ts_match_tile_kernel(
                     if (slow) {
                         const uint32_t idx = (qtail + ofs) & (kRing - 1);
                         qk[idx] = kk[j];
-                        qm[idx] = tg[j] | (pr[j] << 16) | (gw << 29);
+                        qm[idx] = tg[j] | (pr[j] << 16) | gwbits;
                     }
                     qtail += (uint32_t)__popcll(bal);
                     if (qtail - qhead >= 64u) drain(64u);
