@@ -47,8 +47,8 @@ FRAME_BYTES = H * W
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--frames", type=int, default=10000, help="1080p frames per GPU per step")
     ap.add_argument("--corpus", type=int, default=0, help="corpus videos (default 5000 at N=1, 100000 at N>1)")
     ap.add_argument("--queries", type=int, default=1024, help="query videos per match batch")
@@ -123,6 +123,49 @@ def cpu_baseline_scene(frames: torch.Tensor, n_frames: int, n_threads: int, min_
                       "core-seconds (the reference's ffmpeg binary is not available: a port, not the reference)"}, out
 
 
+def cpu_baseline_match(ids, offs, keys, queries, n_threads: int = 0):
+    """(i) the pure-Python restatement with the reference's loop shape
+    (db.py:85-91), 1 thread (GIL-bound) on a bounded sample; (ii) the fair CPU bound: C restatement
+    on sorted-unique rows with binary search, all host threads."""
+    from oracle import oracle  # checker / CPU baseline only
+    n_threads = n_threads or min(os.cpu_count() or 1, 16)
+    C = len(ids)
+    rows = [(int(ids[c]), keys[offs[c]:offs[c + 1]].tolist()) for c in range(min(C, 5000))]
+    t0 = time.perf_counter()
+    n_py = 0
+    while time.perf_counter() - t0 < 2.0:                  # ~2 s of single-thread CPython
+        oracle.find_duplicates_py(rows, queries[1 + n_py % max(1, len(queries) - 1)].tolist(), 2)
+        n_py += 1
+    dt_py = time.perf_counter() - t0
+    srt = keys.copy()
+    for c in range(C):
+        srt[offs[c]:offs[c + 1]].sort()
+    nq = min(len(queries), 64)
+    bounds = np.linspace(0, C, n_threads + 1).astype(int)
+    cnt = np.zeros(C, dtype=np.int32); kth = np.zeros(C, dtype=np.int32)
+    L = oracle.lib()
+    qarr = [np.ascontiguousarray(x, dtype=np.float64) for x in queries[:nq]]
+
+    def work(i):
+        for qa in qarr:
+            L.orc_match_kth_sorted(qa.ctypes.data, len(qa), offs.ctypes.data, srt.ctypes.data,
+                                   int(bounds[i]), int(bounds[i + 1]), 2, cnt.ctypes.data, kth.ctypes.data)
+    t0 = time.perf_counter()
+    passes = 0
+    with ThreadPoolExecutor(n_threads) as ex:
+        while time.perf_counter() - t0 < 1.0:
+            list(ex.map(work, range(n_threads)))
+            passes += 1
+    dt_c = time.perf_counter() - t0
+    return {"python_restatement": {"value": n_py * len(rows) / dt_py, "unit": "pairs/s", "cores": 1, "kind": "port",
+                                   "sample": f"oracle.find_duplicates_py (loop shape of db.py:85-91), {n_py} queries vs "
+                                             f"{len(rows)} rows, {dt_py:.2f} s"},
+            "c_sorted_binary_search": {"value": passes * nq * C / dt_c, "unit": "pairs/s", "cores": n_threads,
+                                       "kind": "port",
+                                       "sample": f"oracle orc_match_kth_sorted, {passes} x {nq} queries vs {C} rows, "
+                                                 f"{n_threads} threads, {dt_c:.2f} s = {dt_c * n_threads:.0f} core-seconds"}}
+
+
 def bench_match(args, rank, world, dev):
     C = args.corpus or (5000 if world == 1 else 100000)
     Q = args.queries
@@ -155,6 +198,23 @@ def bench_match(args, rank, world, dev):
         dc.find_duplicates(queries[i % Q], 2)
         lat.append(time.perf_counter() - t)
     n_dups = int((totals > 0).sum().item())
+    # batch-size sweep on this rank's shard (no collective): SURVEY 8d asks for Q = 1, 64 and 1024
+    by_q = {}
+    for q_n in (1, 64, 1024):
+        if q_n > Q:
+            continue
+        dq, do, ml = tc.pack_queries(queries[:q_n], dev)
+        hits = torch.empty((q_n, 1024, 3), dtype=torch.int32, device=dev)
+        n_h = torch.empty(q_n, dtype=torch.int32, device=dev)
+        ts = []
+        for r in range(12):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record(); dc.match(dq, do, ml, 2, 1024, out_hits=hits, out_n=n_h); b.record()
+            torch.cuda.synchronize()
+            ts.append(a.elapsed_time(b))
+        med = float(np.median(ts[2:]))
+        by_q[str(q_n)] = {"kernel_ms": round(med, 4), "pairs_per_s": q_n * len(s_ids) / (med * 1e-3)}
+    cpu = cpu_baseline_match(ids, offs, keys, queries) if (rank == 0 and world == 1 and not args.no_cpu) else None
     dc.close()
     return {"value": pairs / wall, "unit": "pairs/s", "corpus_videos": C, "queries_per_batch": Q,
             "mean_cuts_per_video": round(mean_len, 1), "min_match": 2, "steps": args.match_steps,
@@ -162,6 +222,7 @@ def bench_match(args, rank, world, dev):
             "collective": "one all_gather of [Q,65,3] int32 per batch (top-64 + hit totals)" if sm.collective else "none",
             "queries_with_hits": n_dups,
             "find_duplicates_latency_ms_q1": round(float(np.median(lat)) * 1e3, 3),
+            "match_kernel_by_batch_size": by_q, "cpu_baseline": cpu,
             "roofline": {"bound": "hbm", "achieved": pairs * bytes_per_pair / wall / 1e9 / world,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": pairs * bytes_per_pair / wall / 1e9 / world / HBM_PEAK_GBS,
