@@ -232,6 +232,22 @@ def bench_match(args, rank, world, dev):
                                  "kernel is LDS/issue-bound, not HBM-bound"}}
 
 
+def h2d_cost(dev, n_frames: int = 256):
+    """Separate H2D cost line: pinned host luma -> HBM, never part of `value`."""
+    host = torch.empty((n_frames, H, W), dtype=torch.uint8, pin_memory=True)
+    dst = torch.empty((n_frames, H, W), dtype=torch.uint8, device=dev)
+    ts = []
+    for _ in range(6):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(); dst.copy_(host, non_blocking=True); b.record()
+        torch.cuda.synchronize()
+        ts.append(a.elapsed_time(b))
+    ms = float(np.median(ts[1:]))
+    gbs = n_frames * FRAME_BYTES / ms / 1e6
+    return {"GBps": round(gbs, 1), "ms_per_256_frames": round(ms, 3), "frames_per_s_bound": round(n_frames / ms * 1e3),
+            "note": "pinned host -> HBM copy of 256 x 1080p luma; the PCIe-inclusive ceiling of the scene path"}
+
+
 def pmc_traffic(kernel: str, T: int):
     """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/*_pmc_summary.json:
     FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE), valid for the default T only."""
@@ -285,10 +301,12 @@ def main():
                      "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic("luma_sad", T),
                      "kernel": "luma_sad_flat_kernel<8,nt> (event pair also covers scene_finalize_kernel, <1% of the step)",
                      "algorithmic_bytes_per_launch": (T - 1) * FRAME_BYTES,
-                     "avg_launch_ms": kern_ms,
+                     "avg_launch_ms": kern_ms, "median_launch_ms": float(np.median(res["step_ms"])),
                      "p10_p90_ms": [float(np.percentile(res["step_ms"], 10)),
                                     float(np.percentile(res["step_ms"], 90))]},
     }
+    if rank == 0:
+        out["h2d"] = h2d_cost(dev)
     if rank == 0 and world == 1 and not args.no_cpu:
         cpu, cpu_sad = cpu_baseline_scene(res["frames"], args.cpu_frames, args.cpu_threads)
         gpu_sad = res["scorer"].sad[:len(cpu_sad)].cpu().numpy().view(np.uint64)
