@@ -1,0 +1,92 @@
+/* Plain-C consumer of libtvz.so: no Python, no torch.  Shows that the C ABI of include/tvz.h is
+ * usable from any host language.  Built and run by tests/test_c_abi_gpu.py on the GPU box:
+ *   gcc -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -Iinclude tests/c_abi_smoke.c \
+ *       -Ltvidz_amd -ltvz -L/opt/rocm/lib -lamdhip64 -lm
+ * Checks the reference's known-answer test (inspector/test_app.py:66-83) and a small scene batch
+ * against loops written here. */
+#include <hip/hip_runtime_api.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "tvz.h"
+
+#define CHECK(x) do { int _rc = (x); if (_rc != 0) { fprintf(stderr, "FAIL %s -> %d: %s\n", #x, _rc, tvz_last_error()); return 1; } } while (0)
+#define HIPCHECK(x) do { hipError_t _e = (x); if (_e != hipSuccess) { fprintf(stderr, "FAIL %s: %s\n", #x, hipGetErrorString(_e)); return 1; } } while (0)
+#define EXPECT(c) do { if (!(c)) { fprintf(stderr, "FAIL expectation %s (line %d)\n", #c, __LINE__); return 1; } } while (0)
+
+int main(void) {
+    EXPECT(tvz_version() == TVZ_VERSION);
+
+    /* --- corpus match: inspector/test_app.py:66-83 --- */
+    tvz_corpus *c = NULL;
+    CHECK(tvz_corpus_create(&c, 0));
+    int32_t ids[2] = {1, 2};
+    int64_t offs[3] = {0, 5, 10};
+    double keys[10] = {1.0, 2.0, 3.0, 4.0, 5.0, 10.0, 20.0, 30.0, 40.0, 50.0};
+    CHECK(tvz_corpus_upload(c, ids, offs, keys, 2, 10));
+    int32_t oid[8], ocnt[8], okth[8];
+    int64_t n = -1;
+    double q1[5] = {10.0, 20.0, 30.0, 40.0, 50.0};
+    CHECK(tvz_find_duplicates(c, q1, 5, 5, -1, 8, oid, ocnt, okth, &n));
+    EXPECT(n == 1 && oid[0] == 2 && ocnt[0] == 5 && okth[0] == 4);
+    double third[5] = {1.0, 2.0, 3.0, 4.0, 5.0};
+    CHECK(tvz_corpus_upsert(c, 3, third, 5));
+    CHECK(tvz_find_duplicates(c, third, 5, 5, -1, 8, oid, ocnt, okth, &n));
+    EXPECT(n == 2 && oid[0] == 1 && oid[1] == 3 && ocnt[0] == 5 && ocnt[1] == 5);
+    CHECK(tvz_find_duplicates(c, third, 5, 2, /*exclude self*/ 3, 8, oid, ocnt, okth, &n));
+    EXPECT(n == 1 && oid[0] == 1 && okth[0] == 1);           /* streaming: stops at the 2nd cut */
+    int64_t nr, nk, na;
+    CHECK(tvz_corpus_stats(c, &nr, &nk, &na));
+    EXPECT(nr == 3 && nk == 15);
+    EXPECT(tvz_find_duplicates(NULL, q1, 5, 5, -1, 8, oid, ocnt, okth, &n) == TVZ_ERR_INVALID);
+    EXPECT(strlen(tvz_last_error()) > 0);
+    CHECK(tvz_corpus_destroy(c));
+
+    /* --- scene scores: 6 frames of 48x64 luma --- */
+    enum { T = 6, H = 48, W = 64 };
+    static uint8_t frames[T][H][W];
+    unsigned s = 12345;
+    int level[T] = {40, 42, 200, 199, 60, 61};
+    for (int t = 0; t < T; t++)
+        for (int y = 0; y < H; y++)
+            for (int x = 0; x < W; x++) {
+                s = s * 1103515245u + 12345u;
+                frames[t][y][x] = (uint8_t)(level[t] + (int)((s >> 16) % 5) - 2);
+            }
+    uint8_t *d_luma; uint64_t *d_sad; double *d_mafd, *d_score; uint8_t *d_sel; void *d_ws;
+    size_t ws = tvz_scene_workspace_bytes(T, H, W);
+    EXPECT(ws > 0);
+    HIPCHECK(hipMalloc((void **)&d_luma, sizeof frames));
+    HIPCHECK(hipMalloc((void **)&d_sad, T * 8));
+    HIPCHECK(hipMalloc((void **)&d_mafd, T * 8));
+    HIPCHECK(hipMalloc((void **)&d_score, T * 8));
+    HIPCHECK(hipMalloc((void **)&d_sel, T));
+    HIPCHECK(hipMalloc(&d_ws, ws));
+    HIPCHECK(hipMemcpy(d_luma, frames, sizeof frames, hipMemcpyHostToDevice));
+    CHECK(tvz_scene_scores_u8(d_luma, T, H, W, (int64_t)H * W, W, NULL, 0.0, 8, 0.3, d_sad, d_mafd, d_score,
+                              d_sel, d_ws, ws, NULL));
+    HIPCHECK(hipDeviceSynchronize());
+    uint64_t sad[T]; double mafd[T], score[T]; uint8_t sel[T];
+    HIPCHECK(hipMemcpy(sad, d_sad, sizeof sad, hipMemcpyDeviceToHost));
+    HIPCHECK(hipMemcpy(mafd, d_mafd, sizeof mafd, hipMemcpyDeviceToHost));
+    HIPCHECK(hipMemcpy(score, d_score, sizeof score, hipMemcpyDeviceToHost));
+    HIPCHECK(hipMemcpy(sel, d_sel, sizeof sel, hipMemcpyDeviceToHost));
+    double prev = 0.0;
+    for (int t = 0; t < T; t++) {
+        uint64_t e = 0;
+        if (t) for (int y = 0; y < H; y++) for (int x = 0; x < W; x++) e += (uint64_t)abs((int)frames[t][y][x] - (int)frames[t - 1][y][x]);
+        EXPECT(sad[t] == e);
+        if (!t) { EXPECT(score[0] == 0.0 && sel[0] == 0); continue; }
+        double m = (double)e / (double)(W * H) / 1.0, diff = fabs(m - prev);
+        float f = (float)((m > diff ? diff : m) / 100.);
+        f = f < 0 ? 0 : (f > 1 ? 1 : f);
+        EXPECT(mafd[t] == m && score[t] == (double)f && sel[t] == ((double)f > 0.3));
+        prev = m;
+    }
+    EXPECT(sel[2] == 1 && sel[4] == 1 && sel[1] == 0 && sel[3] == 0 && sel[5] == 0);
+    hipFree(d_luma); hipFree(d_sad); hipFree(d_mafd); hipFree(d_score); hipFree(d_sel); hipFree(d_ws);
+    printf("c_abi_smoke OK\n");
+    return 0;
+}
