@@ -120,6 +120,11 @@ def main():
     add("test_app.py:78-83 third identical", c3, [1.0, 2.0, 3.0, 4.0, 5.0], 5)
     add("app.py:399-408 debug scenario", [[1, [1.2, 5.7, 12.3, 18.9]]], [1.2, 5.7, 12.3, 18.9], 2)
     add("app.py:372 default vector", [[7, [1.2, 5.7, 12.3, 18.9, 25.1]]], [1.2, 5.7], 2)
+    # sample rows of docs/tvidz-detailed-guide.md:1268-1272 ("Partial match with video 1")
+    doc = [[1, [1.2, 5.7, 12.3, 18.9, 25.1]], [2, [2.1, 8.4, 15.7, 22.1, 28.9]], [3, [1.2, 5.7, 12.3]]]
+    add("guide.md:1268-1272 sample rows, query = video 3", doc, [1.2, 5.7, 12.3], 2)
+    add("guide.md:1268-1272 sample rows, query = video 1, default min_match", doc, [1.2, 5.7, 12.3, 18.9, 25.1], 5)
+    add("guide.md:1268-1272 sample rows, query = video 2", doc, [2.1, 8.4, 15.7, 22.1, 28.9], 3)
     add("query multiplicity counts", [[1, [1.2, 9.9]]], [1.2, 1.2], 2)
     add("candidate multiplicity does not", [[1, [1.2, 1.2, 1.2]]], [1.2], 2)
     add("candidate multiplicity min1", [[1, [1.2, 1.2, 1.2]]], [1.2], 1)
