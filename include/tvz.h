@@ -149,7 +149,8 @@ int tvz_corpus_stats(tvz_corpus *c, int64_t *n_rows, int64_t *n_keys, int64_t *a
  *   d_exclude_ids : int32[Q] or NULL
  *   d_hits      : int32[Q][cap][3] out;  d_hits_n : int32[Q] out = number of
  *                 hits found (may exceed cap; only the first cap are stored)
- *   max_query_len : upper bound on any query's length (<= 4095; sizes the query tile) */
+ *   max_query_len : upper bound on any query's length (<= 4095; sizes the query tile).  If it
+ *                 is NOT an upper bound the affected queries get d_hits_n = INT32_MIN. */
 int tvz_match(tvz_corpus *c, const double *d_queries, const int64_t *d_q_offsets,
               int32_t Q, int32_t max_query_len, int32_t min_match,
               const int32_t *d_exclude_ids, int32_t cap,

@@ -355,3 +355,15 @@ def test_upserts_concurrent_with_matches(dc):
     assert not errs, errs
     for v in (90001, 90002, 90003):
         assert dc.find_duplicates([1000.0 * (v - 90000) + 1e6 + 0.5 * i for i in range(300)], 300) == [(v, 300)]
+
+
+def test_wrong_max_query_len_is_flagged_not_truncated(dc):
+    dc.upload([(1, [1.0, 2.0, 3.0])])
+    queries = [np.arange(300, dtype=np.float64)] * 16           # 4800 entries for one 16-query tile
+    d_q, d_off, max_len = tc.pack_queries(queries, DEV)
+    hits, n = dc.match(d_q, d_off, 200, 1, 8)                    # lying about the bound
+    torch.cuda.synchronize()
+    assert (n.cpu().numpy() == np.iinfo(np.int32).min).all()
+    hits, n = dc.match(d_q, d_off, max_len, 1, 8)                # honest bound: correct answer
+    torch.cuda.synchronize()
+    assert (n.cpu().numpy() == 1).all() and (hits[:, 0, 1].cpu().numpy() == 3).all()

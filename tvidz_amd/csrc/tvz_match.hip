@@ -24,6 +24,7 @@
 // Kernel ts_topk_kernel: per query bitonic selection of the k best hits ordered by
 //   (kth, video_id, count) over one or several (all-gathered) hit lists.
 #include <algorithm>
+#include <climits>
 #include <cstring>
 #include <mutex>
 #include <shared_mutex>
@@ -174,8 +175,13 @@ __global__ __launch_bounds__(kTileBlock) void ts_match_tile_kernel(
     }
     __syncthreads();
     const int64_t qbase = s_qoff[0];
-    int total = (int)(s_qoff[nq] - qbase);
-    if (total > kTileMaxEntries) total = kTileMaxEntries;  // host guarantees this never trims
+    if (s_qoff[nq] - qbase > kTileMaxEntries) {
+        // the caller's max_query_len was not an upper bound: poison the affected counters instead
+        // of returning silently truncated matches (every row chunk of this tile takes this exit)
+        if (threadIdx.x < nq) hits_n[q0 + threadIdx.x] = INT32_MIN;
+        return;
+    }
+    const int total = (int)(s_qoff[nq] - qbase);
     for (int e = threadIdx.x; e < total; e += kTileBlock) {
         int ql = 0;
         while (ql + 1 < nq && s_qoff[ql + 1] - qbase <= e) ++ql;
