@@ -158,7 +158,7 @@ int tvz_match(tvz_corpus *c, const double *d_queries, const int64_t *d_q_offsets
 
 /* Host-in / host-out single query: the drop-in for db.find_duplicates.
  * Results sorted by (video_id, count).  *n_out = number of hits (if > cap only
- * cap are returned).  h_out_kth may be NULL. */
+ * cap are returned).  h_out_kth may be NULL.  Any query length is accepted. */
 int tvz_find_duplicates(tvz_corpus *c, const double *h_query, int64_t n, int32_t min_match,
                         int32_t exclude_id, int64_t cap, int32_t *h_out_ids,
                         int32_t *h_out_counts, int32_t *h_out_kth, int64_t *n_out);

@@ -128,10 +128,27 @@ def test_ragged_rows_and_long_queries(dc):
         _check_batch(dc, ids, offs, keys, queries, mm)
 
 
-def test_query_too_long_is_rejected(dc):
-    dc.upload([(1, [1.0])])
+def test_queries_longer_than_a_tile(dc):
+    """find_duplicates has no length limit (the reference has none): > 4095 timestamps take the
+    sorted-query path; the batched tvz_match keeps the documented 4095 limit."""
+    rng = np.random.default_rng(77)
+    rows = []
+    for v in range(300):
+        L = int(rng.choice([0, 1, 5, 40, 300, 5000]))
+        rows.append((v + 1, np.round(rng.uniform(0, 2000, L), 1).tolist()))
+    dc.upload(rows)
+    ids, offs, keys = tc.rows_to_csr(rows)
+    for n in (4096, 5000, 12000):
+        q = np.round(rng.uniform(0, 2000, n), 1)
+        q[10:14] = [np.nan, -0.0, 0.0, q[9]]
+        for mm in (0, 1, 2, 7, 300):
+            cnt, kth = oracle.match_kth_csr(q, offs, keys, mm)
+            exp = sorted((int(ids[c]), int(cnt[c]), int(kth[c])) for c in range(len(ids))
+                         if cnt[c] >= mm and ids[c] != 5)
+            assert dc.find_duplicates(q, mm, exclude_id=5, with_kth=True) == exp, (n, mm)
+    d_q, d_off, max_len = tc.pack_queries([np.arange(5000, dtype=np.float64)], DEV)
     with pytest.raises(RuntimeError, match="exceeds the supported"):
-        dc.find_duplicates(np.arange(5000, dtype=np.float64), 1)
+        dc.match(d_q, d_off, max_len, 1, 8)
 
 
 def test_hit_list_overflow_reports_true_count(dc):

@@ -342,6 +342,48 @@ __global__ __launch_bounds__(kTileBlock) void ts_match_tile_kernel(
     }
 }
 
+// ---- queries longer than a tile (> 4095 timestamps): counts by searching the SORTED query ----
+// Rare (a video with thousands of cuts), so simple beats fast: a 16-lane group owns a row, every
+// row key is binary-searched in the query's sorted distinct keys (sq, with multiplicities) and the
+// hit (video_id, count) is emitted with kth = -2 - row, which ts_kth_fixup_kernel resolves.
+template <int CTRL>
+__device__ __forceinline__ int dpp_row16(int v) {
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true);
+}
+
+__global__ __launch_bounds__(kBlock) void ts_match_longq_kernel(
+    const Row *__restrict__ rows, int64_t n_rows, const int64_t *__restrict__ keys,
+    const int64_t *__restrict__ sq, const int32_t *__restrict__ smult, int32_t m, int32_t min_match,
+    int32_t cap, int32_t *__restrict__ hits, int32_t *__restrict__ hits_n) {
+    const int gl = threadIdx.x & (kGroup - 1);
+    const int64_t r = (int64_t)blockIdx.x * kGroupsPerBlock + threadIdx.x / kGroup;
+    if (r >= n_rows) return;                       // whole 16-lane groups leave together
+    const Row row = rows[r];
+    const int64_t *rk = keys + row.off;
+    int cnt = 0;
+    for (int i = gl; i < row.len; i += kGroup) {
+        const int64_t k = rk[i];
+        int lo = 0, hi = m;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (sq[mid] < k) lo = mid + 1; else hi = mid;
+        }
+        if (lo < m && sq[lo] == k) cnt += smult[lo];
+    }
+    cnt += dpp_row16<0xB1>(cnt);    // quad_perm [1,0,3,2]
+    cnt += dpp_row16<0x4E>(cnt);    // quad_perm [2,3,0,1]
+    cnt += dpp_row16<0x141>(cnt);   // row_half_mirror
+    cnt += dpp_row16<0x140>(cnt);   // row_mirror
+    if (gl == 0 && cnt >= min_match) {
+        const int slot = atomicAdd(&hits_n[0], 1);
+        if (slot < cap) {
+            hits[slot * 3 + 0] = row.vid;
+            hits[slot * 3 + 1] = cnt;
+            hits[slot * 3 + 2] = (min_match <= 0) ? -1 : -2 - (int32_t)r;
+        }
+    }
+}
+
 // kth for min_match > 5: per stored hit, walk the query in order and binary-search the row.
 __global__ __launch_bounds__(kBlock) void ts_kth_fixup_kernel(
     const Row *__restrict__ rows, const int64_t *__restrict__ keys,
@@ -550,6 +592,7 @@ struct Staging {
     int32_t *d_hits = nullptr;   int64_t hits_cap = 0;
     int32_t *d_hits_n = nullptr;
     int32_t *h_hits = nullptr;   int64_t h_hits_cap = 0;  // pinned
+    int64_t *d_sq = nullptr;     int32_t *d_smult = nullptr;  int64_t sq_cap = 0;  // long queries
     int64_t *h_small = nullptr;                          // pinned: qoff[2] + hits_n
 };
 
@@ -736,6 +779,8 @@ void staging_free(Staging *s) {
     if (s->d_hits_n) (void)hipFree(s->d_hits_n);
     if (s->h_hits) (void)hipHostFree(s->h_hits);
     if (s->h_small) (void)hipHostFree(s->h_small);
+    if (s->d_sq) (void)hipFree(s->d_sq);
+    if (s->d_smult) (void)hipFree(s->d_smult);
     if (s->stream) (void)hipStreamDestroy(s->stream);
     delete s;
 }
@@ -896,9 +941,7 @@ TVZ_EXPORT int tvz_find_duplicates(tvz_corpus *c, const double *h_query, int64_t
     TVZ_REQUIRE(n >= 0 && cap >= 0 && cap <= INT32_MAX, "bad size");
     TVZ_REQUIRE(n == 0 || h_query, "h_query is NULL");
     TVZ_REQUIRE(cap == 0 || (h_out_ids && h_out_counts), "NULL outputs");
-    if (n > kMaxQueryLen)
-        return tvz::fail(TVZ_ERR_UNSUPPORTED, "query of %lld timestamps exceeds the supported %d",
-                         (long long)n, kMaxQueryLen);
+    TVZ_REQUIRE(n <= INT32_MAX, "query too long");
     DeviceGuard dg(c->device);
     Staging *s = nullptr;
     if (int rc = staging_get(c, &s)) return rc;
@@ -920,11 +963,56 @@ TVZ_EXPORT int tvz_find_duplicates(tvz_corpus *c, const double *h_query, int64_t
     TVZ_HIP(hipMemcpyAsync(s->d_qoff, s->h_small, 16, hipMemcpyHostToDevice, s->stream));
     if (n) TVZ_HIP(hipMemcpyAsync(s->d_query, h_query, (size_t)n * 8, hipMemcpyHostToDevice, s->stream));
     int32_t *d_excl = nullptr;  // exclusion is applied on the host for the single-query form
-    {
+    if (n <= kMaxQueryLen) {
         std::shared_lock<std::shared_mutex> lk(c->mu);
         if (int rc = launch_match(c, s->d_query, s->d_qoff, 1, (int32_t)n, min_match, d_excl,
                                   (int32_t)cap, s->d_hits, s->d_hits_n, s->stream))
             return rc;
+        if (int rc = record(c, s->stream)) return rc;
+    } else {
+        // longer than a query tile: sorted distinct keys + multiplicities, searched per row key
+        std::vector<int64_t> sk;
+        sk.reserve((size_t)n);
+        for (int64_t i = 0; i < n; ++i) {
+            int64_t k;
+            if (canon_key(h_query[i], k)) sk.push_back(k);
+        }
+        std::sort(sk.begin(), sk.end());
+        std::vector<int64_t> uq;
+        std::vector<int32_t> mult;
+        for (size_t i = 0; i < sk.size(); ++i) {
+            if (!uq.empty() && uq.back() == sk[i]) ++mult.back();
+            else { uq.push_back(sk[i]); mult.push_back(1); }
+        }
+        const int64_t m = (int64_t)uq.size();
+        if (m + 1 > s->sq_cap) {
+            if (s->d_sq) (void)hipFree(s->d_sq);
+            if (s->d_smult) (void)hipFree(s->d_smult);
+            s->sq_cap = m + 1;
+            TVZ_HIP(hipMalloc(&s->d_sq, (size_t)s->sq_cap * 8));
+            TVZ_HIP(hipMalloc(&s->d_smult, (size_t)s->sq_cap * 4));
+        }
+        if (m) {
+            TVZ_HIP(hipMemcpyAsync(s->d_sq, uq.data(), (size_t)m * 8, hipMemcpyHostToDevice, s->stream));
+            TVZ_HIP(hipMemcpyAsync(s->d_smult, mult.data(), (size_t)m * 4, hipMemcpyHostToDevice, s->stream));
+        }
+        TVZ_HIP(hipMemsetAsync(s->d_hits_n, 0, sizeof(int32_t), s->stream));
+        std::shared_lock<std::shared_mutex> lk(c->mu);
+        const int64_t n_rows = (int64_t)c->h_rows.size();
+        if (n_rows) {
+            hipLaunchKernelGGL(ts_match_longq_kernel, dim3((unsigned)tvz::ceil_div(n_rows, kGroupsPerBlock)),
+                               dim3(kBlock), 0, s->stream, c->rows.p, n_rows, c->keys.p, s->d_sq,
+                               s->d_smult, (int32_t)m, min_match, (int32_t)cap, s->d_hits, s->d_hits_n);
+            TVZ_HIP(hipGetLastError());
+            if (min_match > 0) {
+                hipLaunchKernelGGL(ts_kth_fixup_kernel, dim3(1), dim3(kBlock), 0, s->stream, c->rows.p,
+                                   c->keys.p, s->d_query, s->d_qoff, min_match, (int32_t)cap, s->d_hits,
+                                   s->d_hits_n);
+                TVZ_HIP(hipGetLastError());
+            }
+        }
+        // the staging stream reads the vectors above asynchronously: finish before they go away
+        TVZ_HIP(hipStreamSynchronize(s->stream));
         if (int rc = record(c, s->stream)) return rc;
     }
     int32_t *h_n = reinterpret_cast<int32_t *>(s->h_small + 2);
