@@ -225,3 +225,36 @@ def test_16bit_padded_rows_generic_path():
     torch.cuda.synchronize()
     o_sad = oracle.luma_sad(big[:, 3:33, 5:58])
     assert (sad.cpu().numpy().view(np.uint64) == o_sad).all()
+
+
+def test_fuzz_shapes_strides_chunking():
+    """Seeded fuzz: random sizes (flat and generic paths), padded/unaligned views, random chunking
+    with carried state, 8- and 16-bit: always bit-exact against the oracle."""
+    rng = np.random.default_rng(424242)
+    for trial in range(40):
+        H, W, T = int(rng.integers(1, 97)), int(rng.integers(1, 130)), int(rng.integers(1, 200))
+        if trial % 5 == 0:
+            H, W = int(rng.integers(1, 40)) * 2, int(rng.integers(1, 40)) * 8      # flat-eligible
+        s16 = trial % 3 == 2
+        bd = int(rng.choice([10, 12, 16])) if s16 else 8
+        pad_h, pad_w, off_h, off_w = (int(x) for x in rng.integers(0, 5, 4))
+        dt = np.uint16 if s16 else np.uint8
+        big = rng.integers(0, 1 << bd, size=(T, H + pad_h + off_h, W + pad_w + off_w)).astype(dt)
+        big[T // 2:] = (big[T // 2:] // 3).astype(dt)                 # a level change: real cuts
+        view_np = big[:, off_h:off_h + H, off_w:off_w + W]
+        d_big = torch.from_numpy(big.view(np.int16) if s16 else big).to(DEV)
+        d_view = d_big[:, off_h:off_h + H, off_w:off_w + W]
+        o_sad = oracle.luma_sad(view_np)
+        o_sel, o_score, o_mafd, _ = oracle.scene_select(o_sad, H, W, 0.3, bitdepth=bd)
+        step = int(rng.integers(1, T + 1))
+        sc = scene.SceneScorer(H, W, step, DEV, 0.3, bitdepth=bd)
+        sads, sels, scores = [], [], []
+        for s0 in range(0, T, step):
+            part = d_view[s0:s0 + step]
+            sad, mafd, score, sel = sc.score_batch(part)
+            sc.remember_tail(part)
+            sads.append(sad.cpu().numpy().view(np.uint64).copy())
+            sels.append(sel.cpu().numpy().copy())
+            scores.append(score.cpu().numpy().copy())
+        assert (np.concatenate(sads) == o_sad).all(), (trial, H, W, T, step, bd)
+        assert (np.concatenate(scores) == o_score).all() and (np.concatenate(sels) == o_sel).all(), trial
