@@ -33,6 +33,10 @@
 
 #include "tvz_common.h"
 
+#ifndef TVZ_MATCH_STEP
+#define TVZ_MATCH_STEP 2   // 16-byte key loads per lane and sweep step (4 keys); 3/4/6 measured no faster
+#endif
+
 namespace {
 
 constexpr int kBlock = 256;
@@ -281,24 +285,35 @@ __global__ __launch_bounds__(kTileBlock) void ts_match_tile_kernel(
         if (live) row = rows[r];
         const int64_t *rk = keys + row.off + gl * 2;
         const int nmine = row.len - gl * 2;                       // keys at or after this lane's first
-        longlong2 v0 = make_longlong2(0, 0), v1 = v0;
-        if (nmine > 0) v0 = *reinterpret_cast<const longlong2 *>(rk);
-        if (nmine > kGroup * 2) v1 = *reinterpret_cast<const longlong2 *>(rk + kGroup * 2);
-        for (int i = 0; __ballot(i < nmine) != 0ull; i += 2 * kGroup * 2) {
-            const int64_t kk[4] = {v0.x, v0.y, v1.x, v1.y};
-            const int in = i + 2 * kGroup * 2;                    // next step's loads, in flight
-            if (in < nmine) v0 = *reinterpret_cast<const longlong2 *>(rk + in);
-            if (in + kGroup * 2 < nmine) v1 = *reinterpret_cast<const longlong2 *>(rk + in + kGroup * 2);
-            uint32_t pr[4], tg[4];
-            uint2 w[4];
+        // kStep 16-byte loads (2 keys each) per lane and step, the next step's loads in flight
+        constexpr int kStep = TVZ_MATCH_STEP;
+        constexpr int kStride = kGroup * 2;                       // keys between a lane's loads
+        longlong2 v[kStep];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < kStep; ++j)
+            v[j] = (nmine > j * kStride) ? *reinterpret_cast<const longlong2 *>(rk + j * kStride)
+                                         : make_longlong2(0, 0);
+        for (int i = 0; __ballot(i < nmine) != 0ull; i += kStep * kStride) {
+            int64_t kk[2 * kStep];
+#pragma unroll
+            for (int j = 0; j < kStep; ++j) {
+                kk[2 * j] = v[j].x;
+                kk[2 * j + 1] = v[j].y;
+            }
+            const int in = i + kStep * kStride;
+#pragma unroll
+            for (int j = 0; j < kStep; ++j)
+                if (in + j * kStride < nmine) v[j] = *reinterpret_cast<const longlong2 *>(rk + in + j * kStride);
+            uint32_t pr[2 * kStep], tg[2 * kStep];
+            uint2 w[2 * kStep];
+#pragma unroll
+            for (int j = 0; j < 2 * kStep; ++j) {
                 hash_pair_tag(kk[j], pr[j], tg[j]);
                 w[j] = pairs[pr[j]];
             }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const bool valid = i + (j / 2) * kGroup * 2 + (j & 1) < nmine;
+            for (int j = 0; j < 2 * kStep; ++j) {
+                const bool valid = i + (j / 2) * kStride + (j & 1) < nmine;
                 // needs the slow path: tag present in the home pair, or the pair is full
                 const bool slow = valid & (((w[j].x >> 16) == tg[j]) | (w[j].y != kFree));
                 const unsigned long long bal = __ballot(slow);
