@@ -10,19 +10,24 @@
 //   keys    = arena of canonical float64 bit patterns (int64): per row sorted, unique,
 //             NaN dropped, -0.0 folded to +0.0; every row starts 16-byte aligned.
 //
-// Kernel ts_match_tile_kernel: grid = (row chunks, query tiles).  A 1024-thread block builds ONE
-//   hash table in LDS for a tile of up to 16 queries (open addressing on the canonical key; each
-//   key heads a chain of (query-in-tile, position) entries, so query multiplicity is exact), then
-//   sweeps its chunk of rows: a 16-lane group owns one row at a time, streams its keys with
-//   16-byte loads (up to 4 in flight per lane) and probes the table ONCE per key for all queries
-//   of the tile - the Q-tile plays the role a GEMM tile plays: every corpus byte loaded is reused
-//   16 times on chip.  A chain hit bumps the (group, query) counter and the two smallest matching
-//   positions with LDS atomics; after the row, lane q of the group emits query q's hit
-//   (video_id, count, kth).  kth = min_match-th smallest matching position: read from the five
-//   tracked minima for min_match <= 5 (the reference's default 5 and the driver's 2), by ts_kth_fixup_kernel (binary search of
-//   the sorted row per query position) for min_match > 5.  Integer/LDS-bound: no MFMA.
+// Kernel ts_match_tile_kernel<TOP5>: grid = (row chunks, query tiles).  A 1024-thread block builds
+//   ONE hash table in LDS for a tile of up to 16 queries (16-bit tag + chain head per slot, two
+//   slots per aligned 8-byte probe; every query element is a chained (key, position, query) entry,
+//   so query multiplicity is exact), then sweeps its chunk of rows: a 16-lane group owns one row
+//   at a time, streams its keys with 16-byte loads and probes the table ONCE per key for all the
+//   queries of the tile - the tile plays the role a GEMM tile plays: every corpus byte loaded is
+//   reused 16 times on chip.  The per-key fast path is branch-free; lanes that found their tag
+//   (or a full home pair) push the key into a per-wave LDS ring by ballot/mbcnt compaction and the
+//   wave drains the ring 64 entries at a time with every lane busy on the exact probe, full-key
+//   verification and accounting (LDS atomics: hit count + the smallest matching positions).
+//   After a row, lane q of the group emits query q's hit (video_id, count, kth); kth = the
+//   min_match-th smallest matching position, read from the tracked minima for min_match <= 5
+//   (the reference's default 5 and the driver's 2), by ts_kth_fixup_kernel beyond.
+//   Integer / LDS / issue-bound: no MFMA.
+// Kernel ts_match_longq_kernel: single queries longer than a tile (> 4095 timestamps).
 // Kernel ts_topk_kernel: per query bitonic selection of the k best hits ordered by
 //   (kth, video_id, count) over one or several (all-gathered) hit lists.
+// Kernel ts_align_kernel: opt-in shift/tolerance score (never the verdict).
 #include <algorithm>
 #include <climits>
 #include <cstring>
@@ -60,15 +65,6 @@ __host__ __device__ inline bool canon_key(double x, int64_t &k) {
     if (mag > 0x7ff0000000000000ULL) return false;  // NaN: == is always false
     k = (mag == 0) ? 0 : b;                         // -0.0 == +0.0
     return true;
-}
-
-__device__ __forceinline__ uint32_t hash_key(int64_t k, int shift) {
-    const uint32_t lo = (uint32_t)k, hi = (uint32_t)((uint64_t)k >> 32);
-    uint32_t x = lo ^ (hi * 0x9E3779B1u);
-    x *= 0x85EBCA6Bu;
-    x ^= x >> 15;
-    x *= 0xC2B2AE35u;
-    return x >> shift;
 }
 
 // ---- query tile: up to 16 queries share ONE hash table in LDS -----------------------------
