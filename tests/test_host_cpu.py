@@ -202,3 +202,19 @@ def test_y4m_round_trip(tmp_path):
         assert r.read_into(buf) == 5 and (buf == luma[:5]).all()
         assert r.read_into(buf) == 2 and (buf[:2] == luma[5:]).all()
         r.close()
+
+
+def test_y4m_high_bit_depth_round_trip(tmp_path):
+    rng = np.random.default_rng(1)
+    luma = rng.integers(0, 1024, size=(5, 10, 14), dtype=np.uint16)
+    for chroma in ("mono", "420", "444"):
+        p = str(tmp_path / f"hb_{chroma}.y4m")
+        feeder.write_y4m(p, luma, fps=(24, 1), chroma=chroma, bitdepth=10)
+        r = feeder.Y4MReader(p)
+        assert (r.W, r.H, r.bitdepth, r.bps, r.total_frames) == (14, 10, 10, 2, 5)
+        assert (np.stack(list(r)) == luma).all()
+        r.close()
+        r = feeder.Y4MReader(p)
+        buf = np.zeros((5, 10, 14), dtype=np.int16)
+        assert r.read_into(buf) == 5 and (buf.view(np.uint16) == luma).all()
+        r.close()

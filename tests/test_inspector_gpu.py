@@ -126,3 +126,21 @@ def test_concurrent_uploads(rig):
     res = [f.result(timeout=120) for f in futs]
     assert all(r["status"] == "done" for r in res)
     assert [r["duplicates"] for r in res] == [["v0.y4m"], ["v1.y4m"], ["v2.y4m"]]
+
+
+def test_ten_bit_upload_end_to_end(rig):
+    """A yuv420p10-style clip through reader -> feeder -> 16-bit scene kernels -> verdict."""
+    ins, store, files, tmp = rig
+    a8 = _clip(5, [40, 111, 190])
+    a10 = (a8.astype(np.uint16) << 2) | 1                      # 10-bit samples
+    for name in ("1700000050-hdr.y4m", "1700000051-hdr_copy.y4m"):
+        files[name] = str(tmp / name)
+        feeder.write_y4m(files[name], a10, chroma="420", bitdepth=10)
+    sad = oracle.luma_sad(a10)
+    sel, _, _, _ = oracle.scene_select(sad, H, W, 0.3, bitdepth=10)
+    exp = [oracle.pts_time_value(int(i), 1, 30, 0) for i in np.flatnonzero(sel)]
+    assert [round(x * 30) for x in exp] == [40, 111, 190]
+    r1 = ins.analyze_file("videos", "1700000050-hdr.y4m")
+    assert r1["status"] == "done" and r1["scene_cuts"] == exp and r1["duplicates"] == []
+    r2 = ins.analyze_file("videos", "1700000051-hdr_copy.y4m")
+    assert r2["status"] == "done" and r2["duplicates"] == ["hdr.y4m"] and r2["scene_cuts"] == exp[:2]

@@ -63,13 +63,20 @@ class Y4MReader:
                 fps = (int(n), int(d))
             elif k == b"C":
                 cs = v
-        if "p10" in cs or "p12" in cs or "p16" in cs:
-            raise RuntimeError(f"only 8-bit Y4M is supported (C{cs})")
+        # high bit depth: C420p10, C422p12, C444p16, Cmono16 ... = little-endian 16-bit samples
+        self.bitdepth = 8
+        base = cs
+        for suffix, bd in (("p9", 9), ("p10", 10), ("p12", 12), ("p14", 14), ("p16", 16)):
+            if cs.endswith(suffix):
+                self.bitdepth, base = bd, cs[: -len(suffix)]
+        if cs in ("mono9", "mono10", "mono12", "mono16"):
+            self.bitdepth, base = int(cs[4:]), "mono"
+        self.bps = 1 if self.bitdepth == 8 else 2
         if self.W <= 0 or self.H <= 0:
             raise RuntimeError("Y4M header without W/H")
         self.time_base = (fps[1], fps[0])       # ffmpeg's yuv4mpegpipe demuxer: 1/fps
-        self._luma = self.W * self.H
-        self._skip = _chroma_bytes(cs, self.W, self.H)
+        self._luma = self.W * self.H * self.bps
+        self._skip = _chroma_bytes(base, self.W, self.H) * self.bps
         self.total_frames = 0
         if self._own:
             size = os.path.getsize(src) - len(header)
@@ -87,12 +94,13 @@ class Y4MReader:
                 return
             if self._skip:
                 self.f.seek(self._skip, io.SEEK_CUR) if self.f.seekable() else self.f.read(self._skip)
-            yield np.frombuffer(buf, dtype=np.uint8).reshape(self.H, self.W)
+            yield np.frombuffer(buf, dtype=np.uint8 if self.bps == 1 else "<u2").reshape(self.H, self.W)
 
     def read_into(self, out: np.ndarray) -> int:
-        """Fill out[n,H,W] with up to n frames; returns how many were read."""
+        """Fill out[n,H,W] (uint8, or a 16-bit dtype for high bit depth) with up to n frames;
+        returns how many were read."""
         n = 0
-        flat = out.reshape(out.shape[0], -1)
+        flat = out.reshape(out.shape[0], -1).view(np.uint8)
         while n < out.shape[0]:
             line = self.f.readline()
             if not line:
@@ -112,15 +120,23 @@ class Y4MReader:
             self.f.close()
 
 
-def write_y4m(path: str, luma: np.ndarray, fps: Tuple[int, int] = (30, 1), chroma: str = "mono") -> None:
-    """Write uint8 [T,H,W] luma as Y4M (mono, or 420jpeg with neutral chroma) — test/fixture helper."""
+def write_y4m(path: str, luma: np.ndarray, fps: Tuple[int, int] = (30, 1), chroma: str = "mono",
+              bitdepth: int = 8) -> None:
+    """Write [T,H,W] luma as Y4M — test/fixture helper.  uint8 for bitdepth 8 (chroma "mono",
+    "420jpeg", "444"...), uint16 for 9..16 (written as C<chroma>p<bitdepth> / Cmono<bitdepth>,
+    little-endian); chroma planes are neutral."""
     T, H, W = luma.shape
+    bps = 1 if bitdepth == 8 else 2
+    tag = chroma if bitdepth == 8 else (f"mono{bitdepth}" if chroma == "mono" else f"{chroma}p{bitdepth}")
     with open(path, "wb") as f:
-        f.write(f"YUV4MPEG2 W{W} H{H} F{fps[0]}:{fps[1]} Ip A1:1 C{chroma}\n".encode())
-        pad = bytes([128]) * _chroma_bytes(chroma, W, H)
+        f.write(f"YUV4MPEG2 W{W} H{H} F{fps[0]}:{fps[1]} Ip A1:1 C{tag}\n".encode())
+        if bps == 1:
+            pad = bytes([128]) * _chroma_bytes(chroma, W, H)
+        else:
+            pad = np.full(_chroma_bytes(chroma, W, H), 1 << (bitdepth - 1), dtype="<u2").tobytes()
         for t in range(T):
             f.write(b"FRAME\n")
-            f.write(np.ascontiguousarray(luma[t]).tobytes())
+            f.write(np.ascontiguousarray(luma[t], dtype=np.uint8 if bps == 1 else "<u2").tobytes())
             f.write(pad)
 
 
@@ -147,6 +163,7 @@ class FFmpegReader:
         n, d = info["time_base"].split("/")
         self.time_base = (int(n), int(d))
         self.total_frames = int(info["nb_frames"]) if info.get("nb_frames", "").isdigit() else 0
+        self.bitdepth, self.bps = 8, 1
         self._luma = self.W * self.H
         self._skip = _chroma_bytes(self.PLANAR8[self.pix_fmt], self.W, self.H)
         self.proc = subprocess.Popen([self.ffmpeg, "-v", "error", "-i", path, "-f", "rawvideo",
@@ -183,11 +200,13 @@ class FrameFeeder:
         self.batch = int(batch)
         self.device = torch.device(device)
         self.n_slots = n_slots
+        self.bitdepth = getattr(reader, "bitdepth", 8)
+        dt = torch.uint8 if self.bitdepth == 8 else torch.int16     # int16 carries the uint16 bits
         # straight from torch's caching host allocator: freed slots of a finished upload are reused
         # by the next one (a .pin_memory() copy would page-lock ~0.5 GB per slot every time)
-        self.pinned = [torch.empty((self.batch, self.H, self.W), dtype=torch.uint8, pin_memory=True)
+        self.pinned = [torch.empty((self.batch, self.H, self.W), dtype=dt, pin_memory=True)
                        for _ in range(n_slots)]
-        self.dev = [torch.empty((self.batch, self.H, self.W), dtype=torch.uint8, device=self.device)
+        self.dev = [torch.empty((self.batch, self.H, self.W), dtype=dt, device=self.device)
                     for _ in range(n_slots)]
         self.copy_stream = torch.cuda.Stream(self.device)
         self._released = [None] * n_slots   # event on the consumer's stream: slot's kernels enqueued

@@ -143,7 +143,8 @@ class Inspector:
         """GPU restatement of the hot loop app.py:216-291."""
         time_base = reader.time_base
         total_frames = getattr(reader, "total_frames", 0) or 0
-        scorer = scene.SceneScorer(reader.H, reader.W, self.batch, self.device, self.threshold)
+        scorer = scene.SceneScorer(reader.H, reader.W, self.batch, self.device, self.threshold,
+                                   bitdepth=getattr(reader, "bitdepth", 8))
         feeder = FrameFeeder(reader, self.batch, self.device)
         scene_timestamps: List[float] = []
         dups_to_report: List[str] = []

@@ -201,7 +201,8 @@ def detect_scene_cuts(frames: Union[torch.Tensor, Iterable], time_base: Tuple[in
         if chunk.dim() != 3:
             raise RuntimeError("each chunk must be [T,H,W]")
         if scorer is None:
-            scorer = SceneScorer(chunk.shape[1], chunk.shape[2], batch, dev, threshold)
+            scorer = SceneScorer(chunk.shape[1], chunk.shape[2], batch, dev, threshold,
+                                 bitdepth=8 if chunk.dtype == torch.uint8 else 16)
         for s in range(0, chunk.shape[0], scorer.max_batch):
             part = chunk[s:s + scorer.max_batch]
             if part.device != scorer.device:
