@@ -56,6 +56,7 @@ SIGNATURES = {
                             C.c_void_p]),
     # not part of the stable ABI (kernel-shape A/B knob)
     "tvz_scene_set_tuning": (C.c_int, [C.c_int, C.c_int, C.c_int]),
+    "tvz_match_set_tuning": (C.c_int, [C.c_int]),
 }
 
 _lock = threading.Lock()

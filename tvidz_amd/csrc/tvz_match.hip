@@ -353,6 +353,191 @@ __global__ __launch_bounds__(kTileBlock) void ts_match_tile_kernel(
     }
 }
 
+// ---- hash join for large query batches (Q >= 32, min_match <= 2) ----------------------------
+// The LDS tile kernel probes every corpus key once per 16 queries.  For big batches against big
+// corpora a database hash JOIN does less work: build one multimap per tile of 128 queries in device
+// memory (sized to stay in one XCD's 4 MiB L2), then sweep the corpus once per tile - one probe of a
+// corpus key serves 128 queries, 8x fewer probes than the LDS tile.  Blocks of one tile are mapped
+// to one XCD (blockIdx % 8) so its table is served from that XCD's L2.  What it buys is bounded by
+// the L2: a random 16-byte probe moves a whole cache line, and the measured probe rate (~180 G/s)
+// is the L2's random-line rate - LDS has no line granularity, which is why the LDS tile stays
+// competitive with 8x the probes (1.77 vs 2.27 ms at C=100k, Q=1024).  Per (row group, query) state lives in LDS: a u16 hit
+// counter and the two smallest matching positions (u16 + u16 in one CAS word); after a row each
+// lane scans 8 of the tile's 128 queries and emits the hits.
+constexpr int kJoinQ = 128;
+constexpr int kJoinBlock = 1024;
+constexpr int kJoinGroups = kJoinBlock / kGroup;
+constexpr size_t kJoinLds = (size_t)kJoinGroups * kJoinQ * 6;     // 48 KiB
+constexpr int64_t kJEmpty = -1;                                    // 0xff..ff: a NaN pattern
+
+__device__ __forceinline__ uint32_t hash32(int64_t k) {
+    const uint32_t lo = (uint32_t)k, hi = (uint32_t)((uint64_t)k >> 32);
+    uint32_t x = lo ^ (hi + (hi << 3)) ^ (hi >> 9);
+    x ^= x >> 20;
+    const uint32_t y = __umul24(x, 0x9E3779u);
+    return y ^ (y >> 15);
+}
+
+// Table layout: keys int64[S] and packs u32[S] apart, so ONE 16-byte load fetches the two keys of a
+// slot pair; the (position | query-in-tile << 12) pack is only loaded on a match.  Random global
+// accesses cost the CU's address pipeline ~1 lane-address per cycle, so loads per probe are what
+// bounds this kernel (an array-of-structs slot needed two loads per probe: 1.6x slower).
+
+// The table is a MULTIMAP: every query element takes its own slot (the first free one of its key's
+// probe sequence), so a lookup needs no dependent chain loads - it walks the probe sequence up to
+// the first free slot and accounts every slot that carries the key.  (A chained layout was tried:
+// on a 64-lane wave some lane almost always has a chain to follow, and each hop is a dependent
+// ~1 us L2 access.)
+__global__ __launch_bounds__(kBlock) void ts_join_build_kernel(
+    const double *__restrict__ queries, const int64_t *__restrict__ q_offsets, int32_t Q,
+    int32_t max_len, int32_t s_log2, unsigned long long *__restrict__ tkeys,
+    uint32_t *__restrict__ tpack, int32_t *__restrict__ hits_n) {
+    const int q = blockIdx.y;
+    const int64_t o = q_offsets[q];
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    const int64_t len = q_offsets[q + 1] - o;
+    if (len > max_len) {
+        // max_query_len was not an upper bound (the table is sized from it): nothing of this
+        // query is inserted and its counter is poisoned instead (stays negative)
+        if (i == 0) hits_n[q] = INT32_MIN;
+        return;
+    }
+    if (i >= (int)len) return;
+    int64_t k;
+    if (!canon_key(queries[o + i], k)) return;                     // NaN never matches
+    const uint32_t smask = (1u << s_log2) - 1u;
+    const size_t tb = (size_t)(q / kJoinQ) << s_log2;
+    uint32_t h = (hash32(k) >> (32 - s_log2)) & ~1u;               // home pair
+    while (true) {
+        const unsigned long long old = atomicCAS(&tkeys[tb + h], (unsigned long long)kJEmpty,
+                                                 (unsigned long long)k);
+        if (old == (unsigned long long)kJEmpty) break;             // claimed a free slot
+        h = (h + 1) & smask;
+    }
+    tpack[tb + h] = (uint32_t)i | ((uint32_t)(q % kJoinQ) << 12);
+}
+
+__global__ __launch_bounds__(kJoinBlock) void ts_match_join_kernel(
+    const Row *__restrict__ rows, int64_t n_rows, const int64_t *__restrict__ keys,
+    const int64_t *__restrict__ tkeys, const uint32_t *__restrict__ tpack, int32_t s_log2,
+    int32_t Q, int32_t n_tiles, int32_t n_chunks,
+    int32_t min_match, const int32_t *__restrict__ exclude_ids, int32_t cap,
+    int32_t *__restrict__ hits, int32_t *__restrict__ hits_n, int32_t rows_per_block) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint32_t *m12_all = reinterpret_cast<uint32_t *>(smem);                    // [groups][128]
+    uint32_t *cnt_all = m12_all + kJoinGroups * kJoinQ;                        // [groups][64] 2 x u16
+    // block -> (tile, chunk): blocks of one tile share blockIdx % 8, i.e. (observed) one XCD and its L2
+    const int b = blockIdx.x;
+    int tile, chunk;
+    if (8 % n_tiles == 0) {
+        const int g = 8 / n_tiles;                                             // XCDs per tile
+        tile = (b % 8) / g;
+        chunk = (b / 8) * g + (b % 8) % g;
+    } else if (n_tiles % 8 == 0) {
+        tile = (b % 8) + 8 * ((b / 8) % (n_tiles / 8));
+        chunk = (b / 8) / (n_tiles / 8);
+    } else {
+        tile = b / n_chunks;
+        chunk = b % n_chunks;
+    }
+    if (tile >= n_tiles || chunk >= n_chunks) return;
+    const int gl = threadIdx.x & (kGroup - 1);
+    const int g = threadIdx.x / kGroup;
+    uint32_t *m12 = m12_all + g * kJoinQ;
+    uint32_t *cntw = cnt_all + g * (kJoinQ / 2);
+    for (int i = gl; i < kJoinQ; i += kGroup) m12[i] = 0xffffffffu;
+    for (int i = gl; i < kJoinQ / 2; i += kGroup) cntw[i] = 0;
+    const int q0 = tile * kJoinQ;
+    const uint32_t smask = (1u << s_log2) - 1u;
+    const int64_t *tk = tkeys + ((size_t)tile << s_log2);
+    const uint32_t *tp = tpack + ((size_t)tile << s_log2);
+    const int64_t r0 = (int64_t)chunk * rows_per_block;
+    int64_t r1 = r0 + rows_per_block;
+    if (r1 > n_rows) r1 = n_rows;
+
+    auto account = [&](uint32_t pk) {                    // one matching (query, position) entry
+        const uint32_t ql = pk >> 12, pos = pk & 0xfffu;
+        atomicAdd(&cntw[ql >> 1], 1u << (16 * (ql & 1)));
+        uint32_t seen = m12[ql];
+        while (true) {
+            const uint32_t m1 = seen & 0xffffu, m2 = seen >> 16;
+            if (pos >= m2) break;
+            const uint32_t nw = pos < m1 ? ((m1 << 16) | pos) : ((pos << 16) | m1);
+            const uint32_t old = atomicCAS(&m12[ql], seen, nw);
+            if (old == seen) break;
+            seen = old;
+        }
+    };
+    constexpr int kK = 4;                                // keys per lane and step: 8 table loads in flight
+    for (int64_t r = r0 + g; r < r1; r += kJoinGroups) {
+        const Row row = rows[r];
+        const int64_t *rk = keys + row.off;
+        for (int i0 = gl * 2; i0 < row.len; i0 += kGroup * kK) {
+            int64_t kk[kK];
+            bool valid[kK];
+#pragma unroll
+            for (int j = 0; j < kK / 2; ++j) {
+                const int i = i0 + j * kGroup * 2;
+                longlong2 v = make_longlong2(0, 0);
+                if (i < row.len) v = *reinterpret_cast<const longlong2 *>(rk + i);
+                kk[2 * j] = v.x;
+                kk[2 * j + 1] = v.y;
+                valid[2 * j] = i < row.len;
+                valid[2 * j + 1] = i + 1 < row.len;
+            }
+            uint32_t h[kK];
+            longlong2 sk[kK];
+#pragma unroll
+            for (int j = 0; j < kK; ++j) {               // independent L2 reads, all in flight
+                h[j] = (hash32(kk[j]) >> (32 - s_log2)) & ~1u;
+                sk[j] = *reinterpret_cast<const longlong2 *>(tk + h[j]);
+            }
+#pragma unroll
+            for (int j = 0; j < kK; ++j) {
+                if (!valid[j]) continue;
+                if (sk[j].x == kk[j]) account(tp[h[j]]);
+                if (sk[j].x == kJEmpty) continue;
+                if (sk[j].y == kk[j]) account(tp[h[j] + 1]);
+                if (sk[j].y == kJEmpty) continue;
+                uint32_t hh = h[j];                      // home pair full: keep walking (rare)
+                while (true) {
+                    hh = (hh + 2) & smask;
+                    const longlong2 a = *reinterpret_cast<const longlong2 *>(tk + hh);
+                    if (a.x == kk[j]) account(tp[hh]);
+                    if (a.x == kJEmpty) break;
+                    if (a.y == kk[j]) account(tp[hh + 1]);
+                    if (a.y == kJEmpty) break;
+                }
+            }
+        }
+        // lane gl owns queries gl*8 .. gl*8+7 of the tile (4 counter words)
+        const uint4 cw = *reinterpret_cast<const uint4 *>(cntw + gl * 4);
+        const uint32_t w[4] = {cw.x, cw.y, cw.z, cw.w};
+        if (min_match > 0 && (cw.x | cw.y | cw.z | cw.w) == 0) continue;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const uint32_t c = (w[j >> 1] >> (16 * (j & 1))) & 0xffffu;
+            const int ql = gl * 8 + j;
+            const int q = q0 + ql;
+            if (q < Q && (int)c >= min_match) {
+                const uint32_t mm = m12[ql];
+                if (!(exclude_ids && exclude_ids[q] == row.vid)) {
+                    const int32_t kth = min_match <= 0 ? -1 : (int32_t)(min_match == 1 ? (mm & 0xffffu) : (mm >> 16));
+                    const int slot = atomicAdd(&hits_n[q], 1);
+                    if (slot < cap) {
+                        int32_t *hp = hits + ((int64_t)q * cap + slot) * 3;
+                        hp[0] = row.vid;
+                        hp[1] = (int32_t)c;
+                        hp[2] = kth;
+                    }
+                }
+            }
+            if (c) m12[ql] = 0xffffffffu;
+        }
+        *reinterpret_cast<uint4 *>(cntw + gl * 4) = make_uint4(0, 0, 0, 0);
+    }
+}
+
 // ---- queries longer than a tile (> 4095 timestamps): counts by searching the SORTED query ----
 // Rare (a video with thousands of cuts), so simple beats fast: a 16-lane group owns a row, every
 // row key is binary-searched in the query's sorted distinct keys (sq, with multiplicities) and the
@@ -607,6 +792,14 @@ struct Staging {
     int64_t *h_small = nullptr;                          // pinned: qoff[2] + hits_n
 };
 
+// device tables of one hash join; reusable once `done` has completed
+struct JoinWs {
+    unsigned char *base = nullptr;
+    size_t bytes = 0;
+    hipEvent_t done = nullptr;
+    bool busy = false;
+};
+
 template <typename T>
 struct DevBuf {
     T *p = nullptr;
@@ -631,6 +824,8 @@ struct tvz_corpus {
     bool ev_pending[kEvents] = {};
     int ev_next = 0;
     std::vector<Staging *> free_staging;
+    std::mutex join_mu;
+    std::vector<JoinWs *> join_ws;   // tables of in-flight / reusable hash joins
 };
 
 namespace {
@@ -719,6 +914,76 @@ int compact(tvz_corpus *c) {
     return upload_all(c);
 }
 
+// Dispatch (measured A/B, profiles/r1_match_join_ab.txt): the join wins only when its fixed cost
+// (table build, under-filled rounds of blocks) is amortised - C=100k x Q=1024: 1.71 ms vs 2.31 ms
+// for the LDS tile kernel, C=50k x Q=1024: 0.97 vs 1.19, C=100k x Q=256: 0.75 vs 0.93; below that
+// the tile kernel is faster (C=5k x Q=1024: 0.16 vs 0.32 ms).
+constexpr int kJoinMinQ = 256;
+constexpr int64_t kJoinMinRows = 50000;
+int g_use_join = 1;             // 0 = never, 1 = by the rule above, 2 = whenever legal (A/B knob)
+
+int join_ws_get(tvz_corpus *c, size_t bytes, JoinWs **out) {
+    std::lock_guard<std::mutex> lk(c->join_mu);
+    for (JoinWs *w : c->join_ws)
+        if (!w->busy || hipEventQuery(w->done) == hipSuccess) {
+            w->busy = true;
+            if (w->bytes < bytes) {
+                if (w->base) (void)hipFree(w->base);
+                w->base = nullptr;
+                TVZ_HIP(hipMalloc(&w->base, bytes));
+                w->bytes = bytes;
+            }
+            *out = w;
+            return TVZ_OK;
+        }
+    JoinWs *w = new JoinWs();
+    TVZ_HIP(hipEventCreateWithFlags(&w->done, hipEventDisableTiming));
+    TVZ_HIP(hipMalloc(&w->base, bytes));
+    w->bytes = bytes;
+    w->busy = true;
+    c->join_ws.push_back(w);
+    *out = w;
+    return TVZ_OK;
+}
+
+int launch_join(tvz_corpus *c, const double *d_queries, const int64_t *d_q_offsets, int32_t Q,
+                int32_t max_query_len, int32_t min_match, const int32_t *d_exclude_ids,
+                int32_t cap, int32_t *d_hits, int32_t *d_hits_n, hipStream_t st) {
+    const int64_t n_rows = (int64_t)c->h_rows.size();
+    const int n_tiles = (int)tvz::ceil_div(Q, kJoinQ);
+    // slots per tile: load factor <= 0.5 (typically ~0.25) AND small enough to live in one XCD's
+    // 4 MiB L2 next to the streamed corpus (2 MiB at max_query_len <= 512); a table of 4 MiB was
+    // measured at the Infinity-Cache random-line rate (8.5 TB/s) instead of the L2's
+    int s_log2 = 10;
+    while (((int64_t)1 << s_log2) < (int64_t)2 * kJoinQ * max_query_len) ++s_log2;
+    const size_t S = (size_t)1 << s_log2;
+    const size_t b_keys = (size_t)n_tiles * S * 8, b_pack = (size_t)n_tiles * S * 4;
+    JoinWs *ws = nullptr;
+    if (int rc = join_ws_get(c, b_keys + b_pack, &ws)) return rc;
+    unsigned long long *tkeys = reinterpret_cast<unsigned long long *>(ws->base);
+    uint32_t *tpack = reinterpret_cast<uint32_t *>(ws->base + b_keys);
+    TVZ_HIP(hipMemsetAsync(ws->base, 0xff, b_keys, st));    // every key = kJEmpty
+    hipLaunchKernelGGL(ts_join_build_kernel, dim3((unsigned)tvz::ceil_div(max_query_len, kBlock), (unsigned)Q),
+                       dim3(kBlock), 0, st, d_queries, d_q_offsets, Q, max_query_len, s_log2, tkeys, tpack,
+                       d_hits_n);
+    TVZ_HIP(hipGetLastError());
+    // two 1024-thread blocks per CU: about two rounds of 512 blocks, >= 8 rows per 16-lane group
+    const int64_t g = (8 % n_tiles == 0) ? 8 / n_tiles : 1;
+    int64_t chunks = std::max<int64_t>(1, 1024 / n_tiles);
+    chunks = std::min(chunks, std::max<int64_t>(1, n_rows / (8 * kJoinGroups)));
+    chunks = tvz::round_up(chunks, g);
+    const int64_t rpb = tvz::round_up(tvz::ceil_div(n_rows, chunks), kJoinGroups);
+    int64_t blocks = (int64_t)n_tiles * chunks;
+    if (8 % n_tiles == 0) blocks = tvz::round_up(blocks, 8);
+    hipLaunchKernelGGL(ts_match_join_kernel, dim3((unsigned)blocks), dim3(kJoinBlock), kJoinLds, st,
+                       c->rows.p, n_rows, c->keys.p, reinterpret_cast<const int64_t *>(tkeys), tpack, s_log2,
+                       Q, n_tiles, (int32_t)chunks, min_match, d_exclude_ids, cap, d_hits, d_hits_n,
+                       (int32_t)rpb);
+    TVZ_HIP(hipGetLastError());
+    TVZ_HIP(hipEventRecord(ws->done, st));                  // the tables are free again after this
+    return TVZ_OK;
+}
+
 int launch_match(tvz_corpus *c, const double *d_queries, const int64_t *d_q_offsets, int32_t Q,
                  int32_t max_query_len, int32_t min_match, const int32_t *d_exclude_ids,
                  int32_t cap, int32_t *d_hits, int32_t *d_hits_n, hipStream_t st) {
@@ -728,6 +993,10 @@ int launch_match(tvz_corpus *c, const double *d_queries, const int64_t *d_q_offs
     TVZ_HIP(hipMemsetAsync(d_hits_n, 0, (size_t)Q * sizeof(int32_t), st));
     const int64_t n_rows = (int64_t)c->h_rows.size();
     if (n_rows == 0 || Q == 0) return TVZ_OK;
+    const bool join_legal = min_match <= 2 && max_query_len > 0;
+    if (join_legal && (g_use_join == 2 || (g_use_join == 1 && Q >= kJoinMinQ && n_rows >= kJoinMinRows)))
+        return launch_join(c, d_queries, d_q_offsets, Q, max_query_len, min_match, d_exclude_ids, cap,
+                           d_hits, d_hits_n, st);
     // queries per tile: as many as keep the shared table at load <= 0.5 (at most 16)
     int nq = max_query_len > 0 ? kTileMaxEntries / max_query_len : kTileQ;
     nq = std::max(1, std::min(nq, kTileQ));
@@ -825,6 +1094,12 @@ TVZ_EXPORT int tvz_corpus_destroy(tvz_corpus *c) {
         (void)drain(c);
         for (Staging *s : c->free_staging) staging_free(s);
         c->free_staging.clear();
+        for (JoinWs *w : c->join_ws) {
+            if (w->done) { (void)hipEventSynchronize(w->done); (void)hipEventDestroy(w->done); }
+            if (w->base) (void)hipFree(w->base);
+            delete w;
+        }
+        c->join_ws.clear();
         if (c->keys.p) (void)hipFree(c->keys.p);
         if (c->rows.p) (void)hipFree(c->rows.p);
         for (int i = 0; i < tvz_corpus::kEvents; ++i)
@@ -1114,4 +1389,10 @@ TVZ_EXPORT int tvz_align(tvz_corpus *c, const double *d_query, int32_t n, double
                        c->keys.p, d_query, n, eps, (int32_t)nb, d_out);
     TVZ_HIP(hipGetLastError());
     return record(c, st);
+}
+
+// Not part of the stable ABI: 0 = LDS tile kernel only, 1 = dispatch rule, 2 = hash join whenever legal.
+TVZ_EXPORT int tvz_match_set_tuning(int use_join) {
+    g_use_join = use_join < 0 ? 0 : (use_join > 2 ? 2 : use_join);
+    return TVZ_OK;
 }
