@@ -50,7 +50,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--frames", type=int, default=10000, help="1080p frames per GPU per step")
-    ap.add_argument("--corpus", type=int, default=0, help="corpus videos (default 5000 at N=1, 100000 at N>1)")
+    ap.add_argument("--corpus", type=int, default=100000, help="corpus videos, sharded over the ranks (configs[3])")
     ap.add_argument("--queries", type=int, default=1024, help="query videos per match batch")
     ap.add_argument("--match-steps", type=int, default=20)
     ap.add_argument("--no-match", action="store_true")
@@ -167,7 +167,7 @@ def cpu_baseline_match(ids, offs, keys, queries, n_threads: int = 0):
 
 
 def bench_match(args, rank, world, dev):
-    C = args.corpus or (5000 if world == 1 else 100000)
+    C = args.corpus
     Q = args.queries
     ids, offs, keys = synth.synth_timestamp_corpus(C, seed=synth.CORPUS_SEED)
     queries = synth.synth_queries(ids, offs, keys, Q, seed=synth.CORPUS_SEED + 1)
@@ -191,38 +191,46 @@ def bench_match(args, rank, world, dev):
     pairs = Q * C * args.match_steps
     mean_len = float(offs[-1]) / C
     bytes_per_pair = 8.0 * mean_len + 8.0
-    # single-query latency of the find_duplicates drop-in (local shard only)
-    lat = []
-    for i in range(20):
-        t = time.perf_counter()
-        dc.find_duplicates(queries[i % Q], 2)
-        lat.append(time.perf_counter() - t)
+    lat = [0.0]
     n_dups = int((totals > 0).sum().item())
-    # batch-size sweep on this rank's shard (no collective): SURVEY 8d asks for Q = 1, 64 and 1024
-    by_q = {}
-    for q_n in (1, 64, 1024):
-        if q_n > Q:
-            continue
-        dq, do, ml = tc.pack_queries(queries[:q_n], dev)
-        hits = torch.empty((q_n, 1024, 3), dtype=torch.int32, device=dev)
-        n_h = torch.empty(q_n, dtype=torch.int32, device=dev)
-        ts = []
-        for r in range(12):
-            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            a.record(); dc.match(dq, do, ml, 2, 1024, out_hits=hits, out_n=n_h); b.record()
-            torch.cuda.synchronize()
-            ts.append(a.elapsed_time(b))
-        med = float(np.median(ts[2:]))
-        by_q[str(q_n)] = {"kernel_ms": round(med, 4), "pairs_per_s": q_n * len(s_ids) / (med * 1e-3)}
-    cpu = cpu_baseline_match(ids, offs, keys, queries) if (rank == 0 and world == 1 and not args.no_cpu) else None
     dc.close()
+    # configs[2]: 5k-video corpus on one GPU, batch-size sweep (SURVEY 8d asks for Q = 1, 64, 1024)
+    by_q, cpu = {}, None
+    if rank == 0 and world == 1:
+        ids5, offs5, keys5 = synth.synth_timestamp_corpus(5000, seed=synth.CORPUS_SEED)
+        q5 = synth.synth_queries(ids5, offs5, keys5, Q, seed=synth.CORPUS_SEED + 1)
+        dc5 = tc.DeviceCorpus(dev.index)
+        dc5.upload_csr(ids5, offs5, keys5)
+        for q_n in (1, 64, 1024):
+            if q_n > Q:
+                continue
+            dq, do, ml = tc.pack_queries(q5[:q_n], dev)
+            hits = torch.empty((q_n, 1024, 3), dtype=torch.int32, device=dev)
+            n_h = torch.empty(q_n, dtype=torch.int32, device=dev)
+            ts = []
+            for r in range(12):
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record(); dc5.match(dq, do, ml, 2, 1024, out_hits=hits, out_n=n_h); b.record()
+                torch.cuda.synchronize()
+                ts.append(a.elapsed_time(b))
+            med = float(np.median(ts[2:]))
+            by_q[str(q_n)] = {"kernel_ms": round(med, 4), "pairs_per_s": q_n * 5000 / (med * 1e-3)}
+        lat = []
+        for i in range(20):
+            t = time.perf_counter()
+            dc5.find_duplicates(q5[i % Q], 2)
+            lat.append(time.perf_counter() - t)
+        dc5.close()
+        if not args.no_cpu:
+            cpu = cpu_baseline_match(ids5, offs5, keys5, q5)
     return {"value": pairs / wall, "unit": "pairs/s", "corpus_videos": C, "queries_per_batch": Q,
             "mean_cuts_per_video": round(mean_len, 1), "min_match": 2, "steps": args.match_steps,
             "ms_per_batch": wall * 1e3 / args.match_steps,
             "collective": "one all_gather of [Q,65,3] int32 per batch (top-64 + hit totals)" if sm.collective else "none",
             "queries_with_hits": n_dups,
-            "find_duplicates_latency_ms_q1": round(float(np.median(lat)) * 1e3, 3),
-            "match_kernel_by_batch_size": by_q, "cpu_baseline": cpu,
+            "scaling": "strong (the same corpus is sharded over the ranks)",
+            "find_duplicates_latency_ms_q1_c5000": round(float(np.median(lat)) * 1e3, 3),
+            "config2_c5000_kernel_by_batch_size": by_q, "cpu_baseline": cpu,
             "roofline": {"bound": "hbm", "achieved": pairs * bytes_per_pair / wall / 1e9 / world,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": pairs * bytes_per_pair / wall / 1e9 / world / HBM_PEAK_GBS,
