@@ -1,5 +1,4 @@
 """CPU tests: libtvz.so loads without a GPU and exports every symbol include/tvz.h declares."""
-import ctypes
 import os
 import re
 

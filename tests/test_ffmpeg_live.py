@@ -5,9 +5,7 @@ seeded Y4M clip and the reference's own line parser."""
 import shutil
 import subprocess
 
-import numpy as np
 import pytest
-import torch
 
 from tvidz_amd import feeder, scene, synth
 

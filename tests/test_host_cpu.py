@@ -2,7 +2,6 @@
 schema and upsert rule as inspector/db.py) and the Flask routes (same cases as the reference's
 inspector/test_app.py:6-64).  The device corpus is replaced by tests/fakes.OracleCorpus."""
 import json
-import os
 import threading
 import time
 

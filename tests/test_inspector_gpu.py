@@ -2,15 +2,13 @@
 checked against the oracle's replay of the reference loop (inspector/app.py:228-255).
 BASELINE.json configs[0] shape: 10 s 480p30 clips, one a cut-shifted copy of the other."""
 import json
-import os
 
 import numpy as np
 import pytest
-import torch
 
 from oracle import oracle
 from tvidz_amd import db as tdb
-from tvidz_amd import feeder, inspector as insp, scene, synth
+from tvidz_amd import feeder, inspector as insp
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"

@@ -6,11 +6,9 @@ fixture (PARITY UNPINNED, see oracle/tvz_oracle.c): its tests only check interna
 (C vs numpy restatement, chunking, hand-computed cases).
 """
 import json
-import math
 import os
 
 import numpy as np
-import pytest
 
 from oracle import oracle
 

@@ -7,7 +7,7 @@ module only marshals arrays through the C ABI of include/tvz.h.
 from __future__ import annotations
 
 import ctypes as C
-from typing import Iterable, List, Optional, Sequence, Tuple
+from typing import Iterable, Optional, Sequence, Tuple
 
 import numpy as np
 import torch

@@ -20,7 +20,7 @@ from __future__ import annotations
 import os
 import threading
 from datetime import datetime
-from typing import List, Optional, Sequence, Tuple
+from typing import List, Optional, Tuple
 
 from sqlalchemy import JSON, Column, DateTime, Float, ForeignKey, Integer, String, create_engine
 from sqlalchemy.dialects.postgresql import ARRAY as PG_ARRAY

@@ -12,7 +12,7 @@ inspector/app.py:235-255 would report, ordered by (kth, video_id).
 """
 from __future__ import annotations
 
-from typing import Optional, Sequence, Tuple
+from typing import Optional
 
 import numpy as np
 import torch
