@@ -787,7 +787,7 @@ struct Staging {
     int64_t *d_qoff = nullptr;
     int32_t *d_hits = nullptr;   int64_t hits_cap = 0;
     int32_t *d_hits_n = nullptr;
-    int32_t *h_hits = nullptr;   int64_t h_hits_cap = 0;  // pinned
+    int32_t *h_hits = nullptr;   // pinned, hits_cap entries
     int64_t *d_sq = nullptr;     int32_t *d_smult = nullptr;  int64_t sq_cap = 0;  // long queries
     int64_t *h_small = nullptr;                          // pinned: qoff[2] + hits_n
 };
