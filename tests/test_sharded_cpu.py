@@ -95,12 +95,15 @@ def _worker(rank, world, port, C, Q, mm, k, cap, q):
         lens = [len(x) for x in queries]
         d_off = torch.from_numpy(np.concatenate([[0], np.cumsum(lens)]).astype(np.int64))
         d_q = torch.from_numpy(np.concatenate(queries))
-        merged, totals = sm.match_topk(d_q, d_off, max(lens), mm,
-                                       torch.tensor(excl, dtype=torch.int32))
+        ex = torch.tensor(excl, dtype=torch.int32)
         exp = _expected(ids, offs, keys, queries, mm, k, excl)
-        for qi in range(Q):
-            assert [tuple(int(x) for x in r) for r in merged[qi]] == exp[qi][0], (rank, qi)
-            assert int(totals[qi]) == exp[qi][1]
+        # plain call, then two batches pipelined (submit i+1 before finishing i)
+        t1 = sm.submit(d_q, d_off, max(lens), mm, ex)
+        t2 = sm.submit(d_q, d_off, max(lens), mm, ex)
+        for merged, totals in (sm.match_topk(d_q, d_off, max(lens), mm, ex), sm.finish(t1), sm.finish(t2)):
+            for qi in range(Q):
+                assert [tuple(int(x) for x in r) for r in merged[qi]] == exp[qi][0], (rank, qi)
+                assert int(totals[qi]) == exp[qi][1]
         q.put((rank, "ok"))
     except Exception as e:  # pragma: no cover
         q.put((rank, repr(e)))

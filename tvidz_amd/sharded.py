@@ -73,22 +73,33 @@ class ShardedMatcher:
         # run the all-gather even in a 1-rank group (used to rehearse the RCCL path on one GPU)
         self.collective = self.world > 1 or (always_collective and inited)
 
-    def match_topk(self, d_queries: torch.Tensor, d_q_offsets: torch.Tensor, max_query_len: int,
-                   min_match: int, d_exclude_ids: Optional[torch.Tensor] = None):
-        """-> (merged int32 [Q,k,3] of (video_id, count, kth), total_hits int32 [Q]) — identical on
-        every rank.  total_hits > k means the list was truncated to the k best."""
+    def submit(self, d_queries: torch.Tensor, d_q_offsets: torch.Tensor, max_query_len: int,
+               min_match: int, d_exclude_ids: Optional[torch.Tensor] = None):
+        """Enqueue local match + per-shard top-k and START the all-gather; returns a ticket for
+        finish().  Submitting batch i+1 before finishing batch i overlaps the collective of one
+        batch with the match kernels of the next (RCCL runs on its own stream)."""
         hits, n = self.backend.match(d_queries, d_q_offsets, max_query_len, min_match, self.cap,
                                      d_exclude_ids)
         local = self.backend.topk_shard(hits, n, self.k)            # [Q, k+1, 3]
         Q = local.shape[0]
         if not self.collective:
-            gathered = local.view(1, Q, self.k + 1, 3)
-        else:
-            # dim-0 concatenation is the layout both RCCL and gloo accept for all_gather_into_tensor
-            flat = torch.empty((self.world * Q, self.k + 1, 3), dtype=torch.int32, device=local.device)
-            dist.all_gather_into_tensor(flat, local.contiguous(), group=self.group)
-            gathered = flat.view(self.world, Q, self.k + 1, 3)
+            return (local.view(1, Q, self.k + 1, 3), None, local)
+        # dim-0 concatenation is the layout both RCCL and gloo accept for all_gather_into_tensor
+        flat = torch.empty((self.world * Q, self.k + 1, 3), dtype=torch.int32, device=local.device)
+        work = dist.all_gather_into_tensor(flat, local.contiguous(), group=self.group, async_op=True)
+        return (flat.view(self.world, Q, self.k + 1, 3), work, local)
+
+    def finish(self, ticket):
+        """-> (merged int32 [Q,k,3] of (video_id, count, kth), total_hits int32 [Q]) — identical on
+        every rank.  total_hits > k means the list was truncated to the k best."""
+        gathered, work, _keepalive = ticket
+        if work is not None:
+            work.wait()                     # makes the current stream wait for the collective
         return self.backend.topk_merge(gathered, self.k)
+
+    def match_topk(self, d_queries: torch.Tensor, d_q_offsets: torch.Tensor, max_query_len: int,
+                   min_match: int, d_exclude_ids: Optional[torch.Tensor] = None):
+        return self.finish(self.submit(d_queries, d_q_offsets, max_query_len, min_match, d_exclude_ids))
 
 
 def verdicts_from_topk(merged: np.ndarray):
