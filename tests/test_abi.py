@@ -49,3 +49,15 @@ def test_product_never_imports_oracle():
                 txt = open(os.path.join(dirpath, f)).read()
                 assert "import oracle" not in txt and "from oracle" not in txt, f
                 assert "libtvz_oracle" not in txt, f
+
+
+def test_bench_refuses_to_run_without_a_gpu():
+    """No CPU fallback anywhere: on a GPU-less host bench.py exits with a clear message."""
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1"],
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert out.returncode != 0 and "needs a GPU" in (out.stderr + out.stdout)
