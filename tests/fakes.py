@@ -41,5 +41,11 @@ class OracleCorpus:
                      if cnt[c] >= min_match and ids[c] != exclude_id)
         return out if with_kth else [(a, b) for a, b, _ in out]
 
+    def align(self, timestamps, eps=0.1, max_offset=60.0):
+        with self.lock:
+            rows = list(self.rows)
+        import numpy as np
+        return np.array(oracle.align_py(rows, list(timestamps), eps, max_offset), dtype=np.int32).reshape(-1, 5)
+
     def close(self):
         pass

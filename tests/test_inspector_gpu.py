@@ -142,3 +142,26 @@ def test_ten_bit_upload_end_to_end(rig):
     assert r1["status"] == "done" and r1["scene_cuts"] == exp and r1["duplicates"] == []
     r2 = ins.analyze_file("videos", "1700000051-hdr_copy.y4m")
     assert r2["status"] == "done" and r2["duplicates"] == ["hdr.y4m"] and r2["scene_cuts"] == exp[:2]
+
+
+def test_opt_in_near_duplicates_flags_the_cut_shifted_copy(tmp_path):
+    """configs[0]: the cut-shifted copy is NOT a duplicate for the reference (exact match) - the
+    verdict stays empty - but the opt-in alignment field reports it with its shift."""
+    store = tdb.Store(f"sqlite:///{tmp_path}/t.db", device=0)
+    files = {}
+    ins = insp.Inspector(store, device=DEV, frame_source=lambda b, k, f, u: (feeder.Y4MReader(files[k]), None),
+                         batch=64, near_duplicates=True)
+    try:
+        cuts = [45, 100, 150, 210, 260]
+        for name, luma in (("a.y4m", _clip(1, cuts)), ("b.y4m", _clip(2, [c + 7 for c in cuts]))):
+            files[name] = str(tmp_path / name)
+            feeder.write_y4m(files[name], luma)
+        ra = ins.analyze_file("videos", "a.y4m")
+        assert ra["duplicates"] == [] and ra["near_duplicates"] == []
+        rb = ins.analyze_file("videos", "b.y4m")
+        assert rb["status"] == "done" and rb["duplicates"] == []            # reference verdict
+        assert len(rb["near_duplicates"]) == 1
+        nd = rb["near_duplicates"][0]
+        assert nd["filename"] == "a.y4m" and nd["jaccard"] == 1.0 and abs(nd["shift_seconds"] + 7 / 30) < 1e-9
+    finally:
+        store.close()

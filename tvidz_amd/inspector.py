@@ -78,7 +78,9 @@ def s3_frame_source(bucket: str, key: str, filename: str, unique_id: str):
 class Inspector:
     def __init__(self, store, device: str = "cuda:0", frame_source: Optional[Callable] = None,
                  threshold: float = scene.DEFAULT_THRESHOLD, min_match: int = 2,
-                 pts_policy: str = scene.PTS_POLICY_G6, batch: int = 256, max_workers: int = 16):
+                 pts_policy: str = scene.PTS_POLICY_G6, batch: int = 256, max_workers: int = 16,
+                 near_duplicates: bool = False, near_eps: float = 1.0 / 30, near_max_offset: float = 30.0,
+                 near_jaccard: float = 0.8):
         self.store = store
         self.device = torch.device(device)
         self.frame_source = frame_source or s3_frame_source
@@ -86,6 +88,10 @@ class Inspector:
         self.min_match = min_match          # app.py:235
         self.pts_policy = pts_policy
         self.batch = batch
+        # opt-in extra, never the verdict: shift/tolerance-aware score (tvz_align) reported in an
+        # additional `near_duplicates` field the reference does not have
+        self.near_duplicates = near_duplicates
+        self.near_eps, self.near_max_offset, self.near_jaccard = near_eps, near_max_offset, near_jaccard
         self.analysis_results: Dict[str, dict] = {}     # app.py:28
         self.analysis_lock = threading.Lock()           # app.py:29
         self.pool = ThreadPoolExecutor(max_workers=max_workers, thread_name_prefix="analyze")
@@ -114,6 +120,8 @@ class Inspector:
                       "total_cuts": len(scene_timestamps),
                       "duplicates": list(set(dups_to_report)) if dups_to_report else [],
                       "original_filename": filename, "clean_filename": original_filename}
+            if self.near_duplicates:
+                result["near_duplicates"] = self._near(video_id, scene_timestamps)
             self._set(analysis_key, result)                                # app.py:294-302
         except Exception as e:                                             # app.py:303-315
             with self.analysis_lock:
@@ -183,6 +191,23 @@ class Inspector:
                 self.store.add_timestamps(video_id, scene_timestamps)                 # :234
             self._progress(analysis_key, scene_timestamps, frames_done, total_frames, dups_to_report)
         return scene_timestamps, dups_to_report
+
+    def _near(self, video_id: int, scene_timestamps):
+        """Rows whose cut pattern aligns with this video's under a constant shift (tolerant Jaccard
+        >= near_jaccard).  Extra field; the exact `duplicates` verdict is untouched."""
+        out = []
+        if len(scene_timestamps) < 2:
+            return out
+        for vid, row_len, best_bin, votes, _zero in self.store.corpus.align(
+                scene_timestamps, eps=self.near_eps, max_offset=self.near_max_offset):
+            if vid == video_id or row_len == 0:
+                continue
+            jacc = votes / float(len(scene_timestamps) + row_len - votes)
+            if jacc >= self.near_jaccard:
+                v = self.store.get_video_by_id(int(vid))
+                out.append({"filename": v.filename if v else None, "video_id": int(vid),
+                            "shift_seconds": float(best_bin) * self.near_eps, "jaccard": round(jacc, 4)})
+        return sorted(out, key=lambda d: (-d["jaccard"], d["video_id"]))
 
     def _progress(self, analysis_key, scene_timestamps, frames_done, total_frames, dups_to_report):
         if total_frames > 0 and frames_done > 0:                           # app.py:259-260
