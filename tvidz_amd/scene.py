@@ -127,16 +127,21 @@ class SceneScorer:
         use_prev = carry and self.have_prev
         es = frames.element_size()
         fn = self.lib.tvz_scene_scores_u8 if self.bitdepth == 8 else self.lib.tvz_scene_scores_u16
-        rc = fn(
+        with torch.cuda.device(self.device):          # launch on the frames' GPU, whatever is current
+            rc = self._call(fn, frames, T, es, use_prev, stream)
+        _lib.check(rc)
+        return (self.sad[:T], self.mafd[:T], self.score[:T] if self.score is not None else None,
+                self.selected[:T])
+
+    def _call(self, fn, frames, T, es, use_prev, stream):
+        return fn(
             frames.data_ptr(), T, self.H, self.W, frames.stride(0) * es, frames.stride(1) * es,
             self.prev_frame.data_ptr() if use_prev else None,
             self.prev_mafd if use_prev else 0.0, self.bitdepth, self.threshold,
             self.sad.data_ptr(), self.mafd.data_ptr(),
             self.score.data_ptr() if self.score is not None else None,
-            self.selected.data_ptr(), self.workspace.data_ptr(), self.ws_bytes, _stream_ptr(stream))
-        _lib.check(rc)
-        return (self.sad[:T], self.mafd[:T], self.score[:T] if self.score is not None else None,
-                self.selected[:T])
+            self.selected.data_ptr(), self.workspace.data_ptr(), self.ws_bytes,
+            (stream if stream is not None else torch.cuda.current_stream(self.device)).cuda_stream)
 
     def remember_tail(self, frames: torch.Tensor) -> None:
         """Keep the batch's last frame + mafd as the predecessor of the next batch."""
@@ -153,10 +158,14 @@ class SceneScorer:
         self._check(frames)
         T = int(frames.shape[0])
         if T:
-            _lib.check(self.lib.tvz_luma_sad_u8(frames.data_ptr(), T, self.H, self.W, frames.stride(0),
-                                                frames.stride(1), self.sad.data_ptr(),
-                                                self.workspace.data_ptr(), self.ws_bytes,
-                                                _stream_ptr(stream)))
+            if self.bitdepth != 8:
+                raise RuntimeError("luma_sad() is the 8-bit entry point; use score_batch for 16-bit")
+            with torch.cuda.device(self.device):
+                s = stream if stream is not None else torch.cuda.current_stream(self.device)
+                _lib.check(self.lib.tvz_luma_sad_u8(frames.data_ptr(), T, self.H, self.W, frames.stride(0),
+                                                    frames.stride(1), self.sad.data_ptr(),
+                                                    self.workspace.data_ptr(), self.ws_bytes,
+                                                    s.cuda_stream))
         return self.sad[:T]
 
 
