@@ -109,6 +109,7 @@ int tvz_scene_scores_u16(const uint16_t *d_luma, int64_t T, int32_t H, int32_t W
 typedef struct tvz_corpus tvz_corpus;
 
 int tvz_corpus_create(tvz_corpus **out, int device);
+/* Must not run concurrently with any other call on the same handle. */
 int tvz_corpus_destroy(tvz_corpus *c);
 
 /* Replace the whole corpus (the `session.query(VideoTimestamps).all()` of

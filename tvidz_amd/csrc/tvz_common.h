@@ -5,6 +5,8 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <exception>
+#include <new>
 
 #include "tvz.h"
 
@@ -34,6 +36,18 @@ inline int fail(int code, const char *fmt, ...) {
     do {                                                                                  \
         if (!(cond)) return tvz::fail(TVZ_ERR_INVALID, __VA_ARGS__);                      \
     } while (0)
+
+// No C++ exception may cross the C ABI: allocation failures become TVZ_ERR_NOMEM.
+#define TVZ_GUARDED(call)                                                                 \
+    try {                                                                                 \
+        return (call);                                                                    \
+    } catch (const std::bad_alloc &) {                                                    \
+        return tvz::fail(TVZ_ERR_NOMEM, "host allocation failed");                        \
+    } catch (const std::exception &e) {                                                   \
+        return tvz::fail(TVZ_ERR_INVALID, "unexpected C++ exception: %s", e.what());      \
+    } catch (...) {                                                                       \
+        return tvz::fail(TVZ_ERR_INVALID, "unexpected C++ exception");                    \
+    }
 
 inline int64_t round_up(int64_t a, int64_t b) { return (a + b - 1) / b * b; }
 inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }

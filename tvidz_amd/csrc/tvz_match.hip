@@ -1067,7 +1067,7 @@ void staging_free(Staging *s) {
 
 }  // namespace
 
-TVZ_EXPORT int tvz_corpus_create(tvz_corpus **out, int device) {
+static int tvz_corpus_create_impl(tvz_corpus **out, int device) {
     TVZ_REQUIRE(out != nullptr, "out is NULL");
     int n = 0;
     TVZ_HIP(hipGetDeviceCount(&n));
@@ -1086,7 +1086,7 @@ TVZ_EXPORT int tvz_corpus_create(tvz_corpus **out, int device) {
     return TVZ_OK;
 }
 
-TVZ_EXPORT int tvz_corpus_destroy(tvz_corpus *c) {
+static int tvz_corpus_destroy_impl(tvz_corpus *c) {
     if (!c) return TVZ_OK;
     DeviceGuard dg(c->device);
     {
@@ -1109,7 +1109,7 @@ TVZ_EXPORT int tvz_corpus_destroy(tvz_corpus *c) {
     return TVZ_OK;
 }
 
-TVZ_EXPORT int tvz_corpus_upload(tvz_corpus *c, const int32_t *h_video_ids,
+static int tvz_corpus_upload_impl(tvz_corpus *c, const int32_t *h_video_ids,
                                  const int64_t *h_offsets, const double *h_keys, int64_t n_rows,
                                  int64_t n_keys) {
     TVZ_REQUIRE(c != nullptr, "corpus is NULL");
@@ -1143,7 +1143,7 @@ TVZ_EXPORT int tvz_corpus_upload(tvz_corpus *c, const int32_t *h_video_ids,
     return upload_all(c);
 }
 
-TVZ_EXPORT int tvz_corpus_upsert(tvz_corpus *c, int32_t video_id, const double *h_keys, int64_t n) {
+static int tvz_corpus_upsert_impl(tvz_corpus *c, int32_t video_id, const double *h_keys, int64_t n) {
     TVZ_REQUIRE(c != nullptr, "corpus is NULL");
     TVZ_REQUIRE(n >= 0 && n <= INT32_MAX && (n == 0 || h_keys), "bad key array");
     DeviceGuard dg(c->device);
@@ -1178,7 +1178,7 @@ TVZ_EXPORT int tvz_corpus_upsert(tvz_corpus *c, int32_t video_id, const double *
     return TVZ_OK;
 }
 
-TVZ_EXPORT int tvz_corpus_clear(tvz_corpus *c) {
+static int tvz_corpus_clear_impl(tvz_corpus *c) {
     TVZ_REQUIRE(c != nullptr, "corpus is NULL");
     DeviceGuard dg(c->device);
     std::unique_lock<std::shared_mutex> lk(c->mu);
@@ -1190,7 +1190,7 @@ TVZ_EXPORT int tvz_corpus_clear(tvz_corpus *c) {
     return TVZ_OK;
 }
 
-TVZ_EXPORT int tvz_corpus_stats(tvz_corpus *c, int64_t *n_rows, int64_t *n_keys,
+static int tvz_corpus_stats_impl(tvz_corpus *c, int64_t *n_rows, int64_t *n_keys,
                                 int64_t *arena_keys) {
     TVZ_REQUIRE(c != nullptr, "corpus is NULL");
     std::shared_lock<std::shared_mutex> lk(c->mu);
@@ -1200,7 +1200,7 @@ TVZ_EXPORT int tvz_corpus_stats(tvz_corpus *c, int64_t *n_rows, int64_t *n_keys,
     return TVZ_OK;
 }
 
-TVZ_EXPORT int tvz_match(tvz_corpus *c, const double *d_queries, const int64_t *d_q_offsets,
+static int tvz_match_impl(tvz_corpus *c, const double *d_queries, const int64_t *d_q_offsets,
                          int32_t Q, int32_t max_query_len, int32_t min_match,
                          const int32_t *d_exclude_ids, int32_t cap, int32_t *d_hits,
                          int32_t *d_hits_n, void *hip_stream) {
@@ -1219,7 +1219,7 @@ TVZ_EXPORT int tvz_match(tvz_corpus *c, const double *d_queries, const int64_t *
     return record(c, st);
 }
 
-TVZ_EXPORT int tvz_find_duplicates(tvz_corpus *c, const double *h_query, int64_t n,
+static int tvz_find_duplicates_impl(tvz_corpus *c, const double *h_query, int64_t n,
                                    int32_t min_match, int32_t exclude_id, int64_t cap,
                                    int32_t *h_out_ids, int32_t *h_out_counts, int32_t *h_out_kth,
                                    int64_t *n_out) {
@@ -1330,7 +1330,7 @@ TVZ_EXPORT int tvz_find_duplicates(tvz_corpus *c, const double *h_query, int64_t
     return TVZ_OK;
 }
 
-TVZ_EXPORT int tvz_topk(const int32_t *d_lists, const int32_t *d_lists_n, int32_t n_lists,
+static int tvz_topk_impl(const int32_t *d_lists, const int32_t *d_lists_n, int32_t n_lists,
                         int32_t Q, int32_t cap, int32_t k, int32_t *d_topk, void *hip_stream) {
     TVZ_REQUIRE(n_lists >= 1 && Q >= 0 && cap >= 0, "bad list shape");
     TVZ_REQUIRE(k >= 1 && k <= kSortCap / 2, "k=%d out of range [1, %d]", k, kSortCap / 2);
@@ -1343,7 +1343,7 @@ TVZ_EXPORT int tvz_topk(const int32_t *d_lists, const int32_t *d_lists_n, int32_
     return TVZ_OK;
 }
 
-TVZ_EXPORT int tvz_topk_shard(const int32_t *d_hits, const int32_t *d_hits_n, int32_t Q,
+static int tvz_topk_shard_impl(const int32_t *d_hits, const int32_t *d_hits_n, int32_t Q,
                               int32_t cap, int32_t k, int32_t *d_out, void *hip_stream) {
     TVZ_REQUIRE(Q >= 0 && cap >= 0, "bad list shape");
     TVZ_REQUIRE(k >= 1 && k <= kSortCap / 2, "k=%d out of range [1, %d]", k, kSortCap / 2);
@@ -1356,7 +1356,7 @@ TVZ_EXPORT int tvz_topk_shard(const int32_t *d_hits, const int32_t *d_hits_n, in
     return TVZ_OK;
 }
 
-TVZ_EXPORT int tvz_topk_merge(const int32_t *d_gathered, int32_t n_ranks, int32_t Q, int32_t k,
+static int tvz_topk_merge_impl(const int32_t *d_gathered, int32_t n_ranks, int32_t Q, int32_t k,
                               int32_t *d_topk, int32_t *d_totals, void *hip_stream) {
     TVZ_REQUIRE(n_ranks >= 1 && Q >= 0, "bad list shape");
     TVZ_REQUIRE(k >= 1 && k <= kSortCap / 2, "k=%d out of range [1, %d]", k, kSortCap / 2);
@@ -1369,7 +1369,7 @@ TVZ_EXPORT int tvz_topk_merge(const int32_t *d_gathered, int32_t n_ranks, int32_
     return TVZ_OK;
 }
 
-TVZ_EXPORT int tvz_align(tvz_corpus *c, const double *d_query, int32_t n, double eps,
+static int tvz_align_impl(tvz_corpus *c, const double *d_query, int32_t n, double eps,
                          double max_offset, int32_t *d_out, void *hip_stream) {
     TVZ_REQUIRE(c != nullptr, "corpus is NULL");
     TVZ_REQUIRE(n >= 0 && (n == 0 || d_query), "bad query");
@@ -1392,7 +1392,72 @@ TVZ_EXPORT int tvz_align(tvz_corpus *c, const double *d_query, int32_t n, double
 }
 
 // Not part of the stable ABI: 0 = LDS tile kernel only, 1 = dispatch rule, 2 = hash join whenever legal.
-TVZ_EXPORT int tvz_match_set_tuning(int use_join) {
+static int tvz_match_set_tuning_impl(int use_join) {
     g_use_join = use_join < 0 ? 0 : (use_join > 2 ? 2 : use_join);
     return TVZ_OK;
+}
+
+TVZ_EXPORT int tvz_corpus_create(tvz_corpus **out, int device) {
+    TVZ_GUARDED(tvz_corpus_create_impl(out, device));
+}
+
+TVZ_EXPORT int tvz_corpus_destroy(tvz_corpus *c) {
+    TVZ_GUARDED(tvz_corpus_destroy_impl(c));
+}
+
+TVZ_EXPORT int tvz_corpus_upload(tvz_corpus *c, const int32_t *h_video_ids,
+                                 const int64_t *h_offsets, const double *h_keys, int64_t n_rows,
+                                 int64_t n_keys) {
+    TVZ_GUARDED(tvz_corpus_upload_impl(c, h_video_ids, h_offsets, h_keys, n_rows, n_keys));
+}
+
+TVZ_EXPORT int tvz_corpus_upsert(tvz_corpus *c, int32_t video_id, const double *h_keys, int64_t n) {
+    TVZ_GUARDED(tvz_corpus_upsert_impl(c, video_id, h_keys, n));
+}
+
+TVZ_EXPORT int tvz_corpus_clear(tvz_corpus *c) {
+    TVZ_GUARDED(tvz_corpus_clear_impl(c));
+}
+
+TVZ_EXPORT int tvz_corpus_stats(tvz_corpus *c, int64_t *n_rows, int64_t *n_keys,
+                                int64_t *arena_keys) {
+    TVZ_GUARDED(tvz_corpus_stats_impl(c, n_rows, n_keys, arena_keys));
+}
+
+TVZ_EXPORT int tvz_match(tvz_corpus *c, const double *d_queries, const int64_t *d_q_offsets,
+                         int32_t Q, int32_t max_query_len, int32_t min_match,
+                         const int32_t *d_exclude_ids, int32_t cap, int32_t *d_hits,
+                         int32_t *d_hits_n, void *hip_stream) {
+    TVZ_GUARDED(tvz_match_impl(c, d_queries, d_q_offsets, Q, max_query_len, min_match, d_exclude_ids, cap, d_hits, d_hits_n, hip_stream));
+}
+
+TVZ_EXPORT int tvz_find_duplicates(tvz_corpus *c, const double *h_query, int64_t n,
+                                   int32_t min_match, int32_t exclude_id, int64_t cap,
+                                   int32_t *h_out_ids, int32_t *h_out_counts, int32_t *h_out_kth,
+                                   int64_t *n_out) {
+    TVZ_GUARDED(tvz_find_duplicates_impl(c, h_query, n, min_match, exclude_id, cap, h_out_ids, h_out_counts, h_out_kth, n_out));
+}
+
+TVZ_EXPORT int tvz_topk(const int32_t *d_lists, const int32_t *d_lists_n, int32_t n_lists,
+                        int32_t Q, int32_t cap, int32_t k, int32_t *d_topk, void *hip_stream) {
+    TVZ_GUARDED(tvz_topk_impl(d_lists, d_lists_n, n_lists, Q, cap, k, d_topk, hip_stream));
+}
+
+TVZ_EXPORT int tvz_topk_shard(const int32_t *d_hits, const int32_t *d_hits_n, int32_t Q,
+                              int32_t cap, int32_t k, int32_t *d_out, void *hip_stream) {
+    TVZ_GUARDED(tvz_topk_shard_impl(d_hits, d_hits_n, Q, cap, k, d_out, hip_stream));
+}
+
+TVZ_EXPORT int tvz_topk_merge(const int32_t *d_gathered, int32_t n_ranks, int32_t Q, int32_t k,
+                              int32_t *d_topk, int32_t *d_totals, void *hip_stream) {
+    TVZ_GUARDED(tvz_topk_merge_impl(d_gathered, n_ranks, Q, k, d_topk, d_totals, hip_stream));
+}
+
+TVZ_EXPORT int tvz_align(tvz_corpus *c, const double *d_query, int32_t n, double eps,
+                         double max_offset, int32_t *d_out, void *hip_stream) {
+    TVZ_GUARDED(tvz_align_impl(c, d_query, n, eps, max_offset, d_out, hip_stream));
+}
+
+TVZ_EXPORT int tvz_match_set_tuning(int use_join) {
+    TVZ_GUARDED(tvz_match_set_tuning_impl(use_join));
 }
