@@ -61,3 +61,27 @@ def test_bench_refuses_to_run_without_a_gpu():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1"],
                          stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
     assert out.returncode != 0 and "needs a GPU" in (out.stderr + out.stdout)
+
+
+def test_entry_points_fail_gracefully_without_a_gpu():
+    """On a GPU-less host the library must return an error code + message, never crash and never
+    fall back to a CPU path (argument validation and the device probe run before any launch)."""
+    import ctypes as C
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    from tvidz_amd import _lib
+    lib = _lib.load()
+    h = C.c_void_p()
+    rc = lib.tvz_corpus_create(C.byref(h), 0)
+    assert rc != 0 and h.value is None and len(lib.tvz_last_error()) > 0
+    with pytest.raises(RuntimeError, match="libtvz error"):
+        _lib.check(rc)
+    # pure argument validation (no HIP call is reached)
+    assert lib.tvz_luma_sad_u8(None, 4, 32, 32, 1024, 32, None, None, 0, None) != 0
+    assert lib.tvz_scene_select(None, 4, 32, 32, 8, 0.3, 0.0, 0, None, None, None, None) != 0
+    assert lib.tvz_topk(None, None, 1, 4, 8, 0, None, None) != 0          # k out of range
+    assert lib.tvz_match(None, None, None, 1, 1, 1, None, 1, None, None, None) != 0
+    from tvidz_amd import scene
+    with pytest.raises(RuntimeError):
+        scene.SceneScorer(32, 32, 4, "cpu")
