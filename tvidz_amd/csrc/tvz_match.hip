@@ -361,13 +361,13 @@ __global__ __launch_bounds__(kTileBlock) void ts_match_tile_kernel(
 // to one XCD (blockIdx % 8) so its table is served from that XCD's L2.  What it buys is bounded by
 // the L2: a random 16-byte probe moves a whole cache line, and the measured probe rate (~180 G/s)
 // is the L2's random-line rate - LDS has no line granularity, which is why the LDS tile stays
-// competitive with 8x the probes (1.77 vs 2.27 ms at C=100k, Q=1024).  Per (row group, query) state lives in LDS: a u16 hit
+// competitive with 8x the probes (1.37 vs 2.29 ms at C=100k, Q=1024).  Per (row group, query) state lives in LDS: a u16 hit
 // counter and the two smallest matching positions (u16 + u16 in one CAS word); after a row each
 // lane scans 8 of the tile's 128 queries and emits the hits.
 constexpr int kJoinQ = 128;
 constexpr int kJoinBlock = 1024;
 constexpr int kJoinGroups = kJoinBlock / kGroup;
-constexpr size_t kJoinLds = (size_t)kJoinGroups * kJoinQ * 6;     // 48 KiB
+constexpr size_t kJoinLds = (size_t)kJoinGroups * kJoinQ * 10;    // 80 KiB: m1, m2 (u32) + u16 counters
 constexpr int64_t kJEmpty = -1;                                    // 0xff..ff: a NaN pattern
 
 __device__ __forceinline__ uint32_t hash32(int64_t k) {
@@ -424,8 +424,9 @@ __global__ __launch_bounds__(kJoinBlock) void ts_match_join_kernel(
     int32_t min_match, const int32_t *__restrict__ exclude_ids, int32_t cap,
     int32_t *__restrict__ hits, int32_t *__restrict__ hits_n, int32_t rows_per_block) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    uint32_t *m12_all = reinterpret_cast<uint32_t *>(smem);                    // [groups][128]
-    uint32_t *cnt_all = m12_all + kJoinGroups * kJoinQ;                        // [groups][64] 2 x u16
+    uint32_t *m1_all = reinterpret_cast<uint32_t *>(smem);                     // [groups][128] smallest pos
+    uint32_t *m2_all = m1_all + kJoinGroups * kJoinQ;                          // [groups][128] 2nd smallest
+    uint32_t *cnt_all = m2_all + kJoinGroups * kJoinQ;                         // [groups][64] 2 x u16
     // block -> (tile, chunk): blocks of one tile share blockIdx % 8, i.e. (observed) one XCD and its L2
     const int b = blockIdx.x;
     int tile, chunk;
@@ -443,9 +444,10 @@ __global__ __launch_bounds__(kJoinBlock) void ts_match_join_kernel(
     if (tile >= n_tiles || chunk >= n_chunks) return;
     const int gl = threadIdx.x & (kGroup - 1);
     const int g = threadIdx.x / kGroup;
-    uint32_t *m12 = m12_all + g * kJoinQ;
+    uint32_t *m1 = m1_all + g * kJoinQ;
+    uint32_t *m2 = m2_all + g * kJoinQ;
     uint32_t *cntw = cnt_all + g * (kJoinQ / 2);
-    for (int i = gl; i < kJoinQ; i += kGroup) m12[i] = 0xffffffffu;
+    for (int i = gl; i < kJoinQ; i += kGroup) { m1[i] = 0xffffffffu; m2[i] = 0xffffffffu; }
     for (int i = gl; i < kJoinQ / 2; i += kGroup) cntw[i] = 0;
     const int q0 = tile * kJoinQ;
     const uint32_t smask = (1u << s_log2) - 1u;
@@ -458,16 +460,10 @@ __global__ __launch_bounds__(kJoinBlock) void ts_match_join_kernel(
     auto account = [&](uint32_t pk) {                    // one matching (query, position) entry
         const uint32_t ql = pk >> 12, pos = pk & 0xfffu;
         atomicAdd(&cntw[ql >> 1], 1u << (16 * (ql & 1)));
-        uint32_t seen = m12[ql];
-        while (true) {
-            const uint32_t m1 = seen & 0xffffu, m2 = seen >> 16;
-            if (pos >= m2) break;
-            const uint32_t nw = pos < m1 ? ((m1 << 16) | pos) : ((pos << 16) | m1);
-            const uint32_t old = atomicCAS(&m12[ql], seen, nw);
-            if (old == seen) break;
-            seen = old;
-        }
+        const uint32_t old = atomicMin(&m1[ql], pos);    // two plain LDS atomics, no CAS loop
+        atomicMin(&m2[ql], old > pos ? old : pos);       // larger of two distinct hits >= 2nd smallest
     };
+
     constexpr int kK = 4;                                // keys per lane and step: 8 table loads in flight
     for (int64_t r = r0 + g; r < r1; r += kJoinGroups) {
         const Row row = rows[r];
@@ -510,31 +506,40 @@ __global__ __launch_bounds__(kJoinBlock) void ts_match_join_kernel(
                 }
             }
         }
-        // lane gl owns queries gl*8 .. gl*8+7 of the tile (4 counter words)
+        // lane gl owns queries gl*8 .. gl*8+7 of the tile (4 counter words of 2 x u16)
         const uint4 cw = *reinterpret_cast<const uint4 *>(cntw + gl * 4);
+        if ((cw.x | cw.y | cw.z | cw.w) == 0 && min_match > 0) continue;      // nothing matched
         const uint32_t w[4] = {cw.x, cw.y, cw.z, cw.w};
-        if (min_match > 0 && (cw.x | cw.y | cw.z | cw.w) == 0) continue;
+        uint32_t todo = 0;                               // bit j: query gl*8+j reaches min_match
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const uint32_t c = (w[j >> 1] >> (16 * (j & 1))) & 0xffffu;
+            const int c = (int)((w[j >> 1] >> (16 * (j & 1))) & 0xffffu);
+            todo |= (uint32_t)(c >= min_match && q0 + gl * 8 + j < Q) << j;
+        }
+        while (todo) {                                   // usually 0 or 1 iterations
+            const int j = __ffs(todo) - 1;
+            todo &= todo - 1;
             const int ql = gl * 8 + j;
             const int q = q0 + ql;
-            if (q < Q && (int)c >= min_match) {
-                const uint32_t mm = m12[ql];
-                if (!(exclude_ids && exclude_ids[q] == row.vid)) {
-                    const int32_t kth = min_match <= 0 ? -1 : (int32_t)(min_match == 1 ? (mm & 0xffffu) : (mm >> 16));
-                    const int slot = atomicAdd(&hits_n[q], 1);
-                    if (slot < cap) {
-                        int32_t *hp = hits + ((int64_t)q * cap + slot) * 3;
-                        hp[0] = row.vid;
-                        hp[1] = (int32_t)c;
-                        hp[2] = kth;
-                    }
+            const uint32_t c = (w[j >> 1] >> (16 * (j & 1))) & 0xffffu;
+            if (!(exclude_ids && exclude_ids[q] == row.vid)) {
+                const int32_t kth = min_match <= 0 ? -1 : (int32_t)(min_match == 1 ? m1[ql] : m2[ql]);
+                const int slot = atomicAdd(&hits_n[q], 1);
+                if (slot < cap) {
+                    int32_t *hp = hits + ((int64_t)q * cap + slot) * 3;
+                    hp[0] = row.vid;
+                    hp[1] = (int32_t)c;
+                    hp[2] = kth;
                 }
             }
-            if (c) m12[ql] = 0xffffffffu;
         }
+        // unconditional reset of this lane's 8 queries: 5 wide LDS stores, no per-query branches
+        const uint4 ones = make_uint4(0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu);
         *reinterpret_cast<uint4 *>(cntw + gl * 4) = make_uint4(0, 0, 0, 0);
+        *reinterpret_cast<uint4 *>(m1 + gl * 8) = ones;
+        *reinterpret_cast<uint4 *>(m1 + gl * 8 + 4) = ones;
+        *reinterpret_cast<uint4 *>(m2 + gl * 8) = ones;
+        *reinterpret_cast<uint4 *>(m2 + gl * 8 + 4) = ones;
     }
 }
 
@@ -914,12 +919,12 @@ int compact(tvz_corpus *c) {
     return upload_all(c);
 }
 
-// Dispatch (measured A/B, profiles/r1_match_join_ab.txt): the join wins only when its fixed cost
-// (table build, under-filled rounds of blocks) is amortised - C=100k x Q=1024: 1.71 ms vs 2.31 ms
-// for the LDS tile kernel, C=50k x Q=1024: 0.97 vs 1.19, C=100k x Q=256: 0.75 vs 0.93; below that
-// the tile kernel is faster (C=5k x Q=1024: 0.16 vs 0.32 ms).
-constexpr int kJoinMinQ = 256;
-constexpr int64_t kJoinMinRows = 50000;
+// Dispatch (measured A/B grid, profiles/r1_match_join_ab.txt): the join wins once its fixed cost
+// (table memset + build, ~30 us) is amortised, i.e. from about 5 M (query, row) pairs per batch:
+// C=100k x Q=1024: 1.37 ms vs 2.29 ms for the LDS tile kernel, C=5k x Q=1024: 0.149 vs 0.169,
+// C=20k x Q=256: 0.186 vs 0.194; below that (C=5k x Q=256: 0.112 vs 0.075) the tile kernel wins.
+constexpr int kJoinMinQ = 64;
+constexpr int64_t kJoinMinPairs = 5000000;
 int g_use_join = 1;             // 0 = never, 1 = by the rule above, 2 = whenever legal (A/B knob)
 
 int join_ws_get(tvz_corpus *c, size_t bytes, JoinWs **out) {
@@ -970,7 +975,7 @@ int launch_join(tvz_corpus *c, const double *d_queries, const int64_t *d_q_offse
     // two 1024-thread blocks per CU: about two rounds of 512 blocks, >= 8 rows per 16-lane group
     const int64_t g = (8 % n_tiles == 0) ? 8 / n_tiles : 1;
     int64_t chunks = std::max<int64_t>(1, 1024 / n_tiles);
-    chunks = std::min(chunks, std::max<int64_t>(1, n_rows / (8 * kJoinGroups)));
+    chunks = std::min(chunks, std::max<int64_t>(1, n_rows / (2 * kJoinGroups)));
     chunks = tvz::round_up(chunks, g);
     const int64_t rpb = tvz::round_up(tvz::ceil_div(n_rows, chunks), kJoinGroups);
     int64_t blocks = (int64_t)n_tiles * chunks;
@@ -994,7 +999,7 @@ int launch_match(tvz_corpus *c, const double *d_queries, const int64_t *d_q_offs
     const int64_t n_rows = (int64_t)c->h_rows.size();
     if (n_rows == 0 || Q == 0) return TVZ_OK;
     const bool join_legal = min_match <= 2 && max_query_len > 0;
-    if (join_legal && (g_use_join == 2 || (g_use_join == 1 && Q >= kJoinMinQ && n_rows >= kJoinMinRows)))
+    if (join_legal && (g_use_join == 2 || (g_use_join == 1 && Q >= kJoinMinQ && (int64_t)Q * n_rows >= kJoinMinPairs)))
         return launch_join(c, d_queries, d_q_offsets, Q, max_query_len, min_match, d_exclude_ids, cap,
                            d_hits, d_hits_n, st);
     // queries per tile: as many as keep the shared table at load <= 0.5 (at most 16)
