@@ -361,13 +361,15 @@ __global__ __launch_bounds__(kTileBlock) void ts_match_tile_kernel(
 // to one XCD (blockIdx % 8) so its table is served from that XCD's L2.  What it buys is bounded by
 // the L2: a random 16-byte probe moves a whole cache line, and the measured probe rate (~180 G/s)
 // is the L2's random-line rate - LDS has no line granularity, which is why the LDS tile stays
-// competitive with 8x the probes (1.37 vs 2.29 ms at C=100k, Q=1024).  Per (row group, query) state lives in LDS: a u16 hit
+// competitive with 8x the probes (1.18 vs 2.30 ms at C=100k, Q=1024).  An LDS presence bitmap of
+// the tile's keys (64 KiB) keeps ~70 % of the corpus keys from touching the L2 at all.  Per (row group, query) state lives in LDS: a u16 hit
 // counter and the two smallest matching positions (u16 + u16 in one CAS word); after a row each
 // lane scans 8 of the tile's 128 queries and emits the hits.
 constexpr int kJoinQ = 128;
 constexpr int kJoinBlock = 1024;
 constexpr int kJoinGroups = kJoinBlock / kGroup;
-constexpr size_t kJoinLds = (size_t)kJoinGroups * kJoinQ * 10;    // 80 KiB: m1, m2 (u32) + u16 counters
+constexpr int kJoinBloomBits = 1 << 19;                           // 64 KiB presence bitmap per tile
+constexpr size_t kJoinLds = (size_t)kJoinGroups * kJoinQ * 10 + kJoinBloomBits / 8;   // 80 + 64 KiB
 constexpr int64_t kJEmpty = -1;                                    // 0xff..ff: a NaN pattern
 
 __device__ __forceinline__ uint32_t hash32(int64_t k) {
@@ -391,7 +393,7 @@ __device__ __forceinline__ uint32_t hash32(int64_t k) {
 __global__ __launch_bounds__(kBlock) void ts_join_build_kernel(
     const double *__restrict__ queries, const int64_t *__restrict__ q_offsets, int32_t Q,
     int32_t max_len, int32_t s_log2, unsigned long long *__restrict__ tkeys,
-    uint32_t *__restrict__ tpack, int32_t *__restrict__ hits_n) {
+    uint32_t *__restrict__ tpack, uint32_t *__restrict__ tbloom, int32_t *__restrict__ hits_n) {
     const int q = blockIdx.y;
     const int64_t o = q_offsets[q];
     const int i = blockIdx.x * kBlock + threadIdx.x;
@@ -407,7 +409,10 @@ __global__ __launch_bounds__(kBlock) void ts_join_build_kernel(
     if (!canon_key(queries[o + i], k)) return;                     // NaN never matches
     const uint32_t smask = (1u << s_log2) - 1u;
     const size_t tb = (size_t)(q / kJoinQ) << s_log2;
-    uint32_t h = (hash32(k) >> (32 - s_log2)) & ~1u;               // home pair
+    const uint32_t hv = hash32(k);
+    const uint32_t bit = hv & (uint32_t)(kJoinBloomBits - 1);      // presence bit (low hash bits)
+    atomicOr(&tbloom[(size_t)(q / kJoinQ) * (kJoinBloomBits / 32) + (bit >> 5)], 1u << (bit & 31));
+    uint32_t h = (hv >> (32 - s_log2)) & ~1u;                      // home pair (high hash bits)
     while (true) {
         const unsigned long long old = atomicCAS(&tkeys[tb + h], (unsigned long long)kJEmpty,
                                                  (unsigned long long)k);
@@ -419,14 +424,15 @@ __global__ __launch_bounds__(kBlock) void ts_join_build_kernel(
 
 __global__ __launch_bounds__(kJoinBlock) void ts_match_join_kernel(
     const Row *__restrict__ rows, int64_t n_rows, const int64_t *__restrict__ keys,
-    const int64_t *__restrict__ tkeys, const uint32_t *__restrict__ tpack, int32_t s_log2,
-    int32_t Q, int32_t n_tiles, int32_t n_chunks,
+    const int64_t *__restrict__ tkeys, const uint32_t *__restrict__ tpack,
+    const uint32_t *__restrict__ tbloom, int32_t s_log2, int32_t Q, int32_t n_tiles, int32_t n_chunks,
     int32_t min_match, const int32_t *__restrict__ exclude_ids, int32_t cap,
     int32_t *__restrict__ hits, int32_t *__restrict__ hits_n, int32_t rows_per_block) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t *m1_all = reinterpret_cast<uint32_t *>(smem);                     // [groups][128] smallest pos
     uint32_t *m2_all = m1_all + kJoinGroups * kJoinQ;                          // [groups][128] 2nd smallest
     uint32_t *cnt_all = m2_all + kJoinGroups * kJoinQ;                         // [groups][64] 2 x u16
+    uint32_t *bloom = cnt_all + kJoinGroups * (kJoinQ / 2);                    // [2^19 bits]
     // block -> (tile, chunk): blocks of one tile share blockIdx % 8, i.e. (observed) one XCD and its L2
     const int b = blockIdx.x;
     int tile, chunk;
@@ -448,6 +454,12 @@ __global__ __launch_bounds__(kJoinBlock) void ts_match_join_kernel(
     uint32_t *m2 = m2_all + g * kJoinQ;
     uint32_t *cntw = cnt_all + g * (kJoinQ / 2);
     for (int i = gl; i < kJoinQ; i += kGroup) { m1[i] = 0xffffffffu; m2[i] = 0xffffffffu; }
+    {   // the tile's presence bitmap: 64 KiB copied from device memory into LDS once per block
+        const uint4 *src = reinterpret_cast<const uint4 *>(tbloom + (size_t)tile * (kJoinBloomBits / 32));
+        uint4 *dst = reinterpret_cast<uint4 *>(bloom);
+        for (int i = threadIdx.x; i < kJoinBloomBits / 128; i += kJoinBlock) dst[i] = src[i];
+    }
+    __syncthreads();
     for (int i = gl; i < kJoinQ / 2; i += kGroup) cntw[i] = 0;
     const int q0 = tile * kJoinQ;
     const uint32_t smask = (1u << s_log2) - 1u;
@@ -485,8 +497,14 @@ __global__ __launch_bounds__(kJoinBlock) void ts_match_join_kernel(
             longlong2 sk[kK];
 #pragma unroll
             for (int j = 0; j < kK; ++j) {               // independent L2 reads, all in flight
-                h[j] = (hash32(kk[j]) >> (32 - s_log2)) & ~1u;
-                sk[j] = *reinterpret_cast<const longlong2 *>(tk + h[j]);
+                // LDS presence filter first: a random probe of the table costs a whole L2 line,
+                // and ~70 % of the corpus keys are in no query of the tile
+                const uint32_t hv = hash32(kk[j]);
+                const uint32_t bit = hv & (uint32_t)(kJoinBloomBits - 1);
+                h[j] = (hv >> (32 - s_log2)) & ~1u;
+                sk[j] = make_longlong2(kJEmpty, kJEmpty);
+                if (valid[j] && ((bloom[bit >> 5] >> (bit & 31)) & 1u))
+                    sk[j] = *reinterpret_cast<const longlong2 *>(tk + h[j]);
             }
 #pragma unroll
             for (int j = 0; j < kK; ++j) {
@@ -921,8 +939,8 @@ int compact(tvz_corpus *c) {
 
 // Dispatch (measured A/B grid, profiles/r1_match_join_ab.txt): the join wins once its fixed cost
 // (table memset + build, ~30 us) is amortised, i.e. from about 5 M (query, row) pairs per batch:
-// C=100k x Q=1024: 1.37 ms vs 2.29 ms for the LDS tile kernel, C=5k x Q=1024: 0.149 vs 0.169,
-// C=20k x Q=256: 0.186 vs 0.194; below that (C=5k x Q=256: 0.112 vs 0.075) the tile kernel wins.
+// C=100k x Q=1024: 1.18 ms vs 2.30 ms for the LDS tile kernel, C=5k x Q=1024: 0.138 vs 0.165,
+// C=20k x Q=256: 0.177 vs 0.198; below that (C=5k x Q=256: 0.109 vs 0.076) the tile kernel wins.
 constexpr int kJoinMinQ = 64;
 constexpr int64_t kJoinMinPairs = 5000000;
 int g_use_join = 1;             // 0 = never, 1 = by the rule above, 2 = whenever legal (A/B knob)
@@ -963,14 +981,17 @@ int launch_join(tvz_corpus *c, const double *d_queries, const int64_t *d_q_offse
     while (((int64_t)1 << s_log2) < (int64_t)2 * kJoinQ * max_query_len) ++s_log2;
     const size_t S = (size_t)1 << s_log2;
     const size_t b_keys = (size_t)n_tiles * S * 8, b_pack = (size_t)n_tiles * S * 4;
+    const size_t b_bloom = (size_t)n_tiles * (kJoinBloomBits / 8);
     JoinWs *ws = nullptr;
-    if (int rc = join_ws_get(c, b_keys + b_pack, &ws)) return rc;
+    if (int rc = join_ws_get(c, b_keys + b_pack + b_bloom, &ws)) return rc;
     unsigned long long *tkeys = reinterpret_cast<unsigned long long *>(ws->base);
     uint32_t *tpack = reinterpret_cast<uint32_t *>(ws->base + b_keys);
+    uint32_t *tbloom = reinterpret_cast<uint32_t *>(ws->base + b_keys + b_pack);
     TVZ_HIP(hipMemsetAsync(ws->base, 0xff, b_keys, st));    // every key = kJEmpty
+    TVZ_HIP(hipMemsetAsync(tbloom, 0, b_bloom, st));
     hipLaunchKernelGGL(ts_join_build_kernel, dim3((unsigned)tvz::ceil_div(max_query_len, kBlock), (unsigned)Q),
                        dim3(kBlock), 0, st, d_queries, d_q_offsets, Q, max_query_len, s_log2, tkeys, tpack,
-                       d_hits_n);
+                       tbloom, d_hits_n);
     TVZ_HIP(hipGetLastError());
     // two 1024-thread blocks per CU: about two rounds of 512 blocks, >= 8 rows per 16-lane group
     const int64_t g = (8 % n_tiles == 0) ? 8 / n_tiles : 1;
@@ -981,9 +1002,9 @@ int launch_join(tvz_corpus *c, const double *d_queries, const int64_t *d_q_offse
     int64_t blocks = (int64_t)n_tiles * chunks;
     if (8 % n_tiles == 0) blocks = tvz::round_up(blocks, 8);
     hipLaunchKernelGGL(ts_match_join_kernel, dim3((unsigned)blocks), dim3(kJoinBlock), kJoinLds, st,
-                       c->rows.p, n_rows, c->keys.p, reinterpret_cast<const int64_t *>(tkeys), tpack, s_log2,
-                       Q, n_tiles, (int32_t)chunks, min_match, d_exclude_ids, cap, d_hits, d_hits_n,
-                       (int32_t)rpb);
+                       c->rows.p, n_rows, c->keys.p, reinterpret_cast<const int64_t *>(tkeys), tpack, tbloom,
+                       s_log2, Q, n_tiles, (int32_t)chunks, min_match, d_exclude_ids, cap, d_hits,
+                       d_hits_n, (int32_t)rpb);
     TVZ_HIP(hipGetLastError());
     TVZ_HIP(hipEventRecord(ws->done, st));                  // the tables are free again after this
     return TVZ_OK;
@@ -1086,6 +1107,8 @@ static int tvz_corpus_create_impl(tvz_corpus **out, int device) {
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)kTileLds));
     TVZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(ts_match_tile_kernel<true>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)kTileLds));
+    TVZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(ts_match_join_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)kJoinLds));
     if (int rc = upload_all(c)) { delete c; return rc; }
     *out = c;
     return TVZ_OK;
