@@ -1028,10 +1028,10 @@ int launch_match(tvz_corpus *c, const double *d_queries, const int64_t *d_q_offs
     nq = std::max(1, std::min(nq, kTileQ));
     const int64_t tiles = tvz::ceil_div(Q, nq);
     // one 1024-thread block per CU (LDS): aim at just under two full rounds of 256 blocks (a
-    // third, mostly empty round costs a whole block time), but >= 8 rows per 16-lane group so
+    // third, mostly empty round costs a whole block time), but >= 2 rows per 16-lane group so
     // that building the tile's table (per block) stays a small part of the block's life
     int64_t chunks = std::max<int64_t>(1, 512 / tiles);
-    chunks = std::min(chunks, std::max<int64_t>(1, n_rows / (8 * kTileGroups)));
+    chunks = std::min(chunks, std::max<int64_t>(1, n_rows / (2 * kTileGroups)));
     const int64_t rpb = tvz::round_up(tvz::ceil_div(n_rows, chunks), kTileGroups);
     chunks = tvz::ceil_div(n_rows, rpb);
     if (tiles > 65535)
