@@ -100,8 +100,8 @@ class DeviceCorpus:
             cap = int(n.value)  # rows were added concurrently: retry with room for all
         m = n.value
         if with_kth:
-            return [(int(ids[i]), int(cnt[i]), int(kth[i])) for i in range(m)]
-        return [(int(ids[i]), int(cnt[i])) for i in range(m)]
+            return list(zip(ids[:m].tolist(), cnt[:m].tolist(), kth[:m].tolist()))
+        return list(zip(ids[:m].tolist(), cnt[:m].tolist()))
 
     # ---- opt-in alignment score (never the verdict; see include/tvz.h tvz_align) ----
     def align(self, timestamps: Sequence[float], eps: float = 0.1, max_offset: float = 60.0):
