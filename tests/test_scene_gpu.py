@@ -258,3 +258,31 @@ def test_fuzz_shapes_strides_chunking():
             scores.append(score.cpu().numpy().copy())
         assert (np.concatenate(sads) == o_sad).all(), (trial, H, W, T, step, bd)
         assert (np.concatenate(scores) == o_score).all() and (np.concatenate(sels) == o_sel).all(), trial
+
+
+def test_scene_path_is_graph_capturable():
+    """The scene entry points enqueue launches only (no allocation, no synchronisation), so a
+    caller can capture a micro-batch step into a HIP graph and replay it on new frame contents."""
+    T, H, W = 64, 270, 480
+    sc = scene.SceneScorer(H, W, T, DEV)
+    static = torch.zeros((T, H, W), dtype=torch.uint8, device=DEV)
+    g = torch.Generator(device=DEV); g.manual_seed(1)
+    a = torch.randint(0, 256, (T, H, W), dtype=torch.uint8, device=DEV, generator=g)
+    b = torch.randint(0, 256, (T, H, W), dtype=torch.uint8, device=DEV, generator=g)
+    b[T // 2:] //= 4
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        static.copy_(a)
+        sc.score_batch(static, carry=False)           # warm-up outside the capture
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        sc.score_batch(static, carry=False)
+    for frames in (a, b, a):
+        static.copy_(frames)
+        graph.replay()
+        torch.cuda.synchronize()
+        o_sad, o_sel, o_score, _ = _oracle_all(frames.cpu().numpy())
+        assert (sc.sad[:T].cpu().numpy().view(np.uint64) == o_sad).all()
+        assert (sc.selected[:T].cpu().numpy() == o_sel).all() and (sc.score[:T].cpu().numpy() == o_score).all()
