@@ -24,7 +24,10 @@
 namespace {
 
 constexpr int kWave = 64;
-constexpr int kBlock = 256;           // 4 waves
+#ifndef TVZ_SCENE_BLOCK
+#define TVZ_SCENE_BLOCK 256
+#endif
+constexpr int kBlock = TVZ_SCENE_BLOCK;  // waves per block x 64
 constexpr int kWavesPerBlock = kBlock / kWave;
 
 struct Tuning {
