@@ -176,7 +176,9 @@ def bench_match(args, rank, world, dev):
     dc.upload_csr(s_ids, s_offs, s_keys)
     d_q, d_off, max_len = tc.pack_queries(queries, dev)
     K_TOP = 16          # per-shard top-k travelling in the all-gather: [Q,17,3] int32 per rank
-    sm = sharded.ShardedMatcher(sharded.HipBackend(dc), k=K_TOP, cap=1024,
+    CAP = 16384         # per-shard hit-list capacity per query (synthetic corpora: ~2,100 hits per
+    #                     query at min_match=2 over 100k videos; overflows are counted below)
+    sm = sharded.ShardedMatcher(sharded.HipBackend(dc), k=K_TOP, cap=CAP,
                                 always_collective=dist.is_initialized())
     for _ in range(3):
         merged, totals = sm.match_topk(d_q, d_off, max_len, 2)
@@ -197,6 +199,10 @@ def bench_match(args, rank, world, dev):
     bytes_per_pair = 8.0 * mean_len + 8.0
     lat = [0.0]
     n_dups = int((totals > 0).sum().item())
+    hits_local, n_local = dc.match(d_q, d_off, max_len, 2, CAP)
+    n_over = int((n_local > CAP).sum().item())
+    mean_hits = float(totals.float().mean().item())
+    del hits_local
     dc.close()
     # configs[2]: 5k-video corpus on one GPU, batch-size sweep (SURVEY 8d asks for Q = 1, 64, 1024)
     by_q, cpu = {}, None
@@ -232,7 +238,8 @@ def bench_match(args, rank, world, dev):
             "ms_per_batch": wall * 1e3 / args.match_steps,
             "collective": (f"one all_gather of [Q,{K_TOP + 1},3] int32 per batch (top-{K_TOP} + hit totals), "
                            "overlapped with the next batch's match") if sm.collective else "none",
-            "queries_with_hits": n_dups,
+            "queries_with_hits": n_dups, "mean_hits_per_query": round(mean_hits, 1),
+            "hit_list_capacity": CAP, "queries_overflowing_capacity_on_rank0": n_over,
             "scaling": "strong (the same corpus is sharded over the ranks)",
             "find_duplicates_latency_ms_q1_c5000": round(float(np.median(lat)) * 1e3, 3),
             "config2_c5000_kernel_by_batch_size": by_q, "cpu_baseline": cpu,
