@@ -19,6 +19,7 @@ dc = tc.DeviceCorpus(0)
 special = np.array([0.0, -0.0, np.nan, np.inf, -np.inf, 5e-324, 1e300, 1.5, 0.1 + 0.2, 0.3])
 stats = {"match_cases": 0, "pairs": 0, "scene_cases": 0, "frames": 0}
 t_end = time.time() + SECONDS
+t_note = time.time() + 30
 
 
 def rand_keys(n, grid):
@@ -102,4 +103,7 @@ while time.time() < t_end:
         sys.exit(1)
     stats["scene_cases"] += 1
     stats["frames"] += T
+    if time.time() > t_note:                       # keep long runs visibly alive
+        print(json.dumps({"progress": stats}), flush=True)
+        t_note = time.time() + 30
 print(json.dumps({"seconds": SECONDS, "seed": SEED, **stats, "result": "no mismatch"}))
