@@ -177,7 +177,9 @@ int tvz_topk(const int32_t *d_lists, const int32_t *d_lists_n, int32_t n_lists, 
  *   d_out : int32[Q][k+1][3] = its k best hits + a row (-1, n_local_hits, TVZ_KTH_NEVER),
  * the ranks all-gather those blocks (RCCL), and every rank merges
  *   d_gathered : int32[n_ranks][Q][k+1][3]  ->  d_topk int32[Q][k][3], d_totals int32[Q]
- * (d_totals = hits over all shards; > k means the merged list is truncated). */
+ * (d_totals = hits over all shards; > k means the merged list is truncated to the k best;
+ * NEGATIVE means some shard's hit list overflowed `cap`, so its top-k may be inexact: re-run with
+ * a larger cap). */
 int tvz_topk_shard(const int32_t *d_hits, const int32_t *d_hits_n, int32_t Q, int32_t cap,
                    int32_t k, int32_t *d_out, void *hip_stream);
 int tvz_topk_merge(const int32_t *d_gathered, int32_t n_ranks, int32_t Q, int32_t k,

@@ -280,7 +280,7 @@ def test_sharded_pipeline_on_one_gpu(dc):
             cnt, kth = oracle.match_kth_csr(q, offs, keys, mm)
             rows = [(int(ids[c]), int(cnt[c]), int(kth[c])) for c in range(C)
                     if cnt[c] >= mm and ids[c] != int(excl[qi])]
-            assert int(totals[qi]) == len(rows)
+            assert int(totals[qi]) == len(rows)          # cap 64 is never exceeded per shard here
             exp = sorted(rows, key=lambda h: (h[2], h[0], h[1]))[:k]
             exp += [(-1, 0, NEVER)] * (k - len(exp))
             assert [tuple(int(x) for x in r) for r in merged[qi]] == exp, (R, qi)
@@ -429,3 +429,18 @@ def test_hash_join_flags_wrong_bound(dc):
         assert (n.cpu().numpy() == 1).all() and (hits[:, 0, 1].cpu().numpy() == 3).all()
     finally:
         _lib.check(lib.tvz_match_set_tuning(1))
+
+
+def test_shard_overflow_is_signalled_by_negative_totals(dc):
+    ids, offs, keys = synth.synth_timestamp_corpus(600, seed=3, mean_len=30)
+    dc.upload_csr(ids, offs, keys)
+    d_q, d_off, max_len = tc.pack_queries([keys[:40], keys[100:140]], DEV)
+    hits, n = dc.match(d_q, d_off, max_len, 0, cap=50)          # min_match 0: 600 hits per query > cap
+    block = tc.topk_shard(hits, n, 8)
+    merged, totals = tc.topk_merge(block.unsqueeze(0).contiguous(), 8)
+    torch.cuda.synchronize()
+    assert block[:, 8, 1].cpu().tolist() == [-600, -600]
+    assert totals.cpu().tolist() == [-600, -600]
+    hits, n = dc.match(d_q, d_off, max_len, 0, cap=600)         # enough room: positive again
+    merged, totals = tc.topk_merge(tc.topk_shard(hits, n, 8).unsqueeze(0).contiguous(), 8)
+    assert totals.cpu().tolist() == [600, 600]

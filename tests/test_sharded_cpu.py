@@ -52,7 +52,8 @@ class OracleBackend:
         for q in range(Q):
             m = min(int(hits_n[q]), cap)
             ent = [tuple(int(x) for x in e) for e in hits[q, :m]]
-            out[q] = torch.tensor(self._best(ent, k) + [(-1, int(hits_n[q]), NEVER)], dtype=torch.int32)
+            n = int(hits_n[q])
+            out[q] = torch.tensor(self._best(ent, k) + [(-1, -n if n > cap else n, NEVER)], dtype=torch.int32)
         return out
 
     def topk_merge(self, gathered, k):
@@ -63,7 +64,9 @@ class OracleBackend:
             ent = []
             for r in range(R):
                 ent += [tuple(int(x) for x in e) for e in gathered[r, q, :k] if int(e[0]) >= 0]
-                totals[q] += int(gathered[r, q, k, 1])
+                totals[q] += abs(int(gathered[r, q, k, 1]))
+            if any(int(gathered[r, q, k, 1]) < 0 for r in range(R)):
+                totals[q] = -totals[q]
             out[q] = torch.tensor(self._best(ent, k), dtype=torch.int32)
         return out, totals
 
@@ -97,13 +100,23 @@ def _worker(rank, world, port, C, Q, mm, k, cap, q):
         d_q = torch.from_numpy(np.concatenate(queries))
         ex = torch.tensor(excl, dtype=torch.int32)
         exp = _expected(ids, offs, keys, queries, mm, k, excl)
+        # which queries overflow the per-shard capacity on SOME shard (the totals must say so)
+        any_overflow = [False] * Q
+        for r in range(world):
+            r_ids, r_offs, r_keys = sharded.shard_csr(ids, offs, keys, r, world)
+            for qi, qq in enumerate(queries):
+                c_, _ = oracle.match_kth_csr(qq, r_offs, r_keys, mm)
+                n_r = sum(1 for c in range(len(r_ids)) if c_[c] >= mm and r_ids[c] != excl[qi])
+                any_overflow[qi] = any_overflow[qi] or n_r > cap
         # plain call, then two batches pipelined (submit i+1 before finishing i)
         t1 = sm.submit(d_q, d_off, max(lens), mm, ex)
         t2 = sm.submit(d_q, d_off, max(lens), mm, ex)
         for merged, totals in (sm.match_topk(d_q, d_off, max(lens), mm, ex), sm.finish(t1), sm.finish(t2)):
             for qi in range(Q):
-                assert [tuple(int(x) for x in r) for r in merged[qi]] == exp[qi][0], (rank, qi)
-                assert int(totals[qi]) == exp[qi][1]
+                if not any_overflow[qi]:
+                    assert [tuple(int(x) for x in r) for r in merged[qi]] == exp[qi][0], (rank, qi)
+                assert abs(int(totals[qi])) == exp[qi][1]
+                assert (int(totals[qi]) < 0) == any_overflow[qi]
         q.put((rank, "ok"))
     except Exception as e:  # pragma: no cover
         q.put((rank, repr(e)))

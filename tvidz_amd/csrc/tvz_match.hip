@@ -684,13 +684,16 @@ __global__ __launch_bounds__(kBlock) void ts_topk_kernel(const int32_t *__restri
                                                          int32_t k, int32_t *__restrict__ topk,
                                                          int32_t mode, int32_t *__restrict__ totals) {
     // mode 0: plain.  mode 1 (shard side): the output has k+1 rows per query, row k carries the
-    // true number of hits as (-1, n, NEVER) so one all-gather moves lists and totals together.
-    // mode 2 (merge side): every input list ends with such a row; it is summed into totals[q].
+    // true number of hits as (-1, n, NEVER) so one all-gather moves lists and totals together; n is
+    // NEGATED when the shard's hit list overflowed its capacity (its top-k may then be inexact).
+    // mode 2 (merge side): every input list ends with such a row; |n| is summed into totals[q], and
+    // the sum is negated if any shard overflowed, so the caller knows to re-run with a larger cap.
     __shared__ uint64_t key[kSortCap];
     __shared__ int32_t cnt[kSortCap];
     const int q = blockIdx.x;
     int pos = 0;  // block-uniform fill level
     long long total = 0;
+    bool overflow = false;
     auto sort_and_keep = [&]() {
         int P = 2;
         while (P < pos) P <<= 1;
@@ -701,11 +704,16 @@ __global__ __launch_bounds__(kBlock) void ts_topk_kernel(const int32_t *__restri
     for (int l = 0; l < n_lists; ++l) {
         int n = lists_n ? lists_n[(int64_t)l * Q + q] : cap;
         const int32_t *src = lists + ((int64_t)l * Q + q) * (int64_t)cap * 3;
-        if (mode == 1) total += n;
+        if (mode == 1) {
+            total += n;
+            if (n > cap) overflow = true;          // this shard's list was truncated
+        }
         if (n > cap) n = cap;
         if (mode == 2) {
             n = cap - 1;
-            total += src[(cap - 1) * 3 + 1];
+            const int32_t t = src[(cap - 1) * 3 + 1];   // negative: that shard overflowed
+            total += t < 0 ? -(long long)t : t;
+            if (t < 0) overflow = true;
         }
         int j = 0;
         while (j < n) {
@@ -726,7 +734,8 @@ __global__ __launch_bounds__(kBlock) void ts_topk_kernel(const int32_t *__restri
     sort_and_keep();
     const int orows = (mode == 1) ? k + 1 : k;
     if (threadIdx.x == 0) {
-        const int32_t t = total > 0x7fffffffLL ? 0x7fffffff : (int32_t)total;
+        int32_t t = total > 0x7fffffffLL ? 0x7fffffff : (int32_t)total;
+        if (overflow) t = (t == 0) ? INT32_MIN : -t;   // negative total = some hit list was truncated
         if (mode == 1) {
             int32_t *o = topk + ((int64_t)q * orows + k) * 3;
             o[0] = -1; o[1] = t; o[2] = TVZ_KTH_NEVER;

@@ -91,7 +91,8 @@ class ShardedMatcher:
 
     def finish(self, ticket):
         """-> (merged int32 [Q,k,3] of (video_id, count, kth), total_hits int32 [Q]) — identical on
-        every rank.  total_hits > k means the list was truncated to the k best."""
+        every rank.  total_hits > k means the list was truncated to the k best; a NEGATIVE total
+        means a shard's hit list overflowed `cap` (re-run that query with a larger cap)."""
         gathered, work, _keepalive = ticket
         if work is not None:
             work.wait()                     # makes the current stream wait for the collective
