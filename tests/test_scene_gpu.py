@@ -286,3 +286,15 @@ def test_scene_path_is_graph_capturable():
         o_sad, o_sel, o_score, _ = _oracle_all(frames.cpu().numpy())
         assert (sc.sad[:T].cpu().numpy().view(np.uint64) == o_sad).all()
         assert (sc.selected[:T].cpu().numpy() == o_sel).all() and (sc.score[:T].cpu().numpy() == o_score).all()
+
+
+def test_detect_scene_cuts_from_a_file_path(tmp_path):
+    from tvidz_amd import feeder
+    T, H, W = 150, 96, 128
+    frames, _ = synth.synth_luma(T, H, W, device=DEV, seed=9, min_scene=15, max_scene=40, adversarial=False)
+    p = str(tmp_path / "clip.y4m")
+    feeder.write_y4m(p, frames.cpu().numpy(), fps=(25, 1), chroma="420jpeg")
+    got = list(scene.detect_scene_cuts(p, batch=64))
+    _, o_sel, _, _ = _oracle_all(frames.cpu().numpy())
+    assert got == [(int(i), oracle.pts_time_value(int(i), 1, 25, 0)) for i in np.flatnonzero(o_sel)]
+    assert len(got) >= 2

@@ -195,14 +195,24 @@ def detect_scene_cuts(frames: Union[torch.Tensor, Iterable], time_base: Tuple[in
                       scorer: Optional[SceneScorer] = None) -> Iterator[Tuple[int, float]]:
     """Yield (frame_idx, pts_time) for every frame ffmpeg's `select=gt(scene,threshold)` keeps.
 
-    frames: a uint8 [T,H,W] luma tensor (CUDA or CPU), or an iterable of such chunks (a frame
-            feeder); chunks are scored in micro-batches of `batch` frames so a caller can stop
+    frames: a uint8 [T,H,W] luma tensor (CUDA or CPU), an iterable of such chunks (a frame
+            feeder), or the path of a media file (Y4M natively, anything else via the host's
+            ffmpeg; its time base replaces `time_base`); chunks are scored in micro-batches of `batch` frames so a caller can stop
             early (the reference terminates ffmpeg at the first duplicate, app.py:249-255).
     pts:    presentation timestamps in time_base units (default: the frame index, i.e. a
             constant-frame-rate stream with time_base = 1/fps).
     """
-    chunks = [frames] if isinstance(frames, torch.Tensor) else frames
     dev = torch.device(device)
+    if isinstance(frames, (str, bytes)) or hasattr(frames, "__fspath__"):
+        # a media file: Y4M is read directly, anything else through the host's ffmpeg as a raw
+        # planar-YUV pipe (the decode half of the reference's single ffmpeg process)
+        from .feeder import FFmpegReader, FrameFeeder, Y4MReader
+        with open(frames, "rb") as f:
+            magic = f.read(9)
+        reader = Y4MReader(frames) if magic == b"YUV4MPEG2" else FFmpegReader(frames)
+        time_base = reader.time_base
+        frames = (d for _, d in FrameFeeder(reader, batch, dev))
+    chunks = [frames] if isinstance(frames, torch.Tensor) else frames
     base = 0
     for chunk in chunks:
         if not isinstance(chunk, torch.Tensor):
