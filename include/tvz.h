@@ -11,8 +11,12 @@
  * Each entry point below cites the seam it replaces.  Everything is plain C:
  * pointers + sizes, no torch / C++ types.  `d_` = device (HBM) pointer,
  * `h_` = host pointer.  `hip_stream` is a hipStream_t passed as void*
- * (NULL = the default stream).  All functions are re-entrant; the only shared
- * mutable object is a tvz_corpus handle, which is internally locked.
+ * (NULL = the default stream).  All functions are re-entrant and the library
+ * keeps NO process-global mutable state: kernel-shape / algorithm choices are
+ * per-call arguments, carried stream state lives in caller-owned device
+ * memory, and the only shared mutable objects are the tvz_corpus / tvz_comm
+ * handles (internally locked).  Hot calls allocate nothing: scratch is a
+ * caller-provided workspace sized by the *_workspace_bytes functions.
  *
  * Error convention: 0 on success, negative tvz_status otherwise; the message
  * is in tvz_last_error() (thread-local).  The Python shim raises
@@ -29,7 +33,7 @@
 extern "C" {
 #endif
 
-#define TVZ_VERSION 100 /* 0.1.0 */
+#define TVZ_VERSION 200 /* 0.2.0 */
 
 typedef enum tvz_status {
     TVZ_OK = 0,
@@ -37,7 +41,8 @@ typedef enum tvz_status {
     TVZ_ERR_HIP = -2,         /* a HIP runtime call failed */
     TVZ_ERR_NOMEM = -3,       /* device or host allocation failed */
     TVZ_ERR_UNSUPPORTED = -4, /* shape outside what the kernels handle */
-    TVZ_ERR_WORKSPACE = -5    /* caller-provided workspace too small */
+    TVZ_ERR_WORKSPACE = -5,   /* caller-provided workspace too small */
+    TVZ_ERR_COMM = -6         /* RCCL missing or a collective failed */
 } tvz_status;
 
 #define TVZ_KTH_NEVER 0x7fffffff /* kth_hit_idx of a candidate that never reaches min_match */
@@ -51,14 +56,33 @@ const char *tvz_last_error(void);
  * libavfilter/f_select.c get_scene_score + scene_sad.c).
  * ------------------------------------------------------------------------ */
 
-/* Bytes of scratch tvz_luma_sad_u8 / tvz_scene_scores_u8 need for a batch. */
+/* Bytes of scratch the scene entry points need for a batch of up to T frames. */
 size_t tvz_scene_workspace_bytes(int64_t T, int32_t H, int32_t W);
+
+/* Stream state: what get_scene_score carries from one frame to the next (the
+ * previous frame and prev_mafd), kept in DEVICE memory so that a stream scored
+ * in micro-batches needs no host round trip between batches and a chain of
+ * batches can be captured in one HIP graph.  The caller owns a buffer of
+ * tvz_scene_state_bytes() bytes (256-byte aligned), resets it once per video
+ * and passes it to every tvz_scene_scores_* call of that video; each call READS
+ * the predecessor (frame + mafd) from it and WRITES its own last frame + mafd
+ * back.  bytes_per_sample: 1 (8-bit) or 2 (9..16-bit luma in uint16). */
+size_t tvz_scene_state_bytes(int32_t H, int32_t W, int32_t bytes_per_sample);
+int tvz_scene_state_reset(void *d_state, void *hip_stream);
+
+/* Kernel-shape override for A/B runs, PER CALL (there is no global knob):
+ * 0 = automatic; otherwise U | (tc << 8) | TVZ_SHAPE_NO_NT where U in {1,2,4,8} is the strip
+ * width (16-byte loads per lane and frame) and tc the frames per time chunk (8,16,32 or a
+ * multiple of 64).  Results never depend on it. */
+#define TVZ_SHAPE_AUTO 0u
+#define TVZ_SHAPE_NO_NT (1u << 30)
+#define TVZ_SHAPE(U, tc) ((uint32_t)(U) | ((uint32_t)(tc) << 8))
 
 /* Luma sum of absolute differences between consecutive frames of a batch.
  *   d_luma : uint8 luma planes, frame t at d_luma + t*frame_stride_bytes,
  *            row y at + y*row_stride_bytes, W bytes per row.
  *   d_sad_out[T] : sad[0] = 0, sad[t] = sum |luma[t] - luma[t-1]|  (exact).
- * Every luma byte is read from HBM once (+1 halo frame per 128-frame chunk).
+ * Every luma byte is read from HBM once (+1 halo frame per time chunk).
  * Fast path: row_stride == W, base and frame stride 16-byte aligned; anything
  * else takes a slower generic kernel with identical results. */
 int tvz_luma_sad_u8(const uint8_t *d_luma, int64_t T, int32_t H, int32_t W,
@@ -69,37 +93,39 @@ int tvz_luma_sad_u8(const uint8_t *d_luma, int64_t T, int32_t H, int32_t W,
 /* get_scene_score epilogue over a SAD vector:
  *   mafd  = sad / (W*H) / 2^(bitdepth-8);  diff = |mafd - prev_mafd|
  *   score = clipf((float)(min(mafd, diff) / 100), 0, 1);  selected = score > threshold
- * have_prev = 0: element 0 is the first frame of the stream (score 0, and
- * element 1 uses prev_mafd_in as ffmpeg's zero-initialised prev_mafd would).
- * have_prev = 1: the batch continues a stream; sad[0] is a real SAD against
- * the previous batch's last frame and prev_mafd_in is that batch's last mafd.
- * d_score / d_mafd may be NULL. */
+ * d_prev_mafd = NULL: element 0 is the first frame of the stream (score 0, and
+ * element 1 sees ffmpeg's zero-initialised prev_mafd).
+ * d_prev_mafd != NULL (device pointer to one double): the batch continues a
+ * stream; sad[0] is a real SAD against the previous batch's last frame and
+ * *d_prev_mafd is that batch's last mafd.  d_score / d_mafd may be NULL. */
 int tvz_scene_select(const uint64_t *d_sad, int64_t T, int32_t H, int32_t W,
-                     int32_t bitdepth, double threshold, double prev_mafd_in,
-                     int32_t have_prev, uint8_t *d_selected, double *d_score,
-                     double *d_mafd, void *hip_stream);
+                     int32_t bitdepth, double threshold, const double *d_prev_mafd,
+                     uint8_t *d_selected, double *d_score, double *d_mafd, void *hip_stream);
 
-/* Fused batch call: luma -> sad, mafd, score, selected in two launches.
- * d_prev_frame (nullable): the last luma plane of the previous batch (tightly
- * packed H*W bytes, 16-byte aligned); when given, have_prev semantics apply and
- * element 0 gets a real score.  Any of d_sad_out/d_score/d_mafd may be NULL. */
+/* Fused batch call: luma -> sad, mafd, score, selected (+ the compacted cut list).
+ *   d_state (nullable): stream state (above).  NULL = a self-contained batch whose frame 0 is
+ *       the first frame of a stream (score 0).  Non-NULL: frame 0 is scored against the state's
+ *       frame unless the state was just reset, and the state is advanced to this batch's end.
+ *   d_cuts (nullable): int32[1 + cuts_cap]; [0] = number of selected frames of the batch, then
+ *       their indices in ascending order (the first cuts_cap of them) - ONE small device-to-host
+ *       copy per micro-batch gives the host everything showinfo would have printed.
+ *   Any of d_sad_out / d_score / d_mafd may be NULL; d_selected is required with d_cuts.
+ * Enqueues kernels only (no allocation, no synchronisation): graph-capturable. */
 int tvz_scene_scores_u8(const uint8_t *d_luma, int64_t T, int32_t H, int32_t W,
-                        int64_t frame_stride_bytes, int64_t row_stride_bytes,
-                        const uint8_t *d_prev_frame, double prev_mafd_in,
-                        int32_t bitdepth, double threshold,
-                        uint64_t *d_sad_out, double *d_mafd, double *d_score,
-                        uint8_t *d_selected, void *d_workspace, size_t workspace_bytes,
+                        int64_t frame_stride_bytes, int64_t row_stride_bytes, void *d_state,
+                        int32_t bitdepth, double threshold, uint64_t *d_sad_out, double *d_mafd,
+                        double *d_score, uint8_t *d_selected, int32_t *d_cuts, int32_t cuts_cap,
+                        void *d_workspace, size_t workspace_bytes, uint32_t shape,
                         void *hip_stream);
 
 /* The same for 9..16-bit luma stored as uint16 (yuv420p10 etc.): ffmpeg's ff_scene_sad16_c sums
  * |a-b| over uint16 samples and get_scene_score divides mafd by 2^(bitdepth-8).  Strides are in
- * BYTES.  d_prev_frame: tightly packed H*W uint16. */
+ * BYTES. */
 int tvz_scene_scores_u16(const uint16_t *d_luma, int64_t T, int32_t H, int32_t W,
-                         int64_t frame_stride_bytes, int64_t row_stride_bytes,
-                         const uint16_t *d_prev_frame, double prev_mafd_in,
-                         int32_t bitdepth, double threshold,
-                         uint64_t *d_sad_out, double *d_mafd, double *d_score,
-                         uint8_t *d_selected, void *d_workspace, size_t workspace_bytes,
+                         int64_t frame_stride_bytes, int64_t row_stride_bytes, void *d_state,
+                         int32_t bitdepth, double threshold, uint64_t *d_sad_out, double *d_mafd,
+                         double *d_score, uint8_t *d_selected, int32_t *d_cuts, int32_t cuts_cap,
+                         void *d_workspace, size_t workspace_bytes, uint32_t shape,
                          void *hip_stream);
 
 /* ------------------------------------------------------------------------
@@ -112,6 +138,10 @@ int tvz_corpus_create(tvz_corpus **out, int device);
 /* Must not run concurrently with any other call on the same handle. */
 int tvz_corpus_destroy(tvz_corpus *c);
 
+/* Pre-size the device arena / row table / single-query staging for at least this many rows and
+ * keys, so later upserts and queries allocate nothing (upload reserves 2x its input itself). */
+int tvz_corpus_reserve(tvz_corpus *c, int64_t n_rows, int64_t n_keys);
+
 /* Replace the whole corpus (the `session.query(VideoTimestamps).all()` of
  * db.py:83 done once instead of per call).  Row r owns
  * h_keys[h_offsets[r] .. h_offsets[r+1]).  Rows need not be sorted or unique;
@@ -120,7 +150,11 @@ int tvz_corpus_upload(tvz_corpus *c, const int32_t *h_video_ids, const int64_t *
                       const double *h_keys, int64_t n_rows, int64_t n_keys);
 
 /* add_timestamps (db.py:43-64): replace the first row of `video_id` with the
- * new list, or append a row if the video has none. */
+ * new list, or append a row if the video has none.  Does NOT wait for matches
+ * in flight: the new keys go to fresh arena space and the 16-byte row entry is
+ * swapped by a stream-ordered device write, so a concurrent match sees the old
+ * or the new row, never a mix; every match ENQUEUED after this call returns
+ * sees the new row (read-your-writes, as a committed db.py:58-62 would give). */
 int tvz_corpus_upsert(tvz_corpus *c, int32_t video_id, const double *h_keys, int64_t n);
 
 /* `/admin/clear-db` (app.py:325-333). */
@@ -144,7 +178,23 @@ int tvz_corpus_stats(tvz_corpus *c, int64_t *n_rows, int64_t *n_keys, int64_t *a
  * on which find_duplicates returns row r  <=>  kth == k.
  * ------------------------------------------------------------------------ */
 
-/* Batched, device-resident form (bench / sharded path).
+/* Which kernel sweeps the corpus, PER CALL (there is no global knob); results never depend on it.
+ *   AUTO : Q <= 8 -> Q1; large batches with min_match <= 2 -> JOIN; else TILE
+ *   Q1   : one corpus sweep per query, the query's keys in a small LDS table, per-lane counters
+ *   TILE : one LDS hash table per tile of <= 16 queries
+ *   JOIN : device-memory hash join per tile of 128 queries (min_match <= 2 only) */
+#define TVZ_ALGO_AUTO 0
+#define TVZ_ALGO_Q1 1
+#define TVZ_ALGO_TILE 2
+#define TVZ_ALGO_JOIN 3
+
+/* Scratch for the batched calls below.  k = 0 for tvz_match (tables of the hash join only);
+ * k > 0 adds the hit lists + per-shard top-k block of tvz_match_topk / tvz_match_sharded
+ * (and n_ranks gathered blocks for the latter; pass n_ranks = 1 otherwise). */
+size_t tvz_match_workspace_bytes(int32_t Q, int32_t max_query_len, int32_t cap, int32_t k,
+                                 int32_t n_ranks);
+
+/* Batched, device-resident form.
  *   d_queries   : float64 keys of all queries back to back
  *   d_q_offsets : int64[Q+1]
  *   d_exclude_ids : int32[Q] or NULL
@@ -155,11 +205,23 @@ int tvz_corpus_stats(tvz_corpus *c, int64_t *n_rows, int64_t *n_keys, int64_t *a
 int tvz_match(tvz_corpus *c, const double *d_queries, const int64_t *d_q_offsets,
               int32_t Q, int32_t max_query_len, int32_t min_match,
               const int32_t *d_exclude_ids, int32_t cap,
-              int32_t *d_hits, int32_t *d_hits_n, void *hip_stream);
+              int32_t *d_hits, int32_t *d_hits_n, void *d_workspace, size_t workspace_bytes,
+              int32_t algo, void *hip_stream);
+
+/* Match + per-shard top-k behind ONE call (hit lists stay in the workspace):
+ *   d_out : int32[Q][k+1][3] = the k best hits by (kth, video_id, count), padded with
+ *           (-1, 0, TVZ_KTH_NEVER), + a row (-1, n_hits, TVZ_KTH_NEVER); n_hits is NEGATED when
+ *           the hit list overflowed `cap` (the top-k may then be inexact: re-run with more). */
+int tvz_match_topk(tvz_corpus *c, const double *d_queries, const int64_t *d_q_offsets,
+                   int32_t Q, int32_t max_query_len, int32_t min_match,
+                   const int32_t *d_exclude_ids, int32_t cap, int32_t k, int32_t *d_out,
+                   void *d_workspace, size_t workspace_bytes, int32_t algo, void *hip_stream);
 
 /* Host-in / host-out single query: the drop-in for db.find_duplicates.
  * Results sorted by (video_id, count).  *n_out = number of hits (if > cap only
- * cap are returned).  h_out_kth may be NULL.  Any query length is accepted. */
+ * cap are returned).  h_out_kth may be NULL.  Any query length is accepted.
+ * One kernel launch + one stream synchronisation for queries of <= 4095 timestamps: the
+ * kernel writes its hits straight into pinned host memory owned by the handle. */
 int tvz_find_duplicates(tvz_corpus *c, const double *h_query, int64_t n, int32_t min_match,
                         int32_t exclude_id, int64_t cap, int32_t *h_out_ids,
                         int32_t *h_out_counts, int32_t *h_out_kth, int64_t *n_out);
@@ -184,6 +246,33 @@ int tvz_topk_shard(const int32_t *d_hits, const int32_t *d_hits_n, int32_t Q, in
                    int32_t k, int32_t *d_out, void *hip_stream);
 int tvz_topk_merge(const int32_t *d_gathered, int32_t n_ranks, int32_t Q, int32_t k,
                    int32_t *d_topk, int32_t *d_totals, void *hip_stream);
+
+/* ------------------------------------------------------------------------
+ * Multi-GPU corpus match: one process per GPU, the corpus rows sharded over
+ * the ranks, ONE RCCL all-gather of the per-shard top-k blocks per query batch.  RCCL is bound at
+ * run time (dlopen of librccl.so, the copy already mapped by the process if there is one), so
+ * libtvz.so loads on hosts without it; tvz_comm_* then return TVZ_ERR_COMM.
+ *   rank 0: tvz_comm_unique_id(id)  -> ship the 128 bytes to the other ranks by any means
+ *   every rank, BEFORE or after its first GPU call: tvz_comm_init(&comm, id, nranks, rank, dev)
+ * ------------------------------------------------------------------------ */
+#define TVZ_UNIQUE_ID_BYTES 128
+typedef struct tvz_comm tvz_comm;
+
+int tvz_comm_unique_id(void *out_id /* TVZ_UNIQUE_ID_BYTES */);
+int tvz_comm_init(tvz_comm **out, const void *unique_id, int32_t n_ranks, int32_t rank,
+                  int32_t device);
+int tvz_comm_info(tvz_comm *comm, int32_t *n_ranks, int32_t *rank);
+int tvz_comm_destroy(tvz_comm *comm);
+
+/* local tvz_match_topk -> ncclAllGather of int32[Q][k+1][3] on `hip_stream` -> tvz_topk_merge.
+ * Every rank gets the same d_topk int32[Q][k][3] and d_totals int32[Q] (see tvz_topk_merge).
+ * Workspace: tvz_match_workspace_bytes(Q, max_query_len, cap, k, n_ranks).  Two calls on two
+ * streams with two workspaces overlap one batch's collective with the next batch's match. */
+int tvz_match_sharded(tvz_corpus *c, tvz_comm *comm, const double *d_queries,
+                      const int64_t *d_q_offsets, int32_t Q, int32_t max_query_len,
+                      int32_t min_match, const int32_t *d_exclude_ids, int32_t cap, int32_t k,
+                      int32_t *d_topk, int32_t *d_totals, void *d_workspace,
+                      size_t workspace_bytes, int32_t algo, void *hip_stream);
 
 /* ------------------------------------------------------------------------
  * Opt-in alignment score.  NOT the reference's verdict: db.py:79 matches

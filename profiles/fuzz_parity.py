@@ -49,11 +49,10 @@ while time.time() < t_end:
     mm = int(rng.choice([-1, 0, 1, 2, 2, 2, 3, 5, 6, 9]))
     excl = None if rng.random() < 0.5 else [int(rng.integers(1, 10 * C + 2)) for _ in range(Q)]
     cap = int(rng.choice([1, 5, max(C, 1)]))
-    mode = int(rng.choice([0, 1, 2]))
-    _lib.check(lib.tvz_match_set_tuning(mode))
+    mode = int(rng.choice([_lib.ALGO_AUTO, _lib.ALGO_Q1, _lib.ALGO_TILE, _lib.ALGO_JOIN]))   # per call
     d_q, d_off, ml = tc.pack_queries(queries, dev)
     d_ex = torch.tensor(excl, dtype=torch.int32, device=dev) if excl is not None else None
-    hits, n = dc.match(d_q, d_off, ml, mm, cap, d_exclude_ids=d_ex)
+    hits, n = dc.match(d_q, d_off, ml, mm, cap, d_exclude_ids=d_ex, algo=mode)
     torch.cuda.synchronize()
     hits, n = hits.cpu().numpy(), n.cpu().numpy()
     for qi, q in enumerate(queries):
@@ -65,7 +64,6 @@ while time.time() < t_end:
         if not ok:
             print("MATCH MISMATCH", dict(C=C, Q=Q, mm=mm, cap=cap, mode=mode, qi=qi, n=int(n[qi]), exp=len(exp)))
             sys.exit(1)
-    _lib.check(lib.tvz_match_set_tuning(1))
     qi = int(rng.integers(0, Q))
     longq = rand_keys(int(rng.choice([10, 4500])), grid)
     for q in (queries[qi], longq):
@@ -93,8 +91,7 @@ while time.time() < t_end:
     sels, sads = [], []
     for s0 in range(0, T, step):
         part = d[s0:s0 + step]
-        sad, _, _, sel = sc.score_batch(part)
-        sc.remember_tail(part)
+        sad, _, _, sel = sc.score_batch(part)      # the carried state stays on the device
         sads.append(sad.cpu().numpy().view(np.uint64).copy()); sels.append(sel.cpu().numpy().copy())
     o_sad = oracle.luma_sad(v)
     o_sel, _, _, _ = oracle.scene_select(o_sad, H, W, 0.3, bitdepth=bd)

@@ -21,16 +21,14 @@ for T in (32, 64, 128, 256, 512, 1024, 2048):
     res = {}
     variants = [("auto", (0, 0, 1))] + [(f"U{u}tc{tc}", (u, tc, 1)) for u in (1, 2, 4, 8) for tc in (8, 16, 32, 64, 128, 256)]
     for name, tune in variants:
-        _lib.check(lib.tvz_scene_set_tuning(*tune))
         sc = scene.SceneScorer(H, W, T, dev)
         ts = []
         for r in range(30):
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            a.record(); sc.score_batch(frames, carry=False); b.record()
+            a.record(); sc.score_batch(frames, carry=False, shape=_lib.shape(*tune)); b.record()
             torch.cuda.synchronize()
             ts.append(a.elapsed_time(b))
         res[name] = round(float(np.median(ts[5:])) * 1e3, 1)
-    _lib.check(lib.tvz_scene_set_tuning(0, 0, 1))
     best = min(res, key=res.get)
     print(json.dumps({"T": T, "auto_us": res["auto"], "best": best, "best_us": res[best],
                       "best_GBps": round((T - 1) * H * W / res[best] / 1e3, 1),

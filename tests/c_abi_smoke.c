@@ -30,6 +30,8 @@ int main(void) {
     int64_t n = -1;
     double q1[5] = {10.0, 20.0, 30.0, 40.0, 50.0};
     CHECK(tvz_find_duplicates(c, q1, 5, 5, -1, 8, oid, ocnt, okth, &n));
+    if (!(n == 1 && oid[0] == 2 && ocnt[0] == 5 && okth[0] == 4))
+        fprintf(stderr, "got n=%lld first=(%d,%d,%d)\n", (long long)n, oid[0], ocnt[0], okth[0]);
     EXPECT(n == 1 && oid[0] == 2 && ocnt[0] == 5 && okth[0] == 4);
     double third[5] = {1.0, 2.0, 3.0, 4.0, 5.0};
     CHECK(tvz_corpus_upsert(c, 3, third, 5));
@@ -65,8 +67,13 @@ int main(void) {
     HIPCHECK(hipMalloc((void **)&d_sel, T));
     HIPCHECK(hipMalloc(&d_ws, ws));
     HIPCHECK(hipMemcpy(d_luma, frames, sizeof frames, hipMemcpyHostToDevice));
-    CHECK(tvz_scene_scores_u8(d_luma, T, H, W, (int64_t)H * W, W, NULL, 0.0, 8, 0.3, d_sad, d_mafd, d_score,
-                              d_sel, d_ws, ws, NULL));
+    int32_t *d_cuts; void *d_state;
+    size_t st_bytes = tvz_scene_state_bytes(H, W, 1);
+    EXPECT(st_bytes >= 2 * (size_t)H * W);
+    HIPCHECK(hipMalloc((void **)&d_cuts, (1 + T) * 4));
+    HIPCHECK(hipMalloc(&d_state, st_bytes));
+    CHECK(tvz_scene_scores_u8(d_luma, T, H, W, (int64_t)H * W, W, NULL, 8, 0.3, d_sad, d_mafd, d_score,
+                              d_sel, d_cuts, T, d_ws, ws, TVZ_SHAPE_AUTO, NULL));
     HIPCHECK(hipDeviceSynchronize());
     uint64_t sad[T]; double mafd[T], score[T]; uint8_t sel[T];
     HIPCHECK(hipMemcpy(sad, d_sad, sizeof sad, hipMemcpyDeviceToHost));
@@ -86,6 +93,43 @@ int main(void) {
         prev = m;
     }
     EXPECT(sel[2] == 1 && sel[4] == 1 && sel[1] == 0 && sel[3] == 0 && sel[5] == 0);
+    int32_t cuts[1 + T];
+    HIPCHECK(hipMemcpy(cuts, d_cuts, sizeof cuts, hipMemcpyDeviceToHost));
+    EXPECT(cuts[0] == 2 && cuts[1] == 2 && cuts[2] == 4);
+    /* the same stream in two chunks through the device-resident state: no host value in between */
+    CHECK(tvz_scene_state_reset(d_state, NULL));
+    CHECK(tvz_scene_scores_u8(d_luma, 4, H, W, (int64_t)H * W, W, d_state, 8, 0.3, NULL, NULL, NULL,
+                              d_sel, d_cuts, T, d_ws, ws, TVZ_SHAPE_AUTO, NULL));
+    HIPCHECK(hipMemcpy(cuts, d_cuts, sizeof cuts, hipMemcpyDeviceToHost));
+    EXPECT(cuts[0] == 1 && cuts[1] == 2);
+    CHECK(tvz_scene_scores_u8(d_luma + 4 * H * W, 2, H, W, (int64_t)H * W, W, d_state, 8, 0.3, NULL, NULL,
+                              NULL, d_sel, d_cuts, T, d_ws, ws, TVZ_SHAPE(4, 64), NULL));
+    HIPCHECK(hipMemcpy(cuts, d_cuts, sizeof cuts, hipMemcpyDeviceToHost));
+    EXPECT(cuts[0] == 1 && cuts[1] == 0);          /* frame 4 of the stream = frame 0 of chunk 2 */
+    /* batched match + top-k behind one call, scratch from the caller */
+    {
+        tvz_corpus *c2 = NULL;
+        CHECK(tvz_corpus_create(&c2, 0));
+        CHECK(tvz_corpus_upload(c2, ids, offs, keys, 2, 10));
+        double *d_q; int64_t *d_off; int32_t *d_out; void *d_mws;
+        int64_t qoff[2] = {0, 5};
+        size_t mws = tvz_match_workspace_bytes(1, 5, 8, 2, 1);
+        EXPECT(mws > 0);
+        HIPCHECK(hipMalloc((void **)&d_q, 5 * 8)); HIPCHECK(hipMalloc((void **)&d_off, 16));
+        HIPCHECK(hipMalloc((void **)&d_out, 3 * 3 * 4)); HIPCHECK(hipMalloc(&d_mws, mws));
+        HIPCHECK(hipMemcpy(d_q, q1, 5 * 8, hipMemcpyHostToDevice));
+        HIPCHECK(hipMemcpy(d_off, qoff, 16, hipMemcpyHostToDevice));
+        CHECK(tvz_match_topk(c2, d_q, d_off, 1, 5, 2, NULL, 8, 2, d_out, d_mws, mws, TVZ_ALGO_AUTO, NULL));
+        HIPCHECK(hipDeviceSynchronize());
+        int32_t out[9];
+        HIPCHECK(hipMemcpy(out, d_out, sizeof out, hipMemcpyDeviceToHost));
+        EXPECT(out[0] == 2 && out[1] == 5 && out[2] == 1);        /* video 2, 5 matches, kth = 1 */
+        EXPECT(out[3] == -1 && out[6] == -1 && out[7] == 1);      /* padding, then the totals row */
+        EXPECT(tvz_match_topk(c2, d_q, d_off, 1, 5, 2, NULL, 8, 2, d_out, d_mws, 16, TVZ_ALGO_AUTO, NULL) == TVZ_ERR_WORKSPACE);
+        hipFree(d_q); hipFree(d_off); hipFree(d_out); hipFree(d_mws);
+        CHECK(tvz_corpus_destroy(c2));
+    }
+    hipFree(d_cuts); hipFree(d_state);
     hipFree(d_luma); hipFree(d_sad); hipFree(d_mafd); hipFree(d_score); hipFree(d_sel); hipFree(d_ws);
     printf("c_abi_smoke OK\n");
     return 0;

@@ -17,7 +17,9 @@ def test_header_declares_the_path():
     names = _declared()
     for must in ("tvz_luma_sad_u8", "tvz_scene_select", "tvz_scene_scores_u8", "tvz_corpus_create",
                  "tvz_corpus_upload", "tvz_corpus_upsert", "tvz_match", "tvz_find_duplicates",
-                 "tvz_topk", "tvz_last_error", "tvz_version"):
+                 "tvz_topk", "tvz_last_error", "tvz_version", "tvz_scene_state_bytes",
+                 "tvz_scene_state_reset", "tvz_match_topk", "tvz_match_workspace_bytes",
+                 "tvz_corpus_reserve", "tvz_comm_unique_id", "tvz_comm_init", "tvz_match_sharded"):
         assert must in names
 
 
@@ -28,9 +30,26 @@ def test_library_builds_loads_and_exports_every_symbol():
     for name in _declared():
         assert hasattr(lib, name), f"{name} declared in tvz.h but not exported"
         assert name in _lib.SIGNATURES, f"{name} has no ctypes signature"
-    assert lib.tvz_version() == 100
+    assert lib.tvz_version() == 200
     assert lib.tvz_scene_workspace_bytes(10000, 1080, 1920) > 0
     assert lib.tvz_scene_workspace_bytes(-1, 1080, 1920) == 0
+    assert lib.tvz_scene_state_bytes(1080, 1920, 1) >= 2 * 1080 * 1920
+    assert lib.tvz_scene_state_bytes(1080, 1920, 3) == 0
+    # workspace sizes are pure arithmetic: hash-join tables only (k = 0) < with hit lists + top-k
+    a = lib.tvz_match_workspace_bytes(1024, 260, 0, 0, 1)
+    b = lib.tvz_match_workspace_bytes(1024, 260, 16384, 16, 8)
+    assert 0 < a < b and b - a >= 1024 * 16384 * 12
+
+
+def test_no_process_global_tuning_knobs():
+    """Kernel-shape / algorithm choices are per-call arguments: the library exports
+    no *_set_tuning entry point and no mutable global."""
+    import subprocess
+    from tvidz_amd import _lib
+    out = subprocess.check_output(["nm", "-D", "--defined-only", _lib.SO_PATH], text=True)
+    names = [l.split()[-1] for l in out.splitlines() if l.strip()]
+    assert not [n for n in names if "set_tuning" in n or n.startswith("g_")], names
+    assert all(n.startswith("tvz_") for n in names if not n.startswith("_")), names
 
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):
@@ -79,9 +98,15 @@ def test_entry_points_fail_gracefully_without_a_gpu():
         _lib.check(rc)
     # pure argument validation (no HIP call is reached)
     assert lib.tvz_luma_sad_u8(None, 4, 32, 32, 1024, 32, None, None, 0, None) != 0
-    assert lib.tvz_scene_select(None, 4, 32, 32, 8, 0.3, 0.0, 0, None, None, None, None) != 0
+    assert lib.tvz_scene_select(None, 4, 32, 32, 8, 0.3, None, None, None, None, None) != 0
+    assert lib.tvz_scene_scores_u8(None, 4, 32, 32, 1024, 32, None, 8, 0.3, None, None, None, None,
+                                   None, 0, None, 0, 0, None) != 0
+    assert lib.tvz_scene_state_reset(None, None) != 0
     assert lib.tvz_topk(None, None, 1, 4, 8, 0, None, None) != 0          # k out of range
-    assert lib.tvz_match(None, None, None, 1, 1, 1, None, 1, None, None, None) != 0
+    assert lib.tvz_match(None, None, None, 1, 1, 1, None, 1, None, None, None, 0, 0, None) != 0
+    assert lib.tvz_match_topk(None, None, None, 1, 1, 1, None, 1, 4, None, None, 0, 0, None) != 0
+    assert lib.tvz_match_sharded(None, None, None, None, 1, 1, 1, None, 1, 4, None, None, None, 0, 0, None) != 0
+    assert lib.tvz_corpus_reserve(None, 1, 1) != 0
     from tvidz_amd import scene
     with pytest.raises(RuntimeError):
         scene.SceneScorer(32, 32, 4, "cpu")

@@ -1,0 +1,223 @@
+"""BASELINE.json configs[4] on one GPU: 64 CONCURRENT 4K (2160x3840) uploads through the Flask
+`/notify` + SSE surface (inspector/app.py:31-44, 64-115), GPU scene-cut scoring + corpus match,
+duplicate verdicts streamed - every record checked against the oracle's replay of the reference
+loop (app.py:228-255, oracle.streaming_verdict_py).
+
+Frames come from an in-memory synthetic reader through the `frame_source` hook (no 50 GB of Y4M on
+disk; the decode leg has its own tests).  Every upload is a distinct procedural 4K clip with its
+own presentation-time offset, so timestamps of different videos never collide and the expected
+verdict of each upload does not depend on how the 64 threads interleave:
+  * 40 unique videos                       -> all cuts reported, no duplicate
+  * 16 copies of 6 LIBRARY videos (ingested before the burst) -> flagged at their 2nd cut
+  *  4 twin pairs uploaded in the same burst: whichever persists first is the other's duplicate
+     (the reference has the same race, app.py:234-238) -> only `duplicates subset-of {twin}` is fixed
+  * then 4 re-uploads of burst videos      -> flagged
+"""
+import json
+import threading
+
+import numpy as np
+import pytest
+
+from oracle import oracle
+from tvidz_amd import db as tdb
+from tvidz_amd import inspector as insp
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+H, W, T = 2160, 3840, 20
+LEVELS = [40, 130, 220, 85, 175, 30, 120, 210]
+_NOISE = None
+
+
+def _noise():
+    global _NOISE
+    if _NOISE is None:
+        _NOISE = np.random.default_rng(4).integers(0, 4, size=(H, W), dtype=np.uint8)
+    return _NOISE
+
+
+def _frame(cuts, t, out):
+    """Flat scenes (level changes by >= 45 at every cut) + a per-frame 2-bit noise pattern."""
+    level = LEVELS[sum(1 for c in cuts if c <= t) % len(LEVELS)]
+    np.add(_noise(), t & 3, out=out)
+    np.bitwise_and(out, 3, out=out)
+    out += level
+
+
+class SynthReader:
+    """What frame_source returns: the reader protocol of tvidz_amd.feeder (H, W, time_base,
+    total_frames, bitdepth, read_into, pts_of, close)."""
+
+    def __init__(self, cuts, pts0):
+        self.cuts, self.pts0 = list(cuts), int(pts0)
+        self.H, self.W, self.time_base, self.total_frames, self.bitdepth = H, W, (1, 30), T, 8
+        self.t = 0
+        self.closed = False
+
+    def read_into(self, out):
+        n = 0
+        while n < out.shape[0] and self.t < T and not self.closed:
+            _frame(self.cuts, self.t, out[n])
+            self.t += 1
+            n += 1
+        return n
+
+    def pts_of(self, n):
+        return self.pts0 + n
+
+    def close(self):
+        self.closed = True
+
+
+def _expected_cut_times(cuts, pts0):
+    frames = np.empty((T, H, W), dtype=np.uint8)
+    for t in range(T):
+        _frame(cuts, t, frames[t])
+    sad = oracle.luma_sad(frames)
+    sel, _, _, _ = oracle.scene_select(sad, H, W, 0.3)
+    idx = np.flatnonzero(sel).tolist()
+    assert idx == list(cuts), (idx, cuts)          # the generator's cuts are what the filter selects
+    return [oracle.pts_time_value(pts0 + i, 1, 30, 0) for i in idx]
+
+
+def _cut_sets(n, rng):
+    out = []
+    while len(out) < n:
+        k = int(rng.integers(3, 6))
+        c = sorted(rng.choice(np.arange(2, T - 1), size=k, replace=False).tolist())
+        if all(b - a >= 2 for a, b in zip(c, c[1:])) and c not in out:   # no back-to-back cuts
+            out.append(c)
+    return out
+
+
+def _sse_last(client, key):
+    body = client.get(f"/status/stream/{key}").get_data(as_text=True)
+    events = [json.loads(l[6:]) for l in body.split("\n\n") if l.startswith("data: ")]
+    assert events and events[-1]["status"] in ("done", "error"), events[-1:]
+    return events
+
+
+def test_64_concurrent_4k_uploads_through_notify_and_sse(tmp_path):
+    rng = np.random.default_rng(2026)
+    n_lib, n_uniq, n_copy, n_twin = 6, 40, 16, 4
+    sets = _cut_sets(n_lib + n_uniq + n_twin, rng)
+    videos = {}                                                     # key -> (cuts, pts0)
+
+    def add(key, cuts, pts0):
+        videos[key] = (cuts, pts0)
+    lib_keys = []
+    for i in range(n_lib):
+        k = f"1700000{i:03d}-lib{i}.mp4"
+        add(k, sets[i], 1000 * (i + 1))
+        lib_keys.append(k)
+    burst = []
+    for i in range(n_uniq):
+        k = f"1700001{i:03d}-uniq{i}.mp4"
+        add(k, sets[n_lib + i], 1000 * (n_lib + 1 + i))
+        burst.append(k)
+    copy_of = {}
+    for i in range(n_copy):
+        src = lib_keys[i % n_lib]
+        k = f"1700002{i:03d}-copy{i}.mp4"
+        add(k, *videos[src])
+        copy_of[k] = src
+        burst.append(k)
+    twins = []
+    for i in range(n_twin):
+        cuts, pts0 = sets[n_lib + n_uniq + i], 1000 * (n_lib + n_uniq + 1 + i)
+        a, b = f"1700003{i:03d}-twin{i}a.mp4", f"1700003{i:03d}-twin{i}b.mp4"
+        add(a, cuts, pts0)
+        add(b, cuts, pts0)
+        twins.append((a, b))
+        burst += [a, b]
+    assert len(burst) == 64
+    order = rng.permutation(len(burst)).tolist()
+    burst = [burst[i] for i in order]
+    expected = {k: _expected_cut_times(c, p) for k, (c, p) in videos.items() if k not in copy_of}
+    for k, src in copy_of.items():
+        expected[k] = expected[src]
+
+    store = tdb.Store(f"sqlite:///{tmp_path}/tvidz.db", device=0)
+    ins = insp.Inspector(store, device=DEV, max_workers=64,
+                         frame_source=lambda bucket, key, filename, uid: (SynthReader(*videos[key]), None))
+    app = insp.create_app(ins, sse_period=0.01)
+    client = app.test_client()
+
+    def notify(key):
+        ev = {"Records": [{"s3": {"bucket": {"name": "videos"}, "object": {"key": key}}}]}
+        r = client.post("/notify", json=ev)
+        assert r.status_code == 200 and r.get_json() == {"status": "Analysis started", "file": key}
+    try:
+        clean = {k: insp.split_filenames(k)[1] for k in videos}
+        # ---- the library, one after the other ----
+        for k in lib_keys:
+            notify(k)
+            last = _sse_last(client, k)[-1]
+            assert last["status"] == "done" and last["scene_cuts"] == expected[k] and last["duplicates"] == []
+        lib_rows = [(i + 1, expected[k]) for i, k in enumerate(lib_keys)]
+        lib_name = {i + 1: clean[k] for i, k in enumerate(lib_keys)}
+        # ---- the burst: 64 notifications back to back, then 64 SSE streams ----
+        for k in burst:
+            notify(k)
+        results, errs = {}, []
+
+        def follow(k):
+            try:
+                results[k] = _sse_last(app.test_client(), k)
+            except Exception as e:  # pragma: no cover
+                errs.append((k, e))
+        th = [threading.Thread(target=follow, args=(k,)) for k in burst]
+        [t.start() for t in th]
+        [t.join(600) for t in th]
+        assert not errs, errs
+        twin_of = {}
+        for a, b in twins:
+            twin_of[a], twin_of[b] = b, a
+        for k in burst:
+            events = results[k]
+            last = events[-1]
+            assert last["status"] == "done", last
+            assert last["original_filename"] == k and last["clean_filename"] == clean[k]
+            assert last == client.get(f"/status/{k}").get_json()                   # SSE == REST record
+            seq = "".join(e["status"][0] for e in events)                          # p* a* d
+            assert seq.lstrip("p").lstrip("a") == "d", seq
+            if k in twin_of:
+                assert set(last["duplicates"]) <= {clean[twin_of[k]]}
+                n = len(last["scene_cuts"])
+                assert last["scene_cuts"] == expected[k][:n] and (n == len(expected[k]) or last["duplicates"])
+                continue
+            # the reference loop replayed by the oracle over the library (other burst videos share
+            # no timestamp with this one, so they cannot change its verdict)
+            corpus = [(vid, list(ts)) for vid, ts in lib_rows]
+            exp_ts, exp_dups = oracle.streaming_verdict_py(expected[k], corpus, 10 ** 6, 2)
+            assert last["scene_cuts"] == exp_ts, k
+            assert sorted(last["duplicates"]) == sorted(lib_name[d] for d in exp_dups), k
+            assert last["total_cuts"] == len(exp_ts) and last["progress"] == 1.0
+            if k in copy_of:
+                assert last["duplicates"] == [clean[copy_of[k]]] and len(exp_ts) == 2
+            else:
+                assert last["duplicates"] == [] and exp_ts == expected[k]
+        # ---- persisted rows: every video's stored fingerprint is what its record reported ----
+        by_name = {}
+        for v in store.list_videos():
+            by_name.setdefault(v["filename"], []).append(v)
+        for k in burst:
+            if k in twin_of:
+                continue
+            rows = [v for v in by_name[clean[k]]]
+            assert len(rows) == 1 and rows[0]["timestamps"] == results[k][-1]["scene_cuts"]
+            if k in copy_of:
+                src = [v for v in by_name[clean[copy_of[k]]]][0]
+                assert rows[0]["duplicates"] == [src["id"]]
+        # ---- re-uploads of burst videos are now duplicates (deterministic again) ----
+        for i, k0 in enumerate([k for k in burst if k.split("-")[1].startswith("uniq")][:4]):
+            k = f"1700009{i:03d}-again{i}.mp4"
+            videos[k] = videos[k0]
+            notify(k)
+            last = _sse_last(client, k)[-1]
+            assert last["status"] == "done" and last["duplicates"] == [clean[k0]]
+            assert last["scene_cuts"] == expected[k0][:2]
+    finally:
+        ins.close()
+        store.close()

@@ -36,7 +36,6 @@ def test_config1_10k_1080p_frames():
     for s0 in range(0, T, 1000):
         part = frames[s0:s0 + 1000]
         _, _, _, s_ = sc2.score_batch(part)
-        sc2.remember_tail(part)
         parts.append(s_.cpu().numpy().copy())
     assert (np.concatenate(parts) == sel_h).all()
     # (4) the cuts are scene boundaries of the generator (or its adversarial flash), and isolated
@@ -54,18 +53,20 @@ def test_config3_100k_corpus_both_kernels_and_oracle():
     queries = synth.synth_queries(ids, offs, keys, Q, seed=synth.CORPUS_SEED + 1)
     dc = tc.DeviceCorpus(0)
     dc.upload_csr(ids, offs, keys)
-    lib = _lib.load()
     d_q, d_off, max_len = tc.pack_queries(queries, DEV)
     res = {}
-    try:
-        for mode in (0, 2):                               # LDS tile kernel, hash join
-            _lib.check(lib.tvz_match_set_tuning(mode))
-            hits, n = dc.match(d_q, d_off, max_len, 2, CAP)
-            torch.cuda.synchronize()
-            res[mode] = (hits.cpu().numpy(), n.cpu().numpy())
-    finally:
-        _lib.check(lib.tvz_match_set_tuning(1))
+    for mode, algo in ((0, _lib.ALGO_TILE), (2, _lib.ALGO_JOIN)):     # LDS tile kernel, hash join
+        hits, n = dc.match(d_q, d_off, max_len, 2, CAP, algo=algo)
+        torch.cuda.synchronize()
+        res[mode] = (hits.cpu().numpy(), n.cpu().numpy())
     assert (res[0][1] == res[2][1]).all(), np.flatnonzero(res[0][1] != res[2][1])[:8]
+    # the per-query sweep on a few of the queries: same hit sets
+    d_q8, d_off8, ml8 = tc.pack_queries(queries[:8], DEV)
+    h8, n8 = dc.match(d_q8, d_off8, ml8, 2, CAP, algo=_lib.ALGO_Q1)
+    torch.cuda.synchronize()
+    h8, n8 = h8.cpu().numpy(), n8.cpu().numpy()
+    for qi in range(8):
+        assert sorted(map(tuple, h8[qi, :n8[qi]].tolist())) == sorted(map(tuple, res[0][0][qi, :res[0][1][qi]].tolist())), qi
     assert (res[0][1] <= CAP).all(), int(res[0][1].max())
     for qi in range(Q):
         a = sorted(map(tuple, res[0][0][qi, :res[0][1][qi]].tolist()))

@@ -82,12 +82,12 @@ def test_golden_streaming_verdicts(dc, golden_dir):
         assert pref == [tuple(e) for e in case["dups"]]
 
 
-def _check_batch(dc, ids, offs, keys, queries, min_match, excl=None, cap=None):
+def _check_batch(dc, ids, offs, keys, queries, min_match, excl=None, cap=None, algo=_lib.ALGO_AUTO):
     d_q, d_off, max_len = tc.pack_queries(queries, DEV)
     C = len(ids)
     cap = cap or max(C, 1)
     d_ex = torch.tensor(excl, dtype=torch.int32, device=DEV) if excl is not None else None
-    hits, n = dc.match(d_q, d_off, max_len, min_match, cap, d_exclude_ids=d_ex)
+    hits, n = dc.match(d_q, d_off, max_len, min_match, cap, d_exclude_ids=d_ex, algo=algo)
     torch.cuda.synchronize()
     hits, n = hits.cpu().numpy(), n.cpu().numpy()
     for qi, q in enumerate(queries):
@@ -116,6 +116,10 @@ def test_batched_match_vs_oracle(dc, C, mean_len, Q, mm):
     _check_batch(dc, ids, offs, keys, queries, mm)
     excl = [int(ids[(7 * i) % C]) for i in range(Q)]
     _check_batch(dc, ids, offs, keys, queries, mm, excl=excl)
+    # every sweep kernel gives the same hits (the per-call `algo` never changes results)
+    for algo in (_lib.ALGO_Q1, _lib.ALGO_TILE, _lib.ALGO_JOIN):
+        _check_batch(dc, ids, offs, keys, queries, mm, excl=excl, algo=algo)
+        _check_batch(dc, ids, offs, keys, queries[:1], mm, algo=algo)
 
 
 def test_ragged_rows_and_long_queries(dc):
@@ -129,6 +133,8 @@ def test_ragged_rows_and_long_queries(dc):
     queries = [np.round(rng.uniform(0, 500, n), 2) for n in (1, 16, 17, 300, 1500, 4095)]
     for mm in (1, 2, 4, 5, 6, 9):
         _check_batch(dc, ids, offs, keys, queries, mm)
+        _check_batch(dc, ids, offs, keys, queries, mm, algo=_lib.ALGO_Q1)
+        _check_batch(dc, ids, offs, keys, queries, mm, algo=_lib.ALGO_TILE)
 
 
 def test_queries_longer_than_a_tile(dc):
@@ -331,6 +337,11 @@ def test_property_random_small_corpora_special_values(dc):
         for mm in (-1, 0, 1, 2, 3, 5, 6, 7):
             excl = [int(rng.integers(1, 15)) for _ in range(Q)] if trial % 2 else None
             _check_batch(dc, ids, offs, keys, queries, mm, excl=excl)
+            _check_batch(dc, ids, offs, keys, queries, mm, excl=excl,
+                         algo=(_lib.ALGO_Q1, _lib.ALGO_TILE, _lib.ALGO_JOIN)[trial % 3])
+            for q0 in queries[:3]:          # the one-launch host path, every min_match
+                exp = sorted(h for h in oracle.find_duplicates_c(rows, q0.tolist(), mm))
+                assert dc.find_duplicates(q0, mm) == exp, (trial, mm)
         q0 = queries[0]
         assert dc.find_duplicates(q0, 1) == sorted(oracle.find_duplicates_c(rows, q0.tolist(), 1))
 
@@ -381,7 +392,7 @@ def test_wrong_max_query_len_is_flagged_not_truncated(dc):
     dc.upload([(1, [1.0, 2.0, 3.0])])
     queries = [np.arange(300, dtype=np.float64)] * 16           # 4800 entries for one 16-query tile
     d_q, d_off, max_len = tc.pack_queries(queries, DEV)
-    hits, n = dc.match(d_q, d_off, 200, 1, 8)                    # lying about the bound
+    hits, n = dc.match(d_q, d_off, 200, 1, 8, algo=_lib.ALGO_TILE)   # lying about the bound
     torch.cuda.synchronize()
     assert (n.cpu().numpy() == np.iinfo(np.int32).min).all()
     hits, n = dc.match(d_q, d_off, max_len, 1, 8)                # honest bound: correct answer
@@ -393,8 +404,7 @@ def test_wrong_max_query_len_is_flagged_not_truncated(dc):
                                              (2500, 40, 257, 2), (64, 12, 33, 0)])
 def test_hash_join_path_vs_oracle_and_tile_kernel(dc, C, mean_len, Q, mm):
     """Q >= 32 with min_match <= 2 takes the hash-join kernels; same hits as the oracle and as the
-    LDS tile kernel (forced through the tuning knob)."""
-    lib = _lib.load()
+    LDS tile kernel (both forced through the per-call `algo`)."""
     ids, offs, keys = synth.synth_timestamp_corpus(C, seed=C + Q, mean_len=mean_len, dup_frac=0.05,
                                                    frag_frac=0.05)
     dc.upload_csr(ids, offs, keys)
@@ -403,32 +413,36 @@ def test_hash_join_path_vs_oracle_and_tile_kernel(dc, C, mean_len, Q, mm):
     queries[3] = np.zeros(0)
     queries[5] = queries[4].copy()                                   # the same video twice in a batch
     excl = [int(ids[(11 * i) % C]) for i in range(Q)]
-    try:
-        _lib.check(lib.tvz_match_set_tuning(2))                     # hash join whenever legal
-        h1, n1 = _check_batch(dc, ids, offs, keys, queries, mm, excl=excl)
-        _check_batch(dc, ids, offs, keys, queries, mm, cap=7)        # overflow: true counts kept
-        _lib.check(lib.tvz_match_set_tuning(0))
-        h0, n0 = _check_batch(dc, ids, offs, keys, queries, mm, excl=excl)
-        assert (n0 == n1).all()
-    finally:
-        _lib.check(lib.tvz_match_set_tuning(1))
+    h1, n1 = _check_batch(dc, ids, offs, keys, queries, mm, excl=excl, algo=_lib.ALGO_JOIN)
+    _check_batch(dc, ids, offs, keys, queries, mm, cap=7, algo=_lib.ALGO_JOIN)   # overflow: true counts kept
+    h0, n0 = _check_batch(dc, ids, offs, keys, queries, mm, excl=excl, algo=_lib.ALGO_TILE)
+    assert (n0 == n1).all()
 
 
-def test_hash_join_flags_wrong_bound(dc):
-    lib = _lib.load()
+def test_hash_join_and_q1_flag_wrong_bound(dc):
     dc.upload([(1, [1.0, 2.0, 3.0])])
     queries = [np.arange(50, dtype=np.float64)] * 40
     d_q, d_off, max_len = tc.pack_queries(queries, DEV)
-    try:
-        _lib.check(lib.tvz_match_set_tuning(2))
-        hits, n = dc.match(d_q, d_off, 20, 1, 8)
-        torch.cuda.synchronize()
-        assert (n.cpu().numpy() < 0).all()
-        hits, n = dc.match(d_q, d_off, max_len, 1, 8)
-        torch.cuda.synchronize()
-        assert (n.cpu().numpy() == 1).all() and (hits[:, 0, 1].cpu().numpy() == 3).all()
-    finally:
-        _lib.check(lib.tvz_match_set_tuning(1))
+    hits, n = dc.match(d_q, d_off, 20, 1, 8, algo=_lib.ALGO_JOIN)
+    torch.cuda.synchronize()
+    assert (n.cpu().numpy() < 0).all()
+    hits, n = dc.match(d_q, d_off, max_len, 1, 8, algo=_lib.ALGO_JOIN)
+    torch.cuda.synchronize()
+    assert (n.cpu().numpy() == 1).all() and (hits[:, 0, 1].cpu().numpy() == 3).all()
+    # the per-query sweep sizes its LDS table from max_query_len: a 2000-key query against a
+    # table sized for 20 keys is flagged, not truncated
+    big = [np.arange(2000, dtype=np.float64)] * 2
+    d_q, d_off, max_len = tc.pack_queries(big, DEV)
+    hits, n = dc.match(d_q, d_off, 20, 1, 8, algo=_lib.ALGO_Q1)
+    torch.cuda.synchronize()
+    assert (n.cpu().numpy() == np.iinfo(np.int32).min).all()
+    hits, n = dc.match(d_q, d_off, max_len, 1, 8, algo=_lib.ALGO_Q1)
+    torch.cuda.synchronize()
+    assert (n.cpu().numpy() == 1).all() and (hits[:, 0, 1].cpu().numpy() == 3).all()
+    # the join without its tables is refused loudly when asked for explicitly
+    small_ws = torch.empty(1024, dtype=torch.uint8, device=DEV)
+    with pytest.raises(RuntimeError, match="workspace"):
+        dc.match(d_q, d_off, max_len, 1, 8, algo=_lib.ALGO_JOIN, workspace=small_ws)
 
 
 def test_shard_overflow_is_signalled_by_negative_totals(dc):
@@ -444,3 +458,116 @@ def test_shard_overflow_is_signalled_by_negative_totals(dc):
     hits, n = dc.match(d_q, d_off, max_len, 0, cap=600)         # enough room: positive again
     merged, totals = tc.topk_merge(tc.topk_shard(hits, n, 8).unsqueeze(0).contiguous(), 8)
     assert totals.cpu().tolist() == [600, 600]
+
+
+def test_match_topk_one_call_equals_match_then_topk(dc):
+    """tvz_match_topk (sweep + histogram-select top-k behind one call, hit lists in the caller's
+    workspace) == tvz_match followed by tvz_topk_shard == the oracle's ordering, for every kernel,
+    for long lists (kth histogram path), ties inside one kth bin, and overflowing capacities."""
+    C, Q, mm = 6000, 24, 1
+    rng = np.random.default_rng(21)
+    grid = np.arange(1, 2001) / 8.0                       # a small alphabet: thousands of hits per query
+    rows = []
+    for c in range(C):
+        r = rng.choice(grid, size=int(rng.integers(5, 40)), replace=False)
+        if rng.random() < 0.5:
+            r = np.append(r, 777.125)                      # half the rows share one key: a huge kth tie
+        rows.append((c + 1, r.tolist()))
+    dc.upload(rows)
+    ids, offs, keys = tc.rows_to_csr(rows)
+    queries = [rng.choice(grid, size=int(rng.integers(20, 160)), replace=False) for _ in range(Q)]
+    queries[1] = np.array([777.125] * 3)                  # every hit has kth == 0: ~3000 ties in one bin
+    queries[2] = np.zeros(0)
+    d_q, d_off, max_len = tc.pack_queries(queries, DEV)
+    excl = torch.tensor([int(ids[(5 * i) % C]) for i in range(Q)], dtype=torch.int32, device=DEV)
+    exp_rows = []
+    for qi, q in enumerate(queries):
+        cnt, kth = oracle.match_kth_csr(q, offs, keys, mm)
+        exp_rows.append([(int(ids[c]), int(cnt[c]), int(kth[c])) for c in range(C)
+                         if cnt[c] >= mm and ids[c] != int(excl[qi])])
+    assert len(exp_rows[1]) > 2500 and len({r[2] for r in exp_rows[1]}) == 1
+    assert max(len(r) for r in exp_rows) > 1500          # long enough for the histogram path
+    for algo in (_lib.ALGO_AUTO, _lib.ALGO_Q1, _lib.ALGO_TILE, _lib.ALGO_JOIN):
+        for k, cap in ((16, C), (1, C), (64, C), (16, 300)):
+            ws = torch.empty(tc.workspace_bytes(Q, max_len, cap, k), dtype=torch.uint8, device=DEV)
+            out = dc.match_topk(d_q, d_off, max_len, mm, cap, k, d_exclude_ids=excl, workspace=ws, algo=algo)
+            torch.cuda.synchronize()
+            out = out.cpu().numpy()
+            for qi in range(Q):
+                rows = exp_rows[qi]
+                tot = int(out[qi, k, 1])
+                assert tuple(out[qi, k][[0, 2]]) == (-1, NEVER)
+                if len(rows) <= cap:
+                    assert tot == len(rows)
+                    exp = sorted(rows, key=lambda h: (h[2], h[0], h[1]))[:k]
+                    exp += [(-1, 0, NEVER)] * (k - len(exp))
+                    assert [tuple(int(x) for x in r) for r in out[qi, :k]] == exp, (algo, k, cap, qi)
+                else:
+                    assert tot == -len(rows)             # overflow is signalled, entries are real hits
+                    got = [tuple(int(x) for x in r) for r in out[qi, :k] if r[0] >= 0]
+                    assert set(got) <= set(rows) and len(got) == min(k, cap)
+    with pytest.raises(RuntimeError, match="workspace"):
+        dc.match_topk(d_q, d_off, max_len, mm, C, 16, workspace=torch.empty(4096, dtype=torch.uint8, device=DEV))
+
+
+def test_two_threads_run_hash_joins_concurrently(dc):
+    """two callers on different streams used to be handed the same hash-join
+    tables.  Scratch is now the caller's workspace: concurrent join batches stay exact."""
+    import threading
+    C, Q = 3000, 96
+    ids, offs, keys = synth.synth_timestamp_corpus(C, seed=5, mean_len=60, dup_frac=0.05)
+    dc.upload_csr(ids, offs, keys)
+    sets = [synth.synth_queries(ids, offs, keys, Q, seed=100 + t, mean_len=60) for t in range(2)]
+    exp = []
+    for qs in sets:
+        e = []
+        for q in qs:
+            cnt, kth = oracle.match_kth_csr(q, offs, keys, 2)
+            e.append(sorted((int(ids[c]), int(cnt[c]), int(kth[c])) for c in range(C) if cnt[c] >= 2))
+        exp.append(e)
+    errs = []
+
+    def work(t):
+        try:
+            st = torch.cuda.Stream()
+            d_q, d_off, max_len = tc.pack_queries(sets[t], DEV)
+            ws = torch.empty(tc.workspace_bytes(Q, max_len), dtype=torch.uint8, device=DEV)
+            hits = torch.empty((Q, C, 3), dtype=torch.int32, device=DEV)
+            n = torch.empty(Q, dtype=torch.int32, device=DEV)
+            torch.cuda.synchronize()
+            for _ in range(25):
+                dc.match(d_q, d_off, max_len, 2, C, out_hits=hits, out_n=n, stream=st, workspace=ws,
+                         algo=_lib.ALGO_JOIN)
+                st.synchronize()
+                hh, nn = hits.cpu().numpy(), n.cpu().numpy()
+                for qi in range(Q):
+                    assert sorted(map(tuple, hh[qi, :nn[qi]].tolist())) == exp[t][qi], (t, qi)
+        except Exception as e:  # pragma: no cover
+            errs.append(e)
+    th = [threading.Thread(target=work, args=(t,)) for t in range(2)]
+    [t.start() for t in th]; [t.join() for t in th]
+    assert not errs, errs
+
+
+def test_upsert_is_stream_ordered_and_read_your_writes(dc):
+    """tvz_corpus_upsert returns without draining matches in flight; a match enqueued after it
+    (any stream) sees the new row; negative video ids are refused (they mark padding)."""
+    ids, offs, keys = synth.synth_timestamp_corpus(4000, seed=12, mean_len=80)
+    dc.upload_csr(ids, offs, keys)
+    d_q, d_off, max_len = tc.pack_queries([np.arange(50) * 0.25 + 9e5], DEV)
+    st = torch.cuda.Stream()
+    prefix = []
+    for i in range(60):
+        prefix.append(9e5 + 0.25 * i)
+        dc.upsert(777777, prefix)
+        got = dc.find_duplicates(prefix, 1)
+        assert got == [(777777, len(prefix))], i
+        hits, n = dc.match(d_q, d_off, max_len, 1, 16, stream=st)       # a user stream: also ordered
+        st.synchronize()
+        assert int(n[0]) == 1 and hits[0, 0].tolist() == [777777, min(len(prefix), 50), 0]
+    with pytest.raises(RuntimeError, match="negative video_id"):
+        dc.upsert(-5, [1.0])
+    with pytest.raises(RuntimeError, match="negative video_id"):
+        dc.upload([(-1, [1.0])])
+    dc.reserve(50000, 4000000)                                           # explicit pre-sizing
+    assert dc.find_duplicates(prefix[:3], 3) == [(777777, 3)]

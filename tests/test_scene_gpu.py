@@ -85,6 +85,15 @@ def test_empty_and_single_frame_batches():
     sad, mafd, score, sel = sc.score_batch(one, carry=False)
     torch.cuda.synchronize()
     assert sad.item() == 0 and score.item() == 0.0 and sel.item() == 0
+    # one-frame batches through the carried state: frame by frame == the whole stream
+    frames = torch.randint(0, 256, (5, 32, 32), dtype=torch.uint8, device=DEV)
+    frames[3:] //= 8
+    o_sad, o_sel, o_score, _ = _oracle_all(frames.cpu().numpy())
+    sc.reset()
+    for t in range(5):
+        sad, mafd, score, sel = sc.score_batch(frames[t:t + 1])
+        assert sc.fetch_cuts() == ([0] if o_sel[t] else [])
+        assert int(sad.item()) == int(o_sad[t]) and score.item() == o_score[t]
 
 
 def test_synthetic_scenes_cuts_match_oracle_and_layout():
@@ -112,7 +121,6 @@ def test_streaming_batches_equal_whole_stream():
     for s in range(0, T, 50):   # batches that are not multiples of the kernel's time chunk
         part = frames[s:s + 50]
         sad, mafd, score, sel = sc.score_batch(part)
-        sc.remember_tail(part)
         sads.append(sad.cpu().numpy().view(np.uint64).copy()); sels.append(sel.cpu().numpy().copy())
         scores.append(score.cpu().numpy().copy())
     assert (np.concatenate(sads) == whole[0]).all()
@@ -144,22 +152,73 @@ def test_standalone_sad_and_select_entry_points():
     assert (sad.cpu().numpy().view(np.uint64) == o_sad).all()
     assert (sel.cpu().numpy() == o_sel).all() and (score.cpu().numpy() == o_score).all()
     assert (mafd.cpu().numpy() == o_mafd).all()
+    # continuing a stream: the predecessor's mafd is read from DEVICE memory (no by-value carry)
+    sad_all = torch.from_numpy(o_sad.view(np.int64)).to(DEV)
+    sel2, score2, _ = scene.scene_select(sad_all[20:].contiguous(), H, W, 0.3, prev_mafd=mafd[19:20].clone())
+    torch.cuda.synchronize()
+    assert (sel2.cpu().numpy() == o_sel[20:]).all() and (score2.cpu().numpy() == o_score[20:]).all()
 
 
-def test_tuning_variants_give_identical_results():
-    lib = _lib.load()
+def test_shape_variants_give_identical_results():
+    """The kernel shape is a per-call argument (no global knob): every shape, same bits - also
+    when the batch continues a stream through the device-resident state."""
     T, H, W = 150, 270, 480
     frames = torch.randint(0, 256, (T, H, W), dtype=torch.uint8, device=DEV)
-    o_sad, _, _, _ = _oracle_all(frames.cpu().numpy())
-    try:
-        for U in (1, 2, 4, 8):
-            for tc in (64, 128, 256):
-                for nt in (0, 1):
-                    _lib.check(lib.tvz_scene_set_tuning(U, tc, nt))
-                    sad, _, _, _ = _gpu_all(frames)
-                    assert (sad == o_sad).all(), (U, tc, nt)
-    finally:
-        _lib.check(lib.tvz_scene_set_tuning(0, 0, 1))
+    frames[70:] //= 3
+    o_sad, o_sel, _, _ = _oracle_all(frames.cpu().numpy())
+    sc = scene.SceneScorer(H, W, T, DEV)
+    for U in (1, 2, 4, 8):
+        for tc in (8, 64, 128, 256):
+            for nt in (False, True):
+                sad, _, _, sel = sc.score_batch(frames, carry=False, shape=_lib.shape(U, tc, nt))
+                assert (sad.cpu().numpy().view(np.uint64) == o_sad).all(), (U, tc, nt)
+                sc.reset()
+                sc.score_batch(frames[:61], shape=_lib.shape(U, tc, nt))
+                head = sc.fetch_cuts()
+                sc.score_batch(frames[61:], shape=_lib.shape(U, tc, nt))
+                got = head + [61 + i for i in sc.fetch_cuts()]
+                assert got == np.flatnonzero(o_sel).tolist(), (U, tc, nt)
+    with pytest.raises(RuntimeError, match="shape"):
+        sc.score_batch(frames, carry=False, shape=_lib.shape(3, 64))
+
+
+def test_chained_batches_in_one_hip_graph_equal_the_whole_stream():
+    """the carried state (previous frame, previous mafd) lives on the device, so a
+    chain of micro-batches has no host round trip in it and is captured in ONE HIP graph; replaying
+    the graph on new frames equals the whole-stream oracle result."""
+    T, H, W, NB = 32, 270, 480, 4
+    sc = scene.SceneScorer(H, W, T, DEV)
+    static = torch.zeros((NB * T, H, W), dtype=torch.uint8, device=DEV)
+    cuts_out = torch.zeros((NB, 1 + sc.cuts_cap), dtype=torch.int32, device=DEV)
+    sel_out = torch.zeros((NB, T), dtype=torch.uint8, device=DEV)
+    g = torch.Generator(device=DEV); g.manual_seed(7)
+
+    def chain():
+        sc.reset()
+        for b in range(NB):
+            _, _, _, sel = sc.score_batch(static[b * T:(b + 1) * T])
+            cuts_out[b].copy_(sc.cuts)
+            sel_out[b].copy_(sel)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        chain()                                        # warm-up outside the capture
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        chain()
+    for trial in range(3):
+        frames, _ = synth.synth_luma(NB * T, H, W, device=DEV, seed=40 + trial, min_scene=9, max_scene=30)
+        static.copy_(frames)
+        graph.replay()
+        torch.cuda.synchronize()
+        _, o_sel, _, _ = _oracle_all(frames.cpu().numpy())
+        assert (sel_out.cpu().numpy().reshape(-1) == o_sel).all(), trial
+        got = []
+        ch = cuts_out.cpu().numpy()
+        for b in range(NB):
+            got += [b * T + int(i) for i in ch[b, 1:1 + ch[b, 0]]]
+        assert got == np.flatnonzero(o_sel).tolist() and len(got) >= 3
 
 
 def test_bad_arguments_raise():
@@ -210,7 +269,6 @@ def test_16bit_luma_matches_oracle(shape, bitdepth):
     for s0 in range(0, T, 4):
         part = d[s0:s0 + 4]
         _, _, _, s_ = sc2.score_batch(part)
-        sc2.remember_tail(part)
         sels.append(s_.cpu().numpy().copy())
     assert (np.concatenate(sels) == o_sel).all()
 
@@ -252,7 +310,6 @@ def test_fuzz_shapes_strides_chunking():
         for s0 in range(0, T, step):
             part = d_view[s0:s0 + step]
             sad, mafd, score, sel = sc.score_batch(part)
-            sc.remember_tail(part)
             sads.append(sad.cpu().numpy().view(np.uint64).copy())
             sels.append(sel.cpu().numpy().copy())
             scores.append(score.cpu().numpy().copy())

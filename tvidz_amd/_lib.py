@@ -14,50 +14,67 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(_HERE, "libtvz.so")
 
 KTH_NEVER = 0x7FFFFFFF
+VERSION = 200
 
 # name -> (restype, argtypes); mirrors include/tvz.h one to one
+_P = C.c_void_p
 SIGNATURES = {
     "tvz_version": (C.c_int, []),
     "tvz_last_error": (C.c_char_p, []),
     "tvz_scene_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int32, C.c_int32]),
-    "tvz_luma_sad_u8": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int64, C.c_int64,
-                                  C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
-    "tvz_scene_select": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32,
-                                   C.c_double, C.c_double, C.c_int32, C.c_void_p, C.c_void_p,
-                                   C.c_void_p, C.c_void_p]),
-    "tvz_scene_scores_u8": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int64,
-                                      C.c_int64, C.c_void_p, C.c_double, C.c_int32, C.c_double,
-                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
-                                      C.c_size_t, C.c_void_p]),
-    "tvz_scene_scores_u16": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int64,
-                                       C.c_int64, C.c_void_p, C.c_double, C.c_int32, C.c_double,
-                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
-                                       C.c_size_t, C.c_void_p]),
+    "tvz_scene_state_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
+    "tvz_scene_state_reset": (C.c_int, [_P, _P]),
+    "tvz_luma_sad_u8": (C.c_int, [_P, C.c_int64, C.c_int32, C.c_int32, C.c_int64, C.c_int64,
+                                  _P, _P, C.c_size_t, _P]),
+    "tvz_scene_select": (C.c_int, [_P, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_double, _P,
+                                   _P, _P, _P, _P]),
+    "tvz_scene_scores_u8": (C.c_int, [_P, C.c_int64, C.c_int32, C.c_int32, C.c_int64, C.c_int64, _P,
+                                      C.c_int32, C.c_double, _P, _P, _P, _P, _P, C.c_int32, _P,
+                                      C.c_size_t, C.c_uint32, _P]),
+    "tvz_scene_scores_u16": (C.c_int, [_P, C.c_int64, C.c_int32, C.c_int32, C.c_int64, C.c_int64, _P,
+                                       C.c_int32, C.c_double, _P, _P, _P, _P, _P, C.c_int32, _P,
+                                       C.c_size_t, C.c_uint32, _P]),
     "tvz_corpus_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int]),
-    "tvz_corpus_destroy": (C.c_int, [C.c_void_p]),
-    "tvz_corpus_upload": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
-                                    C.c_int64]),
-    "tvz_corpus_upsert": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64]),
-    "tvz_corpus_clear": (C.c_int, [C.c_void_p]),
-    "tvz_corpus_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64),
+    "tvz_corpus_destroy": (C.c_int, [_P]),
+    "tvz_corpus_reserve": (C.c_int, [_P, C.c_int64, C.c_int64]),
+    "tvz_corpus_upload": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_int64]),
+    "tvz_corpus_upsert": (C.c_int, [_P, C.c_int32, _P, C.c_int64]),
+    "tvz_corpus_clear": (C.c_int, [_P]),
+    "tvz_corpus_stats": (C.c_int, [_P, C.POINTER(C.c_int64), C.POINTER(C.c_int64),
                                    C.POINTER(C.c_int64)]),
-    "tvz_match": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
-                            C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
-    "tvz_find_duplicates": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32,
-                                      C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
+    "tvz_match_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
+    "tvz_match": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, C.c_int32, _P, C.c_int32, _P, _P, _P,
+                            C.c_size_t, C.c_int32, _P]),
+    "tvz_match_topk": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, C.c_int32, _P, C.c_int32, C.c_int32,
+                                 _P, _P, C.c_size_t, C.c_int32, _P]),
+    "tvz_find_duplicates": (C.c_int, [_P, _P, C.c_int64, C.c_int32, C.c_int32, C.c_int64, _P, _P, _P,
                                       C.POINTER(C.c_int64)]),
-    "tvz_topk": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
-                           C.c_void_p, C.c_void_p]),
-    "tvz_topk_shard": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
-                                 C.c_void_p]),
-    "tvz_topk_merge": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
-                                 C.c_void_p]),
-    "tvz_align": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_double, C.c_double, C.c_void_p,
-                            C.c_void_p]),
-    # not part of the stable ABI (kernel-shape A/B knob)
-    "tvz_scene_set_tuning": (C.c_int, [C.c_int, C.c_int, C.c_int]),
-    "tvz_match_set_tuning": (C.c_int, [C.c_int]),
+    "tvz_topk": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P]),
+    "tvz_topk_shard": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P]),
+    "tvz_topk_merge": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P]),
+    "tvz_comm_unique_id": (C.c_int, [_P]),
+    "tvz_comm_init": (C.c_int, [C.POINTER(C.c_void_p), _P, C.c_int32, C.c_int32, C.c_int32]),
+    "tvz_comm_info": (C.c_int, [_P, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "tvz_comm_destroy": (C.c_int, [_P]),
+    "tvz_match_sharded": (C.c_int, [_P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, _P, C.c_int32,
+                                    C.c_int32, _P, _P, _P, C.c_size_t, C.c_int32, _P]),
+    "tvz_align": (C.c_int, [_P, _P, C.c_int32, C.c_double, C.c_double, _P, _P]),
 }
+
+# per-call selectors of include/tvz.h
+ALGO_AUTO, ALGO_Q1, ALGO_TILE, ALGO_JOIN = 0, 1, 2, 3
+SHAPE_AUTO = 0
+SHAPE_NO_NT = 1 << 30
+UNIQUE_ID_BYTES = 128
+
+
+def shape(U: int = 0, tc: int = 0, nt: bool = True) -> int:
+    """TVZ_SHAPE(U, tc) [| TVZ_SHAPE_NO_NT]: per-call kernel-shape override of the scene kernels."""
+    s = (int(U) & 0xFF) | (int(tc) << 8)
+    if not nt:
+        s |= SHAPE_NO_NT
+    return s
+
 
 _lock = threading.Lock()
 _lib = None

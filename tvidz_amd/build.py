@@ -16,7 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(HERE, "..", "include")
 SO = os.path.join(HERE, "libtvz.so")
-SOURCES = ["tvz_api.hip", "tvz_scene.hip", "tvz_match.hip"]
+SOURCES = ["tvz_api.hip", "tvz_scene.hip", "tvz_match.hip", "tvz_comm.hip"]
 ARCH = "gfx950"
 
 
@@ -41,7 +41,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     cmd = [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared",
            "-fvisibility=hidden", "-Wall", "-Wno-unused-function", f"-I{INCLUDE}", f"-I{CSRC}",
            "-o", SO + ".tmp"] + os.environ.get("TVZ_CXXFLAGS", "").split() + \
-          [os.path.join(CSRC, s) for s in SOURCES]
+          [os.path.join(CSRC, s) for s in SOURCES] + ["-ldl"]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)

@@ -7,6 +7,7 @@ module only marshals arrays through the C ABI of include/tvz.h.
 from __future__ import annotations
 
 import ctypes as C
+import threading
 from typing import Iterable, Optional, Sequence, Tuple
 
 import numpy as np
@@ -35,6 +36,12 @@ def _ptr(a: Optional[np.ndarray]):
     return None if a is None or a.size == 0 else C.c_void_p(a.ctypes.data)
 
 
+def workspace_bytes(Q: int, max_query_len: int, cap: int = 0, k: int = 0, n_ranks: int = 1) -> int:
+    """tvz_match_workspace_bytes: scratch of the batched calls (k = 0: the hash-join tables only)."""
+    return int(_lib.load().tvz_match_workspace_bytes(int(Q), int(max_query_len), int(cap), int(k),
+                                                     int(n_ranks)))
+
+
 class DeviceCorpus:
     """tvz_corpus handle: rows of (video_id, sorted-unique canonical float64 keys) in HBM."""
 
@@ -44,6 +51,8 @@ class DeviceCorpus:
         h = C.c_void_p()
         _lib.check(self.lib.tvz_corpus_create(C.byref(h), self.device))
         self._h = h
+        self._row_bound = 0                 # upper bound on the row count (sizes the output arrays)
+        self._tls = threading.local()
 
     def close(self) -> None:
         if getattr(self, "_h", None):
@@ -57,6 +66,9 @@ class DeviceCorpus:
             pass
 
     # ---- mutation (db.py:43-64 add_timestamps; app.py:325-333 clear-db) ----
+    def reserve(self, n_rows: int, n_keys: int) -> None:
+        _lib.check(self.lib.tvz_corpus_reserve(self._h, int(n_rows), int(n_keys)))
+
     def upload_csr(self, ids: np.ndarray, offsets: np.ndarray, keys: np.ndarray) -> None:
         ids = np.ascontiguousarray(ids, dtype=np.int32)
         offsets = np.ascontiguousarray(offsets, dtype=np.int64)
@@ -65,16 +77,21 @@ class DeviceCorpus:
             raise RuntimeError("offsets must have len(ids)+1 entries")
         _lib.check(self.lib.tvz_corpus_upload(self._h, _ptr(ids), C.c_void_p(offsets.ctypes.data),
                                               _ptr(keys), ids.size, keys.size))
+        self._row_bound = int(ids.size)
 
     def upload(self, rows: Iterable[Tuple[int, Sequence[float]]]) -> None:
         self.upload_csr(*rows_to_csr(rows))
 
     def upsert(self, video_id: int, timestamps: Sequence[float]) -> None:
+        """Stream-ordered on the device: returns without waiting for matches in flight; matches
+        enqueued afterwards see the new row (include/tvz.h tvz_corpus_upsert)."""
         k = np.ascontiguousarray(np.asarray(timestamps, dtype=np.float64))
         _lib.check(self.lib.tvz_corpus_upsert(self._h, int(video_id), _ptr(k), k.size))
+        self._row_bound += 1                # may over-count (a replaced row): only a size bound
 
     def clear(self) -> None:
         _lib.check(self.lib.tvz_corpus_clear(self._h))
+        self._row_bound = 0
 
     def stats(self) -> Tuple[int, int, int]:
         a, b, c = C.c_int64(), C.c_int64(), C.c_int64()
@@ -82,20 +99,28 @@ class DeviceCorpus:
         return a.value, b.value, c.value
 
     # ---- single query, host in / host out: the db.find_duplicates drop-in ----
+    def _out_buffers(self, cap: int):
+        b = getattr(self._tls, "buf", None)
+        if b is None or b[0].size < cap:
+            n = max(cap, 1024)
+            b = (np.empty(n, dtype=np.int32), np.empty(n, dtype=np.int32), np.empty(n, dtype=np.int32),
+                 C.c_int64())
+            b = b + (C.c_void_p(b[0].ctypes.data), C.c_void_p(b[1].ctypes.data), C.c_void_p(b[2].ctypes.data),
+                     C.byref(b[3]))
+            self._tls.buf = b
+        return b
+
     def find_duplicates(self, new_timestamps: Sequence[float], min_match: int = 5,
                         exclude_id: int = -1, with_kth: bool = False):
+        """One kernel launch + one stream synchronisation inside the library (for queries of up to
+        4095 timestamps with min_match <= 5); the output arrays are per-thread and reused."""
         q = np.ascontiguousarray(np.asarray(new_timestamps, dtype=np.float64))
-        cap = max(self.stats()[0], 1)
+        cap = max(self._row_bound, 1)
         while True:
-            ids = np.empty(cap, dtype=np.int32)
-            cnt = np.empty(cap, dtype=np.int32)
-            kth = np.empty(cap, dtype=np.int32)
-            n = C.c_int64()
+            ids, cnt, kth, n, p_ids, p_cnt, p_kth, p_n = self._out_buffers(cap)
             _lib.check(self.lib.tvz_find_duplicates(self._h, _ptr(q), q.size, int(min_match),
-                                                    int(exclude_id), cap, C.c_void_p(ids.ctypes.data),
-                                                    C.c_void_p(cnt.ctypes.data),
-                                                    C.c_void_p(kth.ctypes.data), C.byref(n)))
-            if n.value <= cap:
+                                                    int(exclude_id), ids.size, p_ids, p_cnt, p_kth, p_n))
+            if n.value <= ids.size:
                 break
             cap = int(n.value)  # rows were added concurrently: retry with room for all
         m = n.value
@@ -116,27 +141,107 @@ class DeviceCorpus:
         return out[:n_rows].cpu().numpy()
 
     # ---- batched, device resident ----
-    def match(self, d_queries: torch.Tensor, d_q_offsets: torch.Tensor, max_query_len: int,
-              min_match: int, cap: int, d_exclude_ids: Optional[torch.Tensor] = None,
-              out_hits: Optional[torch.Tensor] = None, out_n: Optional[torch.Tensor] = None,
-              stream: Optional[torch.cuda.Stream] = None):
-        """Enqueue Q queries; returns (hits int32[Q,cap,3], hits_n int32[Q]) device tensors."""
+    def _check_queries(self, d_queries, d_q_offsets):
         dev = d_queries.device
         if dev.type != "cuda" or dev.index != self.device:
             raise RuntimeError(f"queries must live on cuda:{self.device}")
         if d_queries.dtype != torch.float64 or d_q_offsets.dtype != torch.int64:
             raise RuntimeError("queries must be float64 and offsets int64")
-        Q = d_q_offsets.numel() - 1
+        return dev, d_q_offsets.numel() - 1
+
+    def _workspace(self, workspace, need: int, dev, stream):
+        if workspace is None:
+            # per call, from torch's caching allocator (no hipMalloc once warm); pass a persistent
+            # one to keep even that off the hot path
+            workspace = torch.empty(max(need, 256), dtype=torch.uint8, device=dev)
+            workspace.record_stream(stream)
+        elif workspace.device != dev or workspace.dtype != torch.uint8 or workspace.numel() < need:
+            raise RuntimeError(f"workspace must be a uint8 tensor of >= {need} bytes on {dev}")
+        return workspace
+
+    def match(self, d_queries: torch.Tensor, d_q_offsets: torch.Tensor, max_query_len: int,
+              min_match: int, cap: int, d_exclude_ids: Optional[torch.Tensor] = None,
+              out_hits: Optional[torch.Tensor] = None, out_n: Optional[torch.Tensor] = None,
+              stream: Optional[torch.cuda.Stream] = None, workspace: Optional[torch.Tensor] = None,
+              algo: int = _lib.ALGO_AUTO):
+        """Enqueue Q queries; returns (hits int32[Q,cap,3], hits_n int32[Q]) device tensors.
+        `algo`: per-call kernel choice (_lib.ALGO_*); results never depend on it."""
+        dev, Q = self._check_queries(d_queries, d_q_offsets)
         if out_hits is None:
             out_hits = torch.empty((Q, cap, 3), dtype=torch.int32, device=dev)
         if out_n is None:
             out_n = torch.empty(Q, dtype=torch.int32, device=dev)
         s = stream if stream is not None else torch.cuda.current_stream(dev)
+        ws = self._workspace(workspace, workspace_bytes(Q, max_query_len), dev, s)
         _lib.check(self.lib.tvz_match(
             self._h, d_queries.data_ptr(), d_q_offsets.data_ptr(), Q, int(max_query_len),
             int(min_match), d_exclude_ids.data_ptr() if d_exclude_ids is not None else None,
-            int(cap), out_hits.data_ptr(), out_n.data_ptr(), s.cuda_stream))
+            int(cap), out_hits.data_ptr(), out_n.data_ptr(), ws.data_ptr(), ws.numel(), int(algo),
+            s.cuda_stream))
         return out_hits, out_n
+
+    def match_topk(self, d_queries: torch.Tensor, d_q_offsets: torch.Tensor, max_query_len: int,
+                   min_match: int, cap: int, k: int, d_exclude_ids: Optional[torch.Tensor] = None,
+                   out: Optional[torch.Tensor] = None, stream: Optional[torch.cuda.Stream] = None,
+                   workspace: Optional[torch.Tensor] = None, algo: int = _lib.ALGO_AUTO) -> torch.Tensor:
+        """Sweep + per-shard top-k behind ONE library call (hit lists stay in the workspace):
+        -> int32 [Q,k+1,3] = the k best hits by (kth, video_id, count) + a (-1, n_hits, NEVER) row."""
+        dev, Q = self._check_queries(d_queries, d_q_offsets)
+        if out is None:
+            out = torch.empty((Q, k + 1, 3), dtype=torch.int32, device=dev)
+        s = stream if stream is not None else torch.cuda.current_stream(dev)
+        ws = self._workspace(workspace, workspace_bytes(Q, max_query_len, cap, k), dev, s)
+        _lib.check(self.lib.tvz_match_topk(
+            self._h, d_queries.data_ptr(), d_q_offsets.data_ptr(), Q, int(max_query_len),
+            int(min_match), d_exclude_ids.data_ptr() if d_exclude_ids is not None else None,
+            int(cap), int(k), out.data_ptr(), ws.data_ptr(), ws.numel(), int(algo), s.cuda_stream))
+        return out
+
+
+class Comm:
+    """tvz_comm handle: the RCCL communicator of the sharded match, owned by libtvz.so (a non-Python
+    host gets the same path through include/tvz.h).  `unique_id()` on rank 0, ship the 128 bytes to
+    the other ranks by any means, then Comm(id, n_ranks, rank, device) on every rank."""
+
+    @staticmethod
+    def unique_id() -> bytes:
+        buf = C.create_string_buffer(_lib.UNIQUE_ID_BYTES)
+        _lib.check(_lib.load().tvz_comm_unique_id(buf))
+        return buf.raw
+
+    def __init__(self, unique_id: bytes, n_ranks: int, rank: int, device: int = 0):
+        self.lib = _lib.load()
+        if len(unique_id) != _lib.UNIQUE_ID_BYTES:
+            raise RuntimeError("unique id must be 128 bytes")
+        h = C.c_void_p()
+        _lib.check(self.lib.tvz_comm_init(C.byref(h), C.c_char_p(unique_id), int(n_ranks), int(rank),
+                                          int(device)))
+        self._h = h
+        self.n_ranks, self.rank, self.device = int(n_ranks), int(rank), int(device)
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            self.lib.tvz_comm_destroy(self._h)
+            self._h = None
+
+    def match_sharded(self, corpus: DeviceCorpus, d_queries: torch.Tensor, d_q_offsets: torch.Tensor,
+                      max_query_len: int, min_match: int, cap: int, k: int,
+                      d_exclude_ids: Optional[torch.Tensor] = None,
+                      workspace: Optional[torch.Tensor] = None,
+                      stream: Optional[torch.cuda.Stream] = None, algo: int = _lib.ALGO_AUTO):
+        """local sweep + top-k -> ncclAllGather -> merge, all enqueued on `stream` by ONE library
+        call; -> (merged int32 [Q,k,3], totals int32 [Q]), identical on every rank."""
+        dev, Q = corpus._check_queries(d_queries, d_q_offsets)
+        merged = torch.empty((Q, k, 3), dtype=torch.int32, device=dev)
+        totals = torch.empty(Q, dtype=torch.int32, device=dev)
+        s = stream if stream is not None else torch.cuda.current_stream(dev)
+        ws = corpus._workspace(workspace, workspace_bytes(Q, max_query_len, cap, k, self.n_ranks), dev, s)
+        _lib.check(self.lib.tvz_match_sharded(
+            corpus._h, self._h, d_queries.data_ptr(), d_q_offsets.data_ptr(), Q, int(max_query_len),
+            int(min_match), d_exclude_ids.data_ptr() if d_exclude_ids is not None else None,
+            int(cap), int(k), merged.data_ptr(), totals.data_ptr(), ws.data_ptr(), ws.numel(),
+            int(algo), s.cuda_stream))
+        return merged, totals
 
 
 def topk(lists: torch.Tensor, lists_n: Optional[torch.Tensor], k: int,

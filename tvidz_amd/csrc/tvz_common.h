@@ -5,6 +5,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <cstring>
 #include <exception>
 #include <new>
 
@@ -53,3 +54,13 @@ inline int64_t round_up(int64_t a, int64_t b) { return (a + b - 1) / b * b; }
 inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 }  // namespace tvz
+
+// Internal (not exported): local sweep + per-shard top-k with the hit lists in the workspace
+// (tvz_match.hip); d_out = NULL writes the block into the workspace's own [Q][k+1][3] area.
+int tvz_match_topk_local(tvz_corpus *c, const double *d_queries, const int64_t *d_q_offsets,
+                         int32_t Q, int32_t max_query_len, int32_t min_match,
+                         const int32_t *d_exclude_ids, int32_t cap, int32_t k, int32_t *d_out,
+                         void *d_workspace, size_t workspace_bytes, int32_t n_ranks, int32_t algo,
+                         void *hip_stream, int32_t **gathered_out);
+int32_t *tvz_ws_local_block(void *d_workspace, int32_t Q, int32_t max_query_len, int32_t cap,
+                            int32_t k, int32_t n_ranks);

@@ -1,4 +1,4 @@
-// tvz_match.hip — timestamp-corpus matcher for MI355X (gfx950, wave64).
+// tvz_match.hip — timestamp-corpus matcher for MI355X (gfx950, wave64): host side.
 //
 // Replaces /root/reference inspector/db.py:76-94 (find_duplicates) and the per-prefix
 // loop around it, inspector/app.py:231-255.  Semantics (db.py:85-91): for every corpus
@@ -6,831 +6,26 @@
 // its multiplicity, the row acts as a set); a row is a hit iff count >= min_match.
 //
 // Device image of `video_timestamps` (db.py:21-27):
-//   rows[r] = {key offset, key count, video_id}           16 B each
+//   rows[r] = {key offset, key count, video_id}           16 B each, swapped by ONE store
 //   keys    = arena of canonical float64 bit patterns (int64): per row sorted, unique,
 //             NaN dropped, -0.0 folded to +0.0; every row starts 16-byte aligned.
+// The arena is APPEND-ONLY between compactions: add_timestamps (db.py:43-64) copies the new
+// keys to fresh arena space and then swaps the 16-byte row entry, both on the handle's mutation
+// stream; matches enqueued later wait for that stream's event on the device.  Nothing on the
+// upsert path waits for the host or for matches in flight (only a compaction or a growth of the
+// arena beyond its reservation drains them).
 //
-// Kernel ts_match_tile_kernel<TOP5>: grid = (row chunks, query tiles).  A 1024-thread block builds
-//   ONE hash table in LDS for a tile of up to 16 queries (16-bit tag + chain head per slot, two
-//   slots per aligned 8-byte probe; every query element is a chained (key, position, query) entry,
-//   so query multiplicity is exact), then sweeps its chunk of rows: a 16-lane group owns one row
-//   at a time, streams its keys with 16-byte loads and probes the table ONCE per key for all the
-//   queries of the tile - the tile plays the role a GEMM tile plays: every corpus byte loaded is
-//   reused 16 times on chip.  The per-key fast path is branch-free; lanes that found their tag
-//   (or a full home pair) push the key into a per-wave LDS ring by ballot/mbcnt compaction and the
-//   wave drains the ring 64 entries at a time with every lane busy on the exact probe, full-key
-//   verification and accounting (LDS atomics: hit count + the smallest matching positions).
-//   After a row, lane q of the group emits query q's hit (video_id, count, kth); kth = the
-//   min_match-th smallest matching position, read from the tracked minima for min_match <= 5
-//   (the reference's default 5 and the driver's 2), by ts_kth_fixup_kernel beyond.
-//   Integer / LDS / issue-bound: no MFMA.
-// Kernel ts_match_longq_kernel: single queries longer than a tile (> 4095 timestamps).
-// Kernel ts_topk_kernel: per query bitonic selection of the k best hits ordered by
-//   (kth, video_id, count) over one or several (all-gathered) hit lists.
-// Kernel ts_align_kernel: opt-in shift/tolerance score (never the verdict).
+// Kernels: tvz_match_kernels.h.  No process-global mutable state: the sweep algorithm is a
+// per-call argument and scratch is the caller's workspace.
 #include <algorithm>
-#include <climits>
-#include <cstring>
 #include <mutex>
 #include <shared_mutex>
 #include <unordered_map>
 #include <vector>
 
-#include "tvz_common.h"
-
-#ifndef TVZ_MATCH_STEP
-#define TVZ_MATCH_STEP 2   // 16-byte key loads per lane and sweep step (4 keys); 3/4/6 measured no faster
-#endif
+#include "tvz_match_kernels.h"
 
 namespace {
-
-constexpr int kBlock = 256;
-constexpr int kGroup = 16;                  // lanes per corpus row
-constexpr int kGroupsPerBlock = kBlock / kGroup;
-constexpr int64_t kEmpty = 0x7ff8dead00000000LL;  // a NaN pattern: never a canonical key
-constexpr int kMaxQueryLen = 4095;          // positions 0..4094 fit 12 bits with 0xfff as "none"
-
-struct Row {
-    int64_t off;
-    int32_t len;
-    int32_t vid;
-};
-static_assert(sizeof(Row) == 16, "Row must be 16 bytes");
-
-// ---- canonical key: integer-only so subnormals / signed zero never meet FP modes ----
-__host__ __device__ inline bool canon_key(double x, int64_t &k) {
-    int64_t b;
-    memcpy(&b, &x, 8);
-    const uint64_t mag = (uint64_t)b & 0x7fffffffffffffffULL;
-    if (mag > 0x7ff0000000000000ULL) return false;  // NaN: == is always false
-    k = (mag == 0) ? 0 : b;                         // -0.0 == +0.0
-    return true;
-}
-
-// ---- query tile: up to 16 queries share ONE hash table in LDS -----------------------------
-// One probe of a corpus key serves every query of the tile, and each corpus row is read once
-// per tile instead of once per query.
-//   slots   : 16384 x u32 = (16-bit tag << 16) | (head entry index); 0xffffffff = empty.
-//             Probed two at a time (one aligned ds_read_b64); load factor <= 0.25, so a probe
-//             almost never needs a second read - what matters on a 64-lane wave is the LONGEST
-//             probe of the wave, not the average.
-//   entries : one per query element of the tile: full canonical key (verification) and
-//             (position, query-in-tile, next entry with the same slot).  Query multiplicity is
-//             therefore exact: every occurrence is its own entry.
-constexpr int kTileBlock = 1024;                      // 16 waves, 64 row groups
-constexpr int kTileGroups = kTileBlock / kGroup;
-constexpr int kTileQ = kGroup;                        // lane <-> query mapping at emission
-constexpr int kTileSlots = 16384;
-constexpr int kTilePairs = kTileSlots / 2;
-constexpr int kTileMaxEntries = 4096;                 // load factor <= 0.25
-constexpr uint32_t kEnd = 0xffffu;
-constexpr uint32_t kFree = 0xffffffffu;
-static_assert(kTileMaxEntries >= kMaxQueryLen, "a single maximal query must fit one tile");
-constexpr int kRing = 128;                            // per-wave slow-path ring (entries)
-constexpr size_t kTileLds = (size_t)kTileSlots * 4 + (size_t)kTileMaxEntries * 8 +
-                            (size_t)kTileMaxEntries * 4 + (size_t)kTileGroups * kTileQ * 3 * 4 +
-                            (size_t)(kTileBlock / 64) * kRing * 12;
-
-// Per (row group, query of the tile) state in LDS: a hit counter and the FIVE smallest matching
-// query positions, packed as 5 x 12 bits (ascending from bit 0, 0xfff = none) in one 64-bit word
-// updated with a CAS loop.  kth for min_match <= 5 (the reference's default and the driver's 2)
-// is read straight from it.
-constexpr int kTop = 5;
-constexpr unsigned long long kTopNone = 0x0fffffffffffffffULL;   // 5 fields of 0xfff
-
-__device__ __forceinline__ unsigned long long top5_insert(unsigned long long p, uint32_t x) {
-    uint32_t a[kTop];
-#pragma unroll
-    for (int i = 0; i < kTop; ++i) a[i] = (uint32_t)(p >> (12 * i)) & 0xfffu;
-#pragma unroll
-    for (int i = 0; i < kTop; ++i) {      // insertion network: keep the smaller, carry the larger
-        const uint32_t lo = a[i] < x ? a[i] : x;
-        x = a[i] < x ? x : a[i];
-        a[i] = lo;
-    }
-    unsigned long long r = 0;
-#pragma unroll
-    for (int i = 0; i < kTop; ++i) r |= (unsigned long long)a[i] << (12 * i);
-    return r;
-}
-
-// pair index (13 bits) and tag (16 bits) from one mix of the key: 9 full-rate VALU ops (one
-// v_mul_u32_u24, no quarter-rate v_mul_lo_u32).  Quality only affects speed: every tag match is
-// verified against the full key.  A tag of 0xffff may "match" a free slot's upper half; the slow
-// path then finds an empty chain (head 0xffff = kEnd), which is the right answer.
-__device__ __forceinline__ void hash_pair_tag(int64_t k, uint32_t &pair, uint32_t &tag) {
-    const uint32_t lo = (uint32_t)k, hi = (uint32_t)((uint64_t)k >> 32);
-    uint32_t x = lo ^ (hi + (hi << 3)) ^ (hi >> 9);
-    x ^= x >> 20;                                   // fold the bits v_mul_u32_u24 ignores
-    const uint32_t y = __umul24(x, 0x9E3779u);
-    pair = y >> (32 - 13);
-    tag = (y >> 3) & 0xffffu;
-}
-static_assert((1 << 13) == kTilePairs, "pair bits must match kTilePairs");
-
-// one matching (query, position) entry: count it and keep the two smallest positions
-// TOP5 = false (min_match <= 2, the streaming driver's case): the 8-byte word holds the smallest
-// and second smallest position as two u32 updated with two LDS atomicMin (7 % faster).
-template <bool TOP5>
-__device__ __forceinline__ void account(uint32_t *cnt, unsigned long long *top, uint32_t ent) {
-    const uint32_t q = (ent >> 12) & 15u;
-    const uint32_t pos = ent & 0xfffu;
-    atomicAdd(&cnt[q], 1u);
-    if constexpr (!TOP5) {
-        uint32_t *m = reinterpret_cast<uint32_t *>(&top[q]);
-        const uint32_t old = atomicMin(&m[0], pos);
-        atomicMin(&m[1], old > pos ? old : pos);   // the larger of two distinct hits: >= 2nd smallest
-        return;
-    }
-    unsigned long long seen = top[q];
-    while (true) {
-        if (((uint32_t)(seen >> (12 * (kTop - 1))) & 0xfffu) <= pos) break;   // not among the 5 smallest
-        const unsigned long long old = atomicCAS(&top[q], seen, top5_insert(seen, pos));
-        if (old == seen) break;
-        seen = old;
-    }
-}
-
-template <bool TOP5>
-__global__ __launch_bounds__(kTileBlock) void ts_match_tile_kernel(
-    const Row *__restrict__ rows, int64_t n_rows, const int64_t *__restrict__ keys,
-    const double *__restrict__ queries, const int64_t *__restrict__ q_offsets, int32_t Q,
-    int32_t nq_tile, int32_t min_match, const int32_t *__restrict__ exclude_ids, int32_t cap,
-    int32_t *__restrict__ hits, int32_t *__restrict__ hits_n, int32_t rows_per_block) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    uint32_t *slots = reinterpret_cast<uint32_t *>(smem);
-    int64_t *ekey = reinterpret_cast<int64_t *>(smem + (size_t)kTileSlots * 4);
-    uint32_t *epack = reinterpret_cast<uint32_t *>(ekey + kTileMaxEntries);
-    unsigned long long *top = reinterpret_cast<unsigned long long *>(epack + kTileMaxEntries);
-    uint32_t *cnt = reinterpret_cast<uint32_t *>(top + kTileGroups * kTileQ);
-    __shared__ int64_t s_qoff[kTileQ + 1];
-
-    const int q0 = blockIdx.y * nq_tile;
-    const int nq = (Q - q0 < nq_tile) ? Q - q0 : nq_tile;
-    if (threadIdx.x <= nq) s_qoff[threadIdx.x] = q_offsets[q0 + threadIdx.x];
-    for (int i = threadIdx.x; i < kTileSlots; i += kTileBlock) slots[i] = kFree;
-    for (int i = threadIdx.x; i < kTileGroups * kTileQ; i += kTileBlock) {
-        top[i] = TOP5 ? kTopNone : ~0ULL;
-        cnt[i] = 0;
-    }
-    __syncthreads();
-    const int64_t qbase = s_qoff[0];
-    if (s_qoff[nq] - qbase > kTileMaxEntries) {
-        // the caller's max_query_len was not an upper bound: poison the affected counters instead
-        // of returning silently truncated matches (every row chunk of this tile takes this exit)
-        if (threadIdx.x < nq) hits_n[q0 + threadIdx.x] = INT32_MIN;
-        return;
-    }
-    const int total = (int)(s_qoff[nq] - qbase);
-    for (int e = threadIdx.x; e < total; e += kTileBlock) {
-        int ql = 0;
-        while (ql + 1 < nq && s_qoff[ql + 1] - qbase <= e) ++ql;
-        const uint32_t pos = (uint32_t)(e - (int)(s_qoff[ql] - qbase));
-        int64_t k;
-        if (!canon_key(queries[qbase + e], k)) continue;   // NaN never matches
-        ekey[e] = k;
-        uint32_t pair, tag;
-        hash_pair_tag(k, pair, tag);
-        // first slot of the probe sequence that is free or already carries this tag
-        uint32_t s = pair * 2, prev = kEnd;
-        while (true) {
-            uint32_t w = slots[s];
-            if (w == kFree) {
-                w = atomicCAS(&slots[s], kFree, (tag << 16) | (uint32_t)e);
-                if (w == kFree) break;                      // claimed an empty slot
-            }
-            if ((w >> 16) == tag) {                         // push on this tag's chain
-                uint32_t seen = w;
-                while (true) {
-                    const uint32_t old = atomicCAS(&slots[s], seen, (seen & 0xffff0000u) | (uint32_t)e);
-                    if (old == seen) break;
-                    seen = old;
-                }
-                prev = seen & 0xffffu;
-                break;
-            }
-            s = (s + 1) & (kTileSlots - 1);
-        }
-        epack[e] = pos | ((uint32_t)ql << 12) | (prev << 16);
-    }
-    __syncthreads();
-
-    const int gl = threadIdx.x & (kGroup - 1);
-    const int g = threadIdx.x / kGroup;
-    uint32_t *gcnt = cnt + g * kTileQ;
-    unsigned long long *gtop = top + g * kTileQ;
-    const bool my_q = gl < nq;
-    const int32_t excl = (exclude_ids && my_q) ? exclude_ids[q0 + gl] : -1;
-    const bool use_excl = exclude_ids != nullptr;
-    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
-    int64_t r1 = r0 + rows_per_block;
-    if (r1 > n_rows) r1 = n_rows;
-    const uint2 *pairs = reinterpret_cast<const uint2 *>(slots);
-
-    // ---- sweep -------------------------------------------------------------------------------
-    // SIMT rule that shapes this loop: an event that is rare per LANE (a corpus key that is in
-    // the tile, ~6 % on the synthetic corpora; a displaced key) still happens in almost every
-    // 64-lane wave-instruction, so handling it inline costs every probe the full slow path.
-    // Instead the per-key fast path is branch-free (hash, one aligned 8-byte LDS read of the home
-    // slot pair, tag compares) and lanes that need more push (key, pair|tag|group) into a per-wave
-    // LDS ring with a ballot/mbcnt compaction; whenever 64 entries are pending the whole wave
-    // drains them with every lane busy on the exact probe + chain verification + accounting.
-    const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
-    const uint32_t gw = (threadIdx.x >> 4) & 3u;                 // group within the wave
-    const uint32_t gwbits = gw << 29;
-    int64_t *qbase_k = reinterpret_cast<int64_t *>(cnt + kTileGroups * kTileQ);
-    int64_t *qk = qbase_k + wave * kRing;
-    uint32_t *qm = reinterpret_cast<uint32_t *>(qbase_k + (kTileBlock / 64) * kRing) + wave * kRing;
-    uint32_t *wcnt = cnt + wave * 4 * kTileQ;                     // the wave's 4 groups
-    unsigned long long *wtop = top + wave * 4 * kTileQ;
-    uint32_t qhead = 0, qtail = 0;                                // wave-uniform
-
-    auto drain = [&](uint32_t n) {                                // n <= 64 pending entries
-        if ((uint32_t)lane < n) {
-            const uint32_t idx = (qhead + lane) & (kRing - 1);
-            const int64_t k = qk[idx];
-            const uint32_t m = qm[idx];
-            const uint32_t tag = m & 0xffffu;
-            uint32_t pair = (m >> 16) & (uint32_t)(kTilePairs - 1);
-            uint32_t *scnt = wcnt + (m >> 29) * kTileQ;
-            unsigned long long *stop = wtop + (m >> 29) * kTileQ;
-            uint32_t e = kEnd;
-            while (true) {      // first slot of the probe sequence that is free or carries the tag
-                const uint2 w = pairs[pair];
-                if ((w.x >> 16) == tag) { e = w.x & 0xffffu; break; }
-                if (w.x == kFree) break;
-                if ((w.y >> 16) == tag) { e = w.y & 0xffffu; break; }
-                if (w.y == kFree) break;
-                pair = (pair + 1) & (uint32_t)(kTilePairs - 1);
-            }
-            while (e != kEnd) {  // every (query, position) entry of that slot; verify the full key
-                const uint32_t ent = epack[e];
-                if (ekey[e] == k) account<TOP5>(scnt, stop, ent);
-                e = ent >> 16;
-            }
-        }
-        qhead += n;
-    };
-
-    const int64_t rw0 = r0 + (int64_t)wave * 4;                   // first row of the wave's groups
-    for (int64_t rr = rw0; rr < r1; rr += kTileGroups) {          // wave-uniform trip count
-        const int64_t r = rr + gw;
-        const bool live = r < r1;
-        Row row = Row{0, 0, -1};
-        if (live) row = rows[r];
-        const int64_t *rk = keys + row.off + gl * 2;
-        const int nmine = row.len - gl * 2;                       // keys at or after this lane's first
-        // kStep 16-byte loads (2 keys each) per lane and step, the next step's loads in flight
-        constexpr int kStep = TVZ_MATCH_STEP;
-        constexpr int kStride = kGroup * 2;                       // keys between a lane's loads
-        longlong2 v[kStep];
-#pragma unroll
-        for (int j = 0; j < kStep; ++j)
-            v[j] = (nmine > j * kStride) ? *reinterpret_cast<const longlong2 *>(rk + j * kStride)
-                                         : make_longlong2(0, 0);
-        for (int i = 0; __ballot(i < nmine) != 0ull; i += kStep * kStride) {
-            int64_t kk[2 * kStep];
-#pragma unroll
-            for (int j = 0; j < kStep; ++j) {
-                kk[2 * j] = v[j].x;
-                kk[2 * j + 1] = v[j].y;
-            }
-            const int in = i + kStep * kStride;
-#pragma unroll
-            for (int j = 0; j < kStep; ++j)
-                if (in + j * kStride < nmine) v[j] = *reinterpret_cast<const longlong2 *>(rk + in + j * kStride);
-            uint32_t pr[2 * kStep], tg[2 * kStep];
-            uint2 w[2 * kStep];
-#pragma unroll
-            for (int j = 0; j < 2 * kStep; ++j) {
-                hash_pair_tag(kk[j], pr[j], tg[j]);
-                w[j] = pairs[pr[j]];
-            }
-#pragma unroll
-            for (int j = 0; j < 2 * kStep; ++j) {
-                const bool valid = i + (j / 2) * kStride + (j & 1) < nmine;
-                // needs the slow path: tag present in the home pair, or the pair is full
-                const bool slow = valid & (((w[j].x >> 16) == tg[j]) | (w[j].y != kFree));
-                const unsigned long long bal = __ballot(slow);
-                if (bal) {                                        // wave-uniform
-                    const uint32_t ofs = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32),
-                                         __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
-                    if (slow) {
-                        const uint32_t idx = (qtail + ofs) & (kRing - 1);
-                        qk[idx] = kk[j];
-                        qm[idx] = tg[j] | (pr[j] << 16) | gwbits;
-                    }
-                    qtail += (uint32_t)__popcll(bal);
-                    if (qtail - qhead >= 64u) drain(64u);
-                }
-            }
-        }
-        if (qtail != qhead) drain(qtail - qhead);                 // row boundary: settle the counts
-        // lane q of the group owns query q of the tile (LDS ops of a wave complete in order)
-        if (my_q & live) {
-            const uint32_t c = gcnt[gl];
-            const unsigned long long t5 = gtop[gl];
-            if (c) {
-                gcnt[gl] = 0;
-                gtop[gl] = TOP5 ? kTopNone : ~0ULL;
-            }
-            if ((int64_t)c >= (int64_t)min_match && !(use_excl && row.vid == excl)) {
-                int32_t kth;
-                if (min_match <= 0) kth = -1;
-                else if (!TOP5) kth = (int32_t)(uint32_t)(min_match == 1 ? t5 : t5 >> 32);
-                else if (min_match <= kTop) kth = (int32_t)((t5 >> (12 * (min_match - 1))) & 0xfffu);
-                else kth = -2 - (int32_t)r;          // resolved by ts_kth_fixup_kernel
-                const int slot = atomicAdd(&hits_n[q0 + gl], 1);
-                if (slot < cap) {
-                    int32_t *h = hits + ((int64_t)(q0 + gl) * cap + slot) * 3;
-                    h[0] = row.vid;
-                    h[1] = (int32_t)c;
-                    h[2] = kth;
-                }
-            }
-        }
-    }
-}
-
-// ---- hash join for large query batches (Q >= 32, min_match <= 2) ----------------------------
-// The LDS tile kernel probes every corpus key once per 16 queries.  For big batches against big
-// corpora a database hash JOIN does less work: build one multimap per tile of 128 queries in device
-// memory (sized to stay in one XCD's 4 MiB L2), then sweep the corpus once per tile - one probe of a
-// corpus key serves 128 queries, 8x fewer probes than the LDS tile.  Blocks of one tile are mapped
-// to one XCD (blockIdx % 8) so its table is served from that XCD's L2.  What it buys is bounded by
-// the L2: a random 16-byte probe moves a whole cache line, and the measured probe rate (~180 G/s)
-// is the L2's random-line rate - LDS has no line granularity, which is why the LDS tile stays
-// competitive with 8x the probes (1.18 vs 2.30 ms at C=100k, Q=1024).  An LDS presence bitmap of
-// the tile's keys (64 KiB) keeps ~70 % of the corpus keys from touching the L2 at all.  Per (row group, query) state lives in LDS: a u16 hit
-// counter and the two smallest matching positions (u16 + u16 in one CAS word); after a row each
-// lane scans 8 of the tile's 128 queries and emits the hits.
-constexpr int kJoinQ = 128;
-constexpr int kJoinBlock = 1024;
-constexpr int kJoinGroups = kJoinBlock / kGroup;
-constexpr int kJoinBloomBits = 1 << 19;                           // 64 KiB presence bitmap per tile
-constexpr size_t kJoinLds = (size_t)kJoinGroups * kJoinQ * 10 + kJoinBloomBits / 8;   // 80 + 64 KiB
-constexpr int64_t kJEmpty = -1;                                    // 0xff..ff: a NaN pattern
-
-__device__ __forceinline__ uint32_t hash32(int64_t k) {
-    const uint32_t lo = (uint32_t)k, hi = (uint32_t)((uint64_t)k >> 32);
-    uint32_t x = lo ^ (hi + (hi << 3)) ^ (hi >> 9);
-    x ^= x >> 20;
-    const uint32_t y = __umul24(x, 0x9E3779u);
-    return y ^ (y >> 15);
-}
-
-// Table layout: keys int64[S] and packs u32[S] apart, so ONE 16-byte load fetches the two keys of a
-// slot pair; the (position | query-in-tile << 12) pack is only loaded on a match.  Random global
-// accesses cost the CU's address pipeline ~1 lane-address per cycle, so loads per probe are what
-// bounds this kernel (an array-of-structs slot needed two loads per probe: 1.6x slower).
-
-// The table is a MULTIMAP: every query element takes its own slot (the first free one of its key's
-// probe sequence), so a lookup needs no dependent chain loads - it walks the probe sequence up to
-// the first free slot and accounts every slot that carries the key.  (A chained layout was tried:
-// on a 64-lane wave some lane almost always has a chain to follow, and each hop is a dependent
-// ~1 us L2 access.)
-__global__ __launch_bounds__(kBlock) void ts_join_build_kernel(
-    const double *__restrict__ queries, const int64_t *__restrict__ q_offsets, int32_t Q,
-    int32_t max_len, int32_t s_log2, unsigned long long *__restrict__ tkeys,
-    uint32_t *__restrict__ tpack, uint32_t *__restrict__ tbloom, int32_t *__restrict__ hits_n) {
-    const int q = blockIdx.y;
-    const int64_t o = q_offsets[q];
-    const int i = blockIdx.x * kBlock + threadIdx.x;
-    const int64_t len = q_offsets[q + 1] - o;
-    if (len > max_len) {
-        // max_query_len was not an upper bound (the table is sized from it): nothing of this
-        // query is inserted and its counter is poisoned instead (stays negative)
-        if (i == 0) hits_n[q] = INT32_MIN;
-        return;
-    }
-    if (i >= (int)len) return;
-    int64_t k;
-    if (!canon_key(queries[o + i], k)) return;                     // NaN never matches
-    const uint32_t smask = (1u << s_log2) - 1u;
-    const size_t tb = (size_t)(q / kJoinQ) << s_log2;
-    const uint32_t hv = hash32(k);
-    const uint32_t bit = hv & (uint32_t)(kJoinBloomBits - 1);      // presence bit (low hash bits)
-    atomicOr(&tbloom[(size_t)(q / kJoinQ) * (kJoinBloomBits / 32) + (bit >> 5)], 1u << (bit & 31));
-    uint32_t h = (hv >> (32 - s_log2)) & ~1u;                      // home pair (high hash bits)
-    while (true) {
-        const unsigned long long old = atomicCAS(&tkeys[tb + h], (unsigned long long)kJEmpty,
-                                                 (unsigned long long)k);
-        if (old == (unsigned long long)kJEmpty) break;             // claimed a free slot
-        h = (h + 1) & smask;
-    }
-    tpack[tb + h] = (uint32_t)i | ((uint32_t)(q % kJoinQ) << 12);
-}
-
-__global__ __launch_bounds__(kJoinBlock) void ts_match_join_kernel(
-    const Row *__restrict__ rows, int64_t n_rows, const int64_t *__restrict__ keys,
-    const int64_t *__restrict__ tkeys, const uint32_t *__restrict__ tpack,
-    const uint32_t *__restrict__ tbloom, int32_t s_log2, int32_t Q, int32_t n_tiles, int32_t n_chunks,
-    int32_t min_match, const int32_t *__restrict__ exclude_ids, int32_t cap,
-    int32_t *__restrict__ hits, int32_t *__restrict__ hits_n, int32_t rows_per_block) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    uint32_t *m1_all = reinterpret_cast<uint32_t *>(smem);                     // [groups][128] smallest pos
-    uint32_t *m2_all = m1_all + kJoinGroups * kJoinQ;                          // [groups][128] 2nd smallest
-    uint32_t *cnt_all = m2_all + kJoinGroups * kJoinQ;                         // [groups][64] 2 x u16
-    uint32_t *bloom = cnt_all + kJoinGroups * (kJoinQ / 2);                    // [2^19 bits]
-    // block -> (tile, chunk): blocks of one tile share blockIdx % 8, i.e. (observed) one XCD and its L2
-    const int b = blockIdx.x;
-    int tile, chunk;
-    if (8 % n_tiles == 0) {
-        const int g = 8 / n_tiles;                                             // XCDs per tile
-        tile = (b % 8) / g;
-        chunk = (b / 8) * g + (b % 8) % g;
-    } else if (n_tiles % 8 == 0) {
-        tile = (b % 8) + 8 * ((b / 8) % (n_tiles / 8));
-        chunk = (b / 8) / (n_tiles / 8);
-    } else {
-        tile = b / n_chunks;
-        chunk = b % n_chunks;
-    }
-    if (tile >= n_tiles || chunk >= n_chunks) return;
-    const int gl = threadIdx.x & (kGroup - 1);
-    const int g = threadIdx.x / kGroup;
-    uint32_t *m1 = m1_all + g * kJoinQ;
-    uint32_t *m2 = m2_all + g * kJoinQ;
-    uint32_t *cntw = cnt_all + g * (kJoinQ / 2);
-    for (int i = gl; i < kJoinQ; i += kGroup) { m1[i] = 0xffffffffu; m2[i] = 0xffffffffu; }
-    {   // the tile's presence bitmap: 64 KiB copied from device memory into LDS once per block
-        const uint4 *src = reinterpret_cast<const uint4 *>(tbloom + (size_t)tile * (kJoinBloomBits / 32));
-        uint4 *dst = reinterpret_cast<uint4 *>(bloom);
-        for (int i = threadIdx.x; i < kJoinBloomBits / 128; i += kJoinBlock) dst[i] = src[i];
-    }
-    __syncthreads();
-    for (int i = gl; i < kJoinQ / 2; i += kGroup) cntw[i] = 0;
-    const int q0 = tile * kJoinQ;
-    const uint32_t smask = (1u << s_log2) - 1u;
-    const int64_t *tk = tkeys + ((size_t)tile << s_log2);
-    const uint32_t *tp = tpack + ((size_t)tile << s_log2);
-    const int64_t r0 = (int64_t)chunk * rows_per_block;
-    int64_t r1 = r0 + rows_per_block;
-    if (r1 > n_rows) r1 = n_rows;
-
-    auto account = [&](uint32_t pk) {                    // one matching (query, position) entry
-        const uint32_t ql = pk >> 12, pos = pk & 0xfffu;
-        atomicAdd(&cntw[ql >> 1], 1u << (16 * (ql & 1)));
-        const uint32_t old = atomicMin(&m1[ql], pos);    // two plain LDS atomics, no CAS loop
-        atomicMin(&m2[ql], old > pos ? old : pos);       // larger of two distinct hits >= 2nd smallest
-    };
-
-    constexpr int kK = 4;                                // keys per lane and step: 8 table loads in flight
-    for (int64_t r = r0 + g; r < r1; r += kJoinGroups) {
-        const Row row = rows[r];
-        const int64_t *rk = keys + row.off;
-        for (int i0 = gl * 2; i0 < row.len; i0 += kGroup * kK) {
-            int64_t kk[kK];
-            bool valid[kK];
-#pragma unroll
-            for (int j = 0; j < kK / 2; ++j) {
-                const int i = i0 + j * kGroup * 2;
-                longlong2 v = make_longlong2(0, 0);
-                if (i < row.len) v = *reinterpret_cast<const longlong2 *>(rk + i);
-                kk[2 * j] = v.x;
-                kk[2 * j + 1] = v.y;
-                valid[2 * j] = i < row.len;
-                valid[2 * j + 1] = i + 1 < row.len;
-            }
-            uint32_t h[kK];
-            longlong2 sk[kK];
-#pragma unroll
-            for (int j = 0; j < kK; ++j) {               // independent L2 reads, all in flight
-                // LDS presence filter first: a random probe of the table costs a whole L2 line,
-                // and ~70 % of the corpus keys are in no query of the tile
-                const uint32_t hv = hash32(kk[j]);
-                const uint32_t bit = hv & (uint32_t)(kJoinBloomBits - 1);
-                h[j] = (hv >> (32 - s_log2)) & ~1u;
-                sk[j] = make_longlong2(kJEmpty, kJEmpty);
-                if (valid[j] && ((bloom[bit >> 5] >> (bit & 31)) & 1u))
-                    sk[j] = *reinterpret_cast<const longlong2 *>(tk + h[j]);
-            }
-#pragma unroll
-            for (int j = 0; j < kK; ++j) {
-                if (!valid[j]) continue;
-                if (sk[j].x == kk[j]) account(tp[h[j]]);
-                if (sk[j].x == kJEmpty) continue;
-                if (sk[j].y == kk[j]) account(tp[h[j] + 1]);
-                if (sk[j].y == kJEmpty) continue;
-                uint32_t hh = h[j];                      // home pair full: keep walking (rare)
-                while (true) {
-                    hh = (hh + 2) & smask;
-                    const longlong2 a = *reinterpret_cast<const longlong2 *>(tk + hh);
-                    if (a.x == kk[j]) account(tp[hh]);
-                    if (a.x == kJEmpty) break;
-                    if (a.y == kk[j]) account(tp[hh + 1]);
-                    if (a.y == kJEmpty) break;
-                }
-            }
-        }
-        // lane gl owns queries gl*8 .. gl*8+7 of the tile (4 counter words of 2 x u16)
-        const uint4 cw = *reinterpret_cast<const uint4 *>(cntw + gl * 4);
-        if ((cw.x | cw.y | cw.z | cw.w) == 0 && min_match > 0) continue;      // nothing matched
-        const uint32_t w[4] = {cw.x, cw.y, cw.z, cw.w};
-        uint32_t todo = 0;                               // bit j: query gl*8+j reaches min_match
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int c = (int)((w[j >> 1] >> (16 * (j & 1))) & 0xffffu);
-            todo |= (uint32_t)(c >= min_match && q0 + gl * 8 + j < Q) << j;
-        }
-        while (todo) {                                   // usually 0 or 1 iterations
-            const int j = __ffs(todo) - 1;
-            todo &= todo - 1;
-            const int ql = gl * 8 + j;
-            const int q = q0 + ql;
-            const uint32_t c = (w[j >> 1] >> (16 * (j & 1))) & 0xffffu;
-            if (!(exclude_ids && exclude_ids[q] == row.vid)) {
-                const int32_t kth = min_match <= 0 ? -1 : (int32_t)(min_match == 1 ? m1[ql] : m2[ql]);
-                const int slot = atomicAdd(&hits_n[q], 1);
-                if (slot < cap) {
-                    int32_t *hp = hits + ((int64_t)q * cap + slot) * 3;
-                    hp[0] = row.vid;
-                    hp[1] = (int32_t)c;
-                    hp[2] = kth;
-                }
-            }
-        }
-        // unconditional reset of this lane's 8 queries: 5 wide LDS stores, no per-query branches
-        const uint4 ones = make_uint4(0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu);
-        *reinterpret_cast<uint4 *>(cntw + gl * 4) = make_uint4(0, 0, 0, 0);
-        *reinterpret_cast<uint4 *>(m1 + gl * 8) = ones;
-        *reinterpret_cast<uint4 *>(m1 + gl * 8 + 4) = ones;
-        *reinterpret_cast<uint4 *>(m2 + gl * 8) = ones;
-        *reinterpret_cast<uint4 *>(m2 + gl * 8 + 4) = ones;
-    }
-}
-
-// ---- queries longer than a tile (> 4095 timestamps): counts by searching the SORTED query ----
-// Rare (a video with thousands of cuts), so simple beats fast: a 16-lane group owns a row, every
-// row key is binary-searched in the query's sorted distinct keys (sq, with multiplicities) and the
-// hit (video_id, count) is emitted with kth = -2 - row, which ts_kth_fixup_kernel resolves.
-template <int CTRL>
-__device__ __forceinline__ int dpp_row16(int v) {
-    return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true);
-}
-
-__global__ __launch_bounds__(kBlock) void ts_match_longq_kernel(
-    const Row *__restrict__ rows, int64_t n_rows, const int64_t *__restrict__ keys,
-    const int64_t *__restrict__ sq, const int32_t *__restrict__ smult, int32_t m, int32_t min_match,
-    int32_t cap, int32_t *__restrict__ hits, int32_t *__restrict__ hits_n) {
-    const int gl = threadIdx.x & (kGroup - 1);
-    const int64_t r = (int64_t)blockIdx.x * kGroupsPerBlock + threadIdx.x / kGroup;
-    if (r >= n_rows) return;                       // whole 16-lane groups leave together
-    const Row row = rows[r];
-    const int64_t *rk = keys + row.off;
-    int cnt = 0;
-    for (int i = gl; i < row.len; i += kGroup) {
-        const int64_t k = rk[i];
-        int lo = 0, hi = m;
-        while (lo < hi) {
-            const int mid = (lo + hi) >> 1;
-            if (sq[mid] < k) lo = mid + 1; else hi = mid;
-        }
-        if (lo < m && sq[lo] == k) cnt += smult[lo];
-    }
-    cnt += dpp_row16<0xB1>(cnt);    // quad_perm [1,0,3,2]
-    cnt += dpp_row16<0x4E>(cnt);    // quad_perm [2,3,0,1]
-    cnt += dpp_row16<0x141>(cnt);   // row_half_mirror
-    cnt += dpp_row16<0x140>(cnt);   // row_mirror
-    if (gl == 0 && cnt >= min_match) {
-        const int slot = atomicAdd(&hits_n[0], 1);
-        if (slot < cap) {
-            hits[slot * 3 + 0] = row.vid;
-            hits[slot * 3 + 1] = cnt;
-            hits[slot * 3 + 2] = (min_match <= 0) ? -1 : -2 - (int32_t)r;
-        }
-    }
-}
-
-// kth for min_match > 5: per stored hit, walk the query in order and binary-search the row.
-__global__ __launch_bounds__(kBlock) void ts_kth_fixup_kernel(
-    const Row *__restrict__ rows, const int64_t *__restrict__ keys,
-    const double *__restrict__ queries, const int64_t *__restrict__ q_offsets, int32_t min_match,
-    int32_t cap, int32_t *__restrict__ hits, const int32_t *__restrict__ hits_n) {
-    const int q = blockIdx.x;
-    const int gl = threadIdx.x & (kGroup - 1);
-    const int g = threadIdx.x / kGroup;
-    const int gshift = (threadIdx.x & 63) & ~(kGroup - 1);
-    int n = hits_n[q];
-    if (n > cap) n = cap;
-    const int64_t qo = q_offsets[q];
-    const int32_t qlen = (int32_t)(q_offsets[q + 1] - qo);
-    const double *qv = queries + qo;
-    for (int j = g; j < n; j += kGroupsPerBlock) {
-        int32_t *h = hits + ((int64_t)q * cap + j) * 3;
-        const int32_t code = h[2];
-        if (code > -2) continue;
-        const Row row = rows[-2 - code];
-        const int64_t *rk = keys + row.off;
-        int kth = TVZ_KTH_NEVER;
-        int running = 0;
-        for (int base = 0; base < qlen && kth == TVZ_KTH_NEVER; base += kGroup) {
-            const int i = base + gl;
-            bool hit = false;
-            int64_t k;
-            if (i < qlen && canon_key(qv[i], k)) {
-                int lo = 0, hi = row.len;
-                while (lo < hi) {
-                    const int mid = (lo + hi) >> 1;
-                    if (rk[mid] < k) lo = mid + 1; else hi = mid;
-                }
-                hit = lo < row.len && rk[lo] == k;
-            }
-            const uint32_t m16 = (uint32_t)(__ballot(hit) >> gshift) & 0xffffu;
-            const int c = __popc(m16);
-            if (running + c >= min_match) {
-                uint32_t m = m16;
-                for (int need = min_match - running; need > 1; --need) m &= m - 1;
-                kth = base + (__ffs(m) - 1);
-            }
-            running += c;
-        }
-        if (gl == 0) h[2] = kth;
-    }
-}
-
-// ---------------------------------------------------------------- top-k
-constexpr int kSortCap = 2048;
-
-__device__ __forceinline__ uint64_t sort_key(int32_t vid, int32_t kth) {
-    return ((uint64_t)(uint32_t)(kth + 1) << 32) | (uint32_t)vid;
-}
-
-__device__ void bitonic_sort(uint64_t *key, int32_t *cnt, int n /* power of two */) {
-    for (int size = 2; size <= n; size <<= 1) {
-        for (int stride = size >> 1; stride > 0; stride >>= 1) {
-            __syncthreads();
-            for (int i = threadIdx.x; i < n / 2; i += blockDim.x) {
-                const int lo = 2 * i - (i & (stride - 1));
-                const int hi = lo + stride;
-                const bool up = (lo & size) == 0;
-                const uint64_t a = key[lo], b = key[hi];
-                const int32_t ca = cnt[lo], cb = cnt[hi];
-                const bool gt = (a > b) || (a == b && ca > cb);
-                if (gt == up) {
-                    key[lo] = b; key[hi] = a;
-                    cnt[lo] = cb; cnt[hi] = ca;
-                }
-            }
-        }
-    }
-    __syncthreads();
-}
-
-__global__ __launch_bounds__(kBlock) void ts_topk_kernel(const int32_t *__restrict__ lists,
-                                                         const int32_t *__restrict__ lists_n,
-                                                         int32_t n_lists, int32_t Q, int32_t cap,
-                                                         int32_t k, int32_t *__restrict__ topk,
-                                                         int32_t mode, int32_t *__restrict__ totals) {
-    // mode 0: plain.  mode 1 (shard side): the output has k+1 rows per query, row k carries the
-    // true number of hits as (-1, n, NEVER) so one all-gather moves lists and totals together; n is
-    // NEGATED when the shard's hit list overflowed its capacity (its top-k may then be inexact).
-    // mode 2 (merge side): every input list ends with such a row; |n| is summed into totals[q], and
-    // the sum is negated if any shard overflowed, so the caller knows to re-run with a larger cap.
-    __shared__ uint64_t key[kSortCap];
-    __shared__ int32_t cnt[kSortCap];
-    const int q = blockIdx.x;
-    int pos = 0;  // block-uniform fill level
-    long long total = 0;
-    bool overflow = false;
-    auto sort_and_keep = [&]() {
-        int P = 2;
-        while (P < pos) P <<= 1;
-        for (int i = pos + threadIdx.x; i < P; i += kBlock) { key[i] = ~0ULL; cnt[i] = 0; }
-        bitonic_sort(key, cnt, P);
-        if (pos > k) pos = k;
-    };
-    for (int l = 0; l < n_lists; ++l) {
-        int n = lists_n ? lists_n[(int64_t)l * Q + q] : cap;
-        const int32_t *src = lists + ((int64_t)l * Q + q) * (int64_t)cap * 3;
-        if (mode == 1) {
-            total += n;
-            if (n > cap) overflow = true;          // this shard's list was truncated
-        }
-        if (n > cap) n = cap;
-        if (mode == 2) {
-            n = cap - 1;
-            const int32_t t = src[(cap - 1) * 3 + 1];   // negative: that shard overflowed
-            total += t < 0 ? -(long long)t : t;
-            if (t < 0) overflow = true;
-        }
-        int j = 0;
-        while (j < n) {
-            int m = n - j;
-            if (m > kSortCap - pos) m = kSortCap - pos;
-            for (int i = threadIdx.x; i < m; i += kBlock) {
-                const int32_t vid = src[(j + i) * 3 + 0];
-                key[pos + i] = vid < 0 ? ~0ULL : sort_key(vid, src[(j + i) * 3 + 2]);
-                cnt[pos + i] = src[(j + i) * 3 + 1];
-            }
-            pos += m;
-            j += m;
-            __syncthreads();
-            if (pos == kSortCap) sort_and_keep();
-        }
-    }
-    __syncthreads();
-    sort_and_keep();
-    const int orows = (mode == 1) ? k + 1 : k;
-    if (threadIdx.x == 0) {
-        int32_t t = total > 0x7fffffffLL ? 0x7fffffff : (int32_t)total;
-        if (overflow) t = (t == 0) ? INT32_MIN : -t;   // negative total = some hit list was truncated
-        if (mode == 1) {
-            int32_t *o = topk + ((int64_t)q * orows + k) * 3;
-            o[0] = -1; o[1] = t; o[2] = TVZ_KTH_NEVER;
-        } else if (mode == 2 && totals) {
-            totals[q] = t;
-        }
-    }
-    for (int i = threadIdx.x; i < k; i += kBlock) {
-        int32_t *o = topk + ((int64_t)q * orows + i) * 3;
-        const uint64_t kk = (i < pos) ? key[i] : ~0ULL;
-        if (kk == ~0ULL) {
-            o[0] = -1; o[1] = 0; o[2] = TVZ_KTH_NEVER;
-        } else {
-            o[0] = (int32_t)(uint32_t)kk;
-            o[1] = cnt[i];
-            o[2] = (int32_t)(uint32_t)(kk >> 32) - 1;
-        }
-    }
-}
-
-// ---------------------------------------------------------------- opt-in alignment score
-// NOT the reference's verdict (db.py:79 is exact-only); north_star's "alignment/Jaccard" and the
-// stale README.md:291 ("0.1 s tolerance") ask for a shift/tolerance-aware score, reported alongside.
-// One wave per row: every (query_i, row_j) difference votes into an LDS histogram of bins of
-// width eps over [-max_offset, +max_offset]; output = best bin (ties: smaller |bin|, then the
-// negative one), its votes, and the votes of bin 0 (tolerant count without shift).
-constexpr int kAlignMaxBins = 4096;   // 16 KB of u32 per wave, 4 waves per block
-
-__global__ __launch_bounds__(kBlock) void ts_align_kernel(
-    const Row *__restrict__ rows, int64_t n_rows, const int64_t *__restrict__ keys,
-    const double *__restrict__ query, int32_t n, double eps, int32_t B,
-    int32_t *__restrict__ out) {
-    __shared__ uint32_t hist_all[kBlock / 64][kAlignMaxBins];
-    const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
-    uint32_t *hist = hist_all[wave];
-    const int nbins = 2 * B + 1;
-    for (int64_t r = (int64_t)blockIdx.x * (kBlock / 64) + wave; r < n_rows;
-         r += (int64_t)gridDim.x * (kBlock / 64)) {
-        const Row row = rows[r];
-        for (int b = lane; b < nbins; b += 64) hist[b] = 0;
-        const int64_t *rk = keys + row.off;
-        for (int j = lane; j < row.len; j += 64) {
-            const double c = __longlong_as_double(rk[j]);
-            for (int i = 0; i < n; ++i) {
-                const double q = query[i];
-                if (q != q) continue;                              // NaN never aligns
-                const double d = floor((c - q) / eps + 0.5);
-                if (d >= -(double)B && d <= (double)B) atomicAdd(&hist[(int)d + B], 1u);
-            }
-        }
-        // LDS ops of one wave complete in order: the votes above are visible to the scan below
-        unsigned long long best = 0;
-        for (int b = lane; b < nbins; b += 64) {
-            const int bin = b - B;
-            const uint32_t order = 2u * (uint32_t)(bin < 0 ? -bin : bin) + (bin > 0 ? 1u : 0u);
-            const unsigned long long key = ((unsigned long long)hist[b] << 14) | (16383u - order);
-            best = key > best ? key : best;
-        }
-        for (int off = 32; off > 0; off >>= 1) {
-            const unsigned long long o = __shfl_xor(best, off);
-            best = o > best ? o : best;
-        }
-        if (lane == 0) {
-            const uint32_t order = 16383u - (uint32_t)(best & 16383u);
-            const int mag = (int)(order >> 1);
-            int32_t *o = out + r * 5;
-            o[0] = row.vid;
-            o[1] = row.len;
-            o[2] = (order & 1u) ? mag : -mag;
-            o[3] = (int32_t)(best >> 14);
-            o[4] = (int32_t)hist[B];
-        }
-    }
-}
-
-// ---------------------------------------------------------------- host side
-struct Staging {
-    hipStream_t stream = nullptr;
-    double *d_query = nullptr;   int64_t query_cap = 0;
-    int64_t *d_qoff = nullptr;
-    int32_t *d_hits = nullptr;   int64_t hits_cap = 0;
-    int32_t *d_hits_n = nullptr;
-    int32_t *h_hits = nullptr;   // pinned, hits_cap entries
-    int64_t *d_sq = nullptr;     int32_t *d_smult = nullptr;  int64_t sq_cap = 0;  // long queries
-    int64_t *h_small = nullptr;                          // pinned: qoff[2] + hits_n
-};
-
-// device tables of one hash join; reusable once `done` has completed
-struct JoinWs {
-    unsigned char *base = nullptr;
-    size_t bytes = 0;
-    hipEvent_t done = nullptr;
-    bool busy = false;
-};
 
 template <typename T>
 struct DevBuf {
@@ -838,11 +33,42 @@ struct DevBuf {
     int64_t cap = 0;
 };
 
+// Per-thread-of-control scratch of tvz_find_duplicates: its own stream, a pinned query buffer
+// and a pinned, device-mapped hit buffer the kernel writes into.  Sized at create / reserve /
+// upload for the reserved row count, so a query allocates nothing.
+struct Staging {
+    hipStream_t stream = nullptr;
+    int64_t *h_query = nullptr;      // pinned: {0, n} + canonical-order query keys (as double bits)
+    int64_t *d_query = nullptr;      // device copy of the same
+    int32_t *h_hits = nullptr;       // pinned + mapped: [blocks][region][3]
+    int32_t *dh_hits = nullptr;      // the device alias of h_hits
+    int32_t *h_counts = nullptr;     // pinned + mapped: [kQ1MaxBlocks]
+    int32_t *dh_counts = nullptr;
+    int64_t hit_slots = 0;           // capacity of h_hits in hits
+    int32_t *d_hits = nullptr;       // device hit list for the paths that need a fix-up pass
+    int32_t *d_hits_n = nullptr;
+    int64_t d_hit_slots = 0;
+    int64_t *d_sq = nullptr;         // long queries: sorted distinct keys + multiplicities
+    int32_t *d_smult = nullptr;
+    int64_t sq_cap = 0;
+};
+
+constexpr int kQ1MaxBlocks = 2048;
+constexpr int64_t kQueryStageKeys = kMaxQueryLen + 1;
+constexpr int kRingSlots = 16;                    // pinned upsert payload ring
+constexpr int64_t kRingSlotKeys = 8192;           // 64 KiB each
+
+struct RingSlot {
+    int64_t *h = nullptr;
+    hipEvent_t ev = nullptr;
+    bool pending = false;
+};
+
 }  // namespace
 
 struct tvz_corpus {
     int device = 0;
-    std::shared_mutex mu;        // exclusive: mutation; shared: enqueueing a match
+    std::shared_mutex mu;        // exclusive: host bookkeeping of a mutation; shared: enqueueing a match
     std::mutex ev_mu;
     std::mutex stage_mu;
     DevBuf<int64_t> keys;
@@ -851,13 +77,19 @@ struct tvz_corpus {
     std::vector<Row> h_rows;
     std::unordered_map<int32_t, int64_t> first_row;  // video_id -> first row index
     int64_t live_keys = 0;
+    // matches in flight (only compaction / reallocation / upload / destroy wait for them)
     static constexpr int kEvents = 32;
     hipEvent_t events[kEvents] = {};
     bool ev_pending[kEvents] = {};
     int ev_next = 0;
+    // mutation stream: upsert payload copies + row swaps, in order
+    hipStream_t mstream = nullptr;
+    hipEvent_t mut_done = nullptr;   // re-recorded after every mutation; matches wait on it
+    bool mut_any = false;
+    RingSlot ring[kRingSlots];
+    int ring_next = 0;
     std::vector<Staging *> free_staging;
-    std::mutex join_mu;
-    std::vector<JoinWs *> join_ws;   // tables of in-flight / reusable hash joins
+    int64_t stage_rows = 0;          // rows the stagings are sized for
 };
 
 namespace {
@@ -885,6 +117,7 @@ int64_t canon_row(const double *src, int64_t n, std::vector<int64_t> &out) {
     return len;
 }
 
+// grow a device buffer (the caller has drained every reader); old contents [0, keep) survive
 template <typename T>
 int ensure(DevBuf<T> &b, int64_t need, int64_t keep) {
     if (need <= b.cap) return TVZ_OK;
@@ -894,21 +127,32 @@ int ensure(DevBuf<T> &b, int64_t need, int64_t keep) {
     if (hipMalloc(&np, (size_t)cap * sizeof(T)) != hipSuccess)
         return tvz::fail(TVZ_ERR_NOMEM, "hipMalloc of %lld bytes failed",
                          (long long)(cap * (int64_t)sizeof(T)));
-    if (b.p && keep > 0) TVZ_HIP(hipMemcpy(np, b.p, (size_t)keep * sizeof(T), hipMemcpyDeviceToDevice));
+    if (b.p && keep > 0) {
+        const hipError_t e = hipMemcpy(np, b.p, (size_t)keep * sizeof(T), hipMemcpyDeviceToDevice);
+        if (e != hipSuccess) {
+            (void)hipFree(np);
+            return tvz::fail(TVZ_ERR_HIP, "device copy while growing a corpus buffer failed: %s",
+                             hipGetErrorString(e));
+        }
+    }
     if (b.p) (void)hipFree(b.p);
     b.p = np;
     b.cap = cap;
     return TVZ_OK;
 }
 
-// wait for every match kernel enqueued so far (caller holds mu exclusively)
+// wait for every match enqueued so far and for the mutation stream (caller holds mu exclusively)
 int drain(tvz_corpus *c) {
-    std::lock_guard<std::mutex> lk(c->ev_mu);
-    for (int i = 0; i < tvz_corpus::kEvents; ++i)
-        if (c->ev_pending[i]) {
-            TVZ_HIP(hipEventSynchronize(c->events[i]));
-            c->ev_pending[i] = false;
-        }
+    {
+        std::lock_guard<std::mutex> lk(c->ev_mu);
+        for (int i = 0; i < tvz_corpus::kEvents; ++i)
+            if (c->ev_pending[i]) {
+                TVZ_HIP(hipEventSynchronize(c->events[i]));
+                c->ev_pending[i] = false;
+            }
+    }
+    TVZ_HIP(hipStreamSynchronize(c->mstream));
+    for (RingSlot &s : c->ring) s.pending = false;
     return TVZ_OK;
 }
 
@@ -922,9 +166,18 @@ int record(tvz_corpus *c, hipStream_t st) {
     return TVZ_OK;
 }
 
-int upload_all(tvz_corpus *c) {
-    if (int rc = ensure(c->keys, (int64_t)c->h_keys.size() + 2, 0)) return rc;
-    if (int rc = ensure(c->rows, (int64_t)c->h_rows.size() + 1, 0)) return rc;
+// every sweep enqueued from now on sees the mutations that have returned (caller holds mu shared)
+int wait_mutations(tvz_corpus *c, hipStream_t st) {
+    if (c->mut_any) TVZ_HIP(hipStreamWaitEvent(st, c->mut_done, 0));
+    return TVZ_OK;
+}
+
+// whole host mirror -> device (caller holds mu exclusively and has drained)
+int upload_all(tvz_corpus *c, int64_t want_rows, int64_t want_keys) {
+    want_keys = std::max<int64_t>(want_keys, (int64_t)c->h_keys.size() + 2);
+    want_rows = std::max<int64_t>(want_rows, (int64_t)c->h_rows.size() + 1);
+    if (int rc = ensure(c->keys, want_keys, 0)) return rc;
+    if (int rc = ensure(c->rows, want_rows, 0)) return rc;
     if (!c->h_keys.empty())
         TVZ_HIP(hipMemcpy(c->keys.p, c->h_keys.data(), c->h_keys.size() * 8, hipMemcpyHostToDevice));
     if (!c->h_rows.empty())
@@ -943,124 +196,48 @@ int compact(tvz_corpus *c) {
         r.off = off;
     }
     c->h_keys.swap(nk);
-    return upload_all(c);
+    return upload_all(c, 0, 0);
 }
 
-// Dispatch (measured A/B grid, profiles/r1_match_join_ab.txt): the join wins once its fixed cost
-// (table memset + build, ~30 us) is amortised, i.e. from about 5 M (query, row) pairs per batch:
-// C=100k x Q=1024: 1.18 ms vs 2.30 ms for the LDS tile kernel, C=5k x Q=1024: 0.138 vs 0.165,
-// C=20k x Q=256: 0.177 vs 0.198; below that (C=5k x Q=256: 0.109 vs 0.076) the tile kernel wins.
-constexpr int kJoinMinQ = 64;
-constexpr int64_t kJoinMinPairs = 5000000;
-int g_use_join = 1;             // 0 = never, 1 = by the rule above, 2 = whenever legal (A/B knob)
+// ---- single-query staging --------------------------------------------------------------------
+void staging_free(Staging *s) {
+    if (s->h_query) (void)hipHostFree(s->h_query);
+    if (s->d_query) (void)hipFree(s->d_query);
+    if (s->h_hits) (void)hipHostFree(s->h_hits);
+    if (s->h_counts) (void)hipHostFree(s->h_counts);
+    if (s->d_hits) (void)hipFree(s->d_hits);
+    if (s->d_hits_n) (void)hipFree(s->d_hits_n);
+    if (s->d_sq) (void)hipFree(s->d_sq);
+    if (s->d_smult) (void)hipFree(s->d_smult);
+    if (s->stream) (void)hipStreamDestroy(s->stream);
+    delete s;
+}
 
-int join_ws_get(tvz_corpus *c, size_t bytes, JoinWs **out) {
-    std::lock_guard<std::mutex> lk(c->join_mu);
-    for (JoinWs *w : c->join_ws)
-        if (!w->busy || hipEventQuery(w->done) == hipSuccess) {
-            w->busy = true;
-            if (w->bytes < bytes) {
-                if (w->base) (void)hipFree(w->base);
-                w->base = nullptr;
-                TVZ_HIP(hipMalloc(&w->base, bytes));
-                w->bytes = bytes;
-            }
-            *out = w;
-            return TVZ_OK;
-        }
-    JoinWs *w = new JoinWs();
-    TVZ_HIP(hipEventCreateWithFlags(&w->done, hipEventDisableTiming));
-    TVZ_HIP(hipMalloc(&w->base, bytes));
-    w->bytes = bytes;
-    w->busy = true;
-    c->join_ws.push_back(w);
-    *out = w;
+// room for the hits of `rows` corpus rows (every block's region rounds up to whole row groups)
+int staging_size(Staging *s, int64_t rows) {
+    const int64_t slots = rows + (int64_t)kQ1MaxBlocks * kQ1Groups;
+    if (slots <= s->hit_slots) return TVZ_OK;
+    if (s->h_hits) (void)hipHostFree(s->h_hits);
+    s->h_hits = nullptr;
+    s->hit_slots = 0;
+    TVZ_HIP(hipHostMalloc(&s->h_hits, (size_t)slots * 12, hipHostMallocMapped));
+    TVZ_HIP(hipHostGetDevicePointer(reinterpret_cast<void **>(&s->dh_hits), s->h_hits, 0));
+    s->hit_slots = slots;
     return TVZ_OK;
 }
 
-int launch_join(tvz_corpus *c, const double *d_queries, const int64_t *d_q_offsets, int32_t Q,
-                int32_t max_query_len, int32_t min_match, const int32_t *d_exclude_ids,
-                int32_t cap, int32_t *d_hits, int32_t *d_hits_n, hipStream_t st) {
-    const int64_t n_rows = (int64_t)c->h_rows.size();
-    const int n_tiles = (int)tvz::ceil_div(Q, kJoinQ);
-    // slots per tile: load factor <= 0.5 (typically ~0.25) AND small enough to live in one XCD's
-    // 4 MiB L2 next to the streamed corpus (2 MiB at max_query_len <= 512); a table of 4 MiB was
-    // measured at the Infinity-Cache random-line rate (8.5 TB/s) instead of the L2's
-    int s_log2 = 10;
-    while (((int64_t)1 << s_log2) < (int64_t)2 * kJoinQ * max_query_len) ++s_log2;
-    const size_t S = (size_t)1 << s_log2;
-    const size_t b_keys = (size_t)n_tiles * S * 8, b_pack = (size_t)n_tiles * S * 4;
-    const size_t b_bloom = (size_t)n_tiles * (kJoinBloomBits / 8);
-    JoinWs *ws = nullptr;
-    if (int rc = join_ws_get(c, b_keys + b_pack + b_bloom, &ws)) return rc;
-    unsigned long long *tkeys = reinterpret_cast<unsigned long long *>(ws->base);
-    uint32_t *tpack = reinterpret_cast<uint32_t *>(ws->base + b_keys);
-    uint32_t *tbloom = reinterpret_cast<uint32_t *>(ws->base + b_keys + b_pack);
-    TVZ_HIP(hipMemsetAsync(ws->base, 0xff, b_keys, st));    // every key = kJEmpty
-    TVZ_HIP(hipMemsetAsync(tbloom, 0, b_bloom, st));
-    hipLaunchKernelGGL(ts_join_build_kernel, dim3((unsigned)tvz::ceil_div(max_query_len, kBlock), (unsigned)Q),
-                       dim3(kBlock), 0, st, d_queries, d_q_offsets, Q, max_query_len, s_log2, tkeys, tpack,
-                       tbloom, d_hits_n);
-    TVZ_HIP(hipGetLastError());
-    // two 1024-thread blocks per CU: about two rounds of 512 blocks, >= 8 rows per 16-lane group
-    const int64_t g = (8 % n_tiles == 0) ? 8 / n_tiles : 1;
-    int64_t chunks = std::max<int64_t>(1, 1024 / n_tiles);
-    chunks = std::min(chunks, std::max<int64_t>(1, n_rows / (2 * kJoinGroups)));
-    chunks = tvz::round_up(chunks, g);
-    const int64_t rpb = tvz::round_up(tvz::ceil_div(n_rows, chunks), kJoinGroups);
-    int64_t blocks = (int64_t)n_tiles * chunks;
-    if (8 % n_tiles == 0) blocks = tvz::round_up(blocks, 8);
-    hipLaunchKernelGGL(ts_match_join_kernel, dim3((unsigned)blocks), dim3(kJoinBlock), kJoinLds, st,
-                       c->rows.p, n_rows, c->keys.p, reinterpret_cast<const int64_t *>(tkeys), tpack, tbloom,
-                       s_log2, Q, n_tiles, (int32_t)chunks, min_match, d_exclude_ids, cap, d_hits,
-                       d_hits_n, (int32_t)rpb);
-    TVZ_HIP(hipGetLastError());
-    TVZ_HIP(hipEventRecord(ws->done, st));                  // the tables are free again after this
-    return TVZ_OK;
-}
-
-int launch_match(tvz_corpus *c, const double *d_queries, const int64_t *d_q_offsets, int32_t Q,
-                 int32_t max_query_len, int32_t min_match, const int32_t *d_exclude_ids,
-                 int32_t cap, int32_t *d_hits, int32_t *d_hits_n, hipStream_t st) {
-    if (max_query_len > kMaxQueryLen)
-        return tvz::fail(TVZ_ERR_UNSUPPORTED, "query of %d timestamps exceeds the supported %d",
-                         max_query_len, kMaxQueryLen);
-    TVZ_HIP(hipMemsetAsync(d_hits_n, 0, (size_t)Q * sizeof(int32_t), st));
-    const int64_t n_rows = (int64_t)c->h_rows.size();
-    if (n_rows == 0 || Q == 0) return TVZ_OK;
-    const bool join_legal = min_match <= 2 && max_query_len > 0;
-    if (join_legal && (g_use_join == 2 || (g_use_join == 1 && Q >= kJoinMinQ && (int64_t)Q * n_rows >= kJoinMinPairs)))
-        return launch_join(c, d_queries, d_q_offsets, Q, max_query_len, min_match, d_exclude_ids, cap,
-                           d_hits, d_hits_n, st);
-    // queries per tile: as many as keep the shared table at load <= 0.5 (at most 16)
-    int nq = max_query_len > 0 ? kTileMaxEntries / max_query_len : kTileQ;
-    nq = std::max(1, std::min(nq, kTileQ));
-    const int64_t tiles = tvz::ceil_div(Q, nq);
-    // one 1024-thread block per CU (LDS): aim at just under two full rounds of 256 blocks (a
-    // third, mostly empty round costs a whole block time), but >= 2 rows per 16-lane group so
-    // that building the tile's table (per block) stays a small part of the block's life
-    int64_t chunks = std::max<int64_t>(1, 512 / tiles);
-    chunks = std::min(chunks, std::max<int64_t>(1, n_rows / (2 * kTileGroups)));
-    const int64_t rpb = tvz::round_up(tvz::ceil_div(n_rows, chunks), kTileGroups);
-    chunks = tvz::ceil_div(n_rows, rpb);
-    if (tiles > 65535)
-        return tvz::fail(TVZ_ERR_UNSUPPORTED, "too many query tiles (%lld)", (long long)tiles);
-    if (min_match <= 2)
-        hipLaunchKernelGGL(ts_match_tile_kernel<false>, dim3((unsigned)chunks, (unsigned)tiles),
-                           dim3(kTileBlock), kTileLds, st, c->rows.p, n_rows, c->keys.p, d_queries,
-                           d_q_offsets, Q, nq, min_match, d_exclude_ids, cap, d_hits, d_hits_n,
-                           (int32_t)rpb);
-    else
-        hipLaunchKernelGGL(ts_match_tile_kernel<true>, dim3((unsigned)chunks, (unsigned)tiles),
-                           dim3(kTileBlock), kTileLds, st, c->rows.p, n_rows, c->keys.p, d_queries,
-                           d_q_offsets, Q, nq, min_match, d_exclude_ids, cap, d_hits, d_hits_n,
-                           (int32_t)rpb);
-    TVZ_HIP(hipGetLastError());
-    if (min_match > kTop) {
-        hipLaunchKernelGGL(ts_kth_fixup_kernel, dim3((unsigned)Q), dim3(kBlock), 0, st, c->rows.p,
-                           c->keys.p, d_queries, d_q_offsets, min_match, cap, d_hits, d_hits_n);
-        TVZ_HIP(hipGetLastError());
-    }
+int staging_new(tvz_corpus *c, Staging **out) {
+    Staging *s = new Staging();
+    struct Guard { Staging *s; ~Guard() { if (s) staging_free(s); } } g{s};
+    TVZ_HIP(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+    TVZ_HIP(hipHostMalloc(&s->h_query, (size_t)(kQueryStageKeys + 2) * 8, hipHostMallocDefault));
+    TVZ_HIP(hipMalloc(&s->d_query, (size_t)(kQueryStageKeys + 2) * 8));
+    TVZ_HIP(hipHostMalloc(&s->h_counts, (size_t)kQ1MaxBlocks * 4, hipHostMallocMapped));
+    TVZ_HIP(hipHostGetDevicePointer(reinterpret_cast<void **>(&s->dh_counts), s->h_counts, 0));
+    TVZ_HIP(hipMalloc(&s->d_hits_n, sizeof(int32_t)));
+    if (int rc = staging_size(s, c->stage_rows)) return rc;
+    g.s = nullptr;
+    *out = s;
     return TVZ_OK;
 }
 
@@ -1073,13 +250,7 @@ int staging_get(tvz_corpus *c, Staging **out) {
             return TVZ_OK;
         }
     }
-    Staging *s = new Staging();
-    TVZ_HIP(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
-    TVZ_HIP(hipMalloc(&s->d_qoff, 2 * sizeof(int64_t)));
-    TVZ_HIP(hipMalloc(&s->d_hits_n, sizeof(int32_t)));
-    TVZ_HIP(hipHostMalloc(&s->h_small, 4 * sizeof(int64_t)));
-    *out = s;
-    return TVZ_OK;
+    return staging_new(c, out);   // more concurrent callers than pre-built stagings
 }
 
 void staging_put(tvz_corpus *c, Staging *s) {
@@ -1087,20 +258,280 @@ void staging_put(tvz_corpus *c, Staging *s) {
     c->free_staging.push_back(s);
 }
 
-void staging_free(Staging *s) {
-    if (s->d_query) (void)hipFree(s->d_query);
-    if (s->d_qoff) (void)hipFree(s->d_qoff);
-    if (s->d_hits) (void)hipFree(s->d_hits);
-    if (s->d_hits_n) (void)hipFree(s->d_hits_n);
-    if (s->h_hits) (void)hipHostFree(s->h_hits);
-    if (s->h_small) (void)hipHostFree(s->h_small);
-    if (s->d_sq) (void)hipFree(s->d_sq);
-    if (s->d_smult) (void)hipFree(s->d_smult);
-    if (s->stream) (void)hipStreamDestroy(s->stream);
-    delete s;
+// reserve device + staging capacity (caller holds mu exclusively; drains only if it must grow)
+int reserve_locked(tvz_corpus *c, int64_t n_rows, int64_t n_keys) {
+    if (n_keys + 2 > c->keys.cap || n_rows + 1 > c->rows.cap) {
+        if (int rc = drain(c)) return rc;
+        if (int rc = ensure(c->keys, n_keys + 2, (int64_t)c->h_keys.size())) return rc;
+        if (int rc = ensure(c->rows, n_rows + 1, (int64_t)c->h_rows.size())) return rc;
+    }
+    if (n_rows > c->stage_rows) {
+        std::lock_guard<std::mutex> lk(c->stage_mu);
+        c->stage_rows = n_rows;
+        for (Staging *s : c->free_staging)
+            if (int rc = staging_size(s, c->stage_rows)) return rc;
+    }
+    return TVZ_OK;
+}
+
+// ---- workspace layout of the batched calls -------------------------------------------------
+struct JoinShape {
+    int n_tiles = 0;
+    int s_log2 = 0;
+    size_t b_keys = 0, b_pack = 0, b_bloom = 0;
+    size_t bytes() const { return b_keys + b_pack + b_bloom; }
+};
+
+JoinShape join_shape(int32_t Q, int32_t max_query_len) {
+    JoinShape j;
+    if (Q <= 0 || max_query_len <= 0) return j;
+    j.n_tiles = (int)tvz::ceil_div(Q, kJoinQ);
+    // slots per tile: load factor <= 0.5 (typically ~0.25) AND small enough to live in one XCD's
+    // 4 MiB L2 next to the streamed corpus (2 MiB at max_query_len <= 512); a table of 4 MiB was
+    // measured at the Infinity-Cache random-line rate instead of the L2's
+    j.s_log2 = 10;
+    while (((int64_t)1 << j.s_log2) < (int64_t)2 * kJoinQ * max_query_len) ++j.s_log2;
+    const size_t S = (size_t)1 << j.s_log2;
+    j.b_keys = (size_t)j.n_tiles * S * 8;
+    j.b_pack = (size_t)j.n_tiles * S * 4;
+    j.b_bloom = (size_t)j.n_tiles * (kJoinBloomBits / 8);
+    return j;
+}
+
+struct WsLayout {
+    unsigned char *join = nullptr;  size_t join_bytes = 0;
+    int32_t *hits = nullptr;        // [Q][cap][3]
+    int32_t *hits_n = nullptr;      // [Q]
+    int32_t *local = nullptr;       // [Q][k+1][3]
+    int32_t *gathered = nullptr;    // [n_ranks][Q][k+1][3]
+    size_t total = 0;
+};
+
+size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+WsLayout ws_layout(void *base, int32_t Q, int32_t max_query_len, int32_t cap, int32_t k,
+                   int32_t n_ranks) {
+    WsLayout w;
+    uintptr_t p = (reinterpret_cast<uintptr_t>(base) + 255) & ~(uintptr_t)255;
+    const uintptr_t p0 = p;
+    w.join_bytes = join_shape(Q, max_query_len).bytes();
+    w.join = reinterpret_cast<unsigned char *>(p);
+    p += al256(w.join_bytes);
+    if (k > 0) {
+        w.hits = reinterpret_cast<int32_t *>(p);
+        p += al256((size_t)Q * (size_t)cap * 12);
+        w.hits_n = reinterpret_cast<int32_t *>(p);
+        p += al256((size_t)Q * 4);
+        w.local = reinterpret_cast<int32_t *>(p);
+        p += al256((size_t)Q * (size_t)(k + 1) * 12);
+        w.gathered = reinterpret_cast<int32_t *>(p);
+        p += al256((size_t)(n_ranks > 1 ? n_ranks : 1) * (size_t)Q * (size_t)(k + 1) * 12);
+    }
+    w.total = (size_t)(p - p0) + 256;
+    return w;
+}
+
+// Dispatch (A/B grids under profiles/): the per-query sweep wins for a handful of queries (each
+// streams the corpus once, no shared table to build); the hash join wins once its fixed cost
+// (table clear + build) is amortised; the LDS tile in between and for min_match > 2.
+constexpr int kQ1MaxQ = 8;
+constexpr int kJoinMinQ = 64;
+constexpr int64_t kJoinMinPairs = 5000000;
+
+int pick_algo(int32_t algo, int32_t Q, int64_t n_rows, int32_t max_query_len, int32_t min_match) {
+    const bool join_legal = min_match <= 2 && max_query_len > 0;
+    if (algo == TVZ_ALGO_AUTO) {
+        if (Q <= kQ1MaxQ) return TVZ_ALGO_Q1;
+        if (join_legal && Q >= kJoinMinQ && (int64_t)Q * n_rows >= kJoinMinPairs) return TVZ_ALGO_JOIN;
+        return TVZ_ALGO_TILE;
+    }
+    if (algo == TVZ_ALGO_JOIN && !join_legal) return TVZ_ALGO_TILE;   // documented: min_match <= 2 only
+    return algo;
+}
+
+int launch_prep(int32_t *d_hits_n, int32_t Q, void *ones, size_t ones_bytes, void *zeros,
+                size_t zero_bytes, hipStream_t st) {
+    const size_t work = std::max<size_t>((size_t)Q, std::max(ones_bytes, zero_bytes) / 16);
+    const int blocks = (int)std::min<size_t>(std::max<size_t>(1, tvz::ceil_div((int64_t)work, kBlock * 4)), 1024);
+    hipLaunchKernelGGL(ts_prep_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, st, d_hits_n, Q,
+                       reinterpret_cast<uint4 *>(ones), ones_bytes / 16,
+                       reinterpret_cast<uint4 *>(zeros), zero_bytes / 16);
+    TVZ_HIP(hipGetLastError());
+    return TVZ_OK;
+}
+
+int launch_join(tvz_corpus *c, const double *d_queries, const int64_t *d_q_offsets, int32_t Q,
+                int32_t max_query_len, int32_t min_match, const int32_t *d_exclude_ids,
+                int32_t cap, int32_t *d_hits, int32_t *d_hits_n, unsigned char *ws, size_t ws_bytes,
+                hipStream_t st) {
+    const int64_t n_rows = (int64_t)c->h_rows.size();
+    const JoinShape j = join_shape(Q, max_query_len);
+    if (ws == nullptr || ws_bytes < j.bytes())
+        return tvz::fail(TVZ_ERR_WORKSPACE, "hash join needs a workspace of %zu bytes (got %zu): size it "
+                                            "with tvz_match_workspace_bytes", j.bytes(), ws_bytes);
+    unsigned long long *tkeys = reinterpret_cast<unsigned long long *>(ws);
+    uint32_t *tpack = reinterpret_cast<uint32_t *>(ws + j.b_keys);
+    uint32_t *tbloom = reinterpret_cast<uint32_t *>(ws + j.b_keys + j.b_pack);
+    // one launch: hit counters = 0, every table key = kJEmpty, presence bitmaps = 0
+    if (int rc = launch_prep(d_hits_n, Q, tkeys, j.b_keys, tbloom, j.b_bloom, st)) return rc;
+    hipLaunchKernelGGL(ts_join_build_kernel, dim3((unsigned)tvz::ceil_div(max_query_len, kBlock), (unsigned)Q),
+                       dim3(kBlock), 0, st, d_queries, d_q_offsets, Q, max_query_len, j.s_log2, tkeys, tpack,
+                       tbloom, d_hits_n);
+    TVZ_HIP(hipGetLastError());
+    // two 1024-thread blocks per CU: about two rounds of 512 blocks, >= 8 rows per 16-lane group
+    const int n_tiles = j.n_tiles;
+    const int64_t g = (8 % n_tiles == 0) ? 8 / n_tiles : 1;
+    int64_t chunks = std::max<int64_t>(1, 1024 / n_tiles);
+    chunks = std::min(chunks, std::max<int64_t>(1, n_rows / (2 * kJoinGroups)));
+    chunks = tvz::round_up(chunks, g);
+    const int64_t rpb = tvz::round_up(tvz::ceil_div(n_rows, chunks), kJoinGroups);
+    int64_t blocks = (int64_t)n_tiles * chunks;
+    if (8 % n_tiles == 0) blocks = tvz::round_up(blocks, 8);
+    hipLaunchKernelGGL(ts_match_join_kernel, dim3((unsigned)blocks), dim3(kJoinBlock), kJoinLds, st,
+                       c->rows.p, n_rows, c->keys.p, reinterpret_cast<const int64_t *>(tkeys), tpack, tbloom,
+                       j.s_log2, Q, n_tiles, (int32_t)chunks, min_match, d_exclude_ids, cap, d_hits,
+                       d_hits_n, (int32_t)rpb);
+    TVZ_HIP(hipGetLastError());
+    return TVZ_OK;
+}
+
+template <bool HOSTOUT>
+int launch_q1(tvz_corpus *c, const double *d_queries, const int64_t *d_q_offsets, int32_t Q,
+              int32_t max_query_len, int32_t min_match, const int32_t *d_exclude_ids,
+              int32_t exclude_one, int32_t cap, int32_t *d_hits, int32_t *d_hits_n, int blocks_x,
+              HostOut ho, hipStream_t st) {
+    const int64_t n_rows = (int64_t)c->h_rows.size();
+    const int s_log2 = q1_slots_log2(max_query_len);
+    const size_t lds = q1_lds_bytes(s_log2);
+    const dim3 grid((unsigned)blocks_x, (unsigned)Q);
+#define TVZ_Q1(MODE)                                                                              \
+    hipLaunchKernelGGL((ts_match_q1_kernel<MODE, HOSTOUT>), grid, dim3(kQ1Block), lds, st, c->rows.p, \
+                       n_rows, c->keys.p, d_queries, d_q_offsets, min_match, d_exclude_ids,          \
+                       exclude_one, cap, d_hits, d_hits_n, s_log2, ho)
+    if (min_match <= 0 || min_match > kTop) TVZ_Q1(kQ1ModeCount);
+    else if (min_match <= 2) TVZ_Q1(kQ1ModeM2);
+    else TVZ_Q1(kQ1ModeTop5);
+#undef TVZ_Q1
+    TVZ_HIP(hipGetLastError());
+    return TVZ_OK;
+}
+
+int q1_blocks(int64_t n_rows, int32_t Q) {
+    // every row group gets >= 1 row; about 8 blocks per CU in total over the Q block columns
+    int64_t b = tvz::ceil_div(n_rows, kQ1Groups);
+    const int64_t per_q = std::max<int64_t>(256, kQ1MaxBlocks / std::max(1, Q));
+    b = std::max<int64_t>(1, std::min(b, per_q));
+    return (int)b;
+}
+
+int launch_match(tvz_corpus *c, const double *d_queries, const int64_t *d_q_offsets, int32_t Q,
+                 int32_t max_query_len, int32_t min_match, const int32_t *d_exclude_ids,
+                 int32_t cap, int32_t *d_hits, int32_t *d_hits_n, unsigned char *ws, size_t ws_bytes,
+                 int32_t algo, hipStream_t st) {
+    if (max_query_len > kMaxQueryLen)
+        return tvz::fail(TVZ_ERR_UNSUPPORTED, "query of %d timestamps exceeds the supported %d",
+                         max_query_len, kMaxQueryLen);
+    TVZ_REQUIRE(algo >= TVZ_ALGO_AUTO && algo <= TVZ_ALGO_JOIN, "unknown algo %d", algo);
+    if (int rc = wait_mutations(c, st)) return rc;
+    const int64_t n_rows = (int64_t)c->h_rows.size();
+    int a = pick_algo(algo, Q, n_rows, max_query_len, min_match);
+    // AUTO never fails for want of scratch: without the join's tables it takes the LDS tile
+    if (a == TVZ_ALGO_JOIN && algo == TVZ_ALGO_AUTO && (ws == nullptr || ws_bytes < join_shape(Q, max_query_len).bytes()))
+        a = TVZ_ALGO_TILE;
+    if (n_rows == 0 || a != TVZ_ALGO_JOIN)
+        if (int rc = launch_prep(d_hits_n, Q, nullptr, 0, nullptr, 0, st)) return rc;
+    if (n_rows == 0 || Q == 0) return TVZ_OK;
+    if (a == TVZ_ALGO_JOIN)
+        return launch_join(c, d_queries, d_q_offsets, Q, max_query_len, min_match, d_exclude_ids, cap,
+                           d_hits, d_hits_n, ws, ws_bytes, st);
+    if (a == TVZ_ALGO_Q1) {
+        if (int rc = launch_q1<false>(c, d_queries, d_q_offsets, Q, max_query_len, min_match,
+                                      d_exclude_ids, -1, cap, d_hits, d_hits_n, q1_blocks(n_rows, Q),
+                                      HostOut{nullptr, nullptr, 0}, st))
+            return rc;
+    } else {
+        // queries per tile: as many as keep the shared table at load <= 0.5 (at most 16)
+        int nq = max_query_len > 0 ? kTileMaxEntries / max_query_len : kTileQ;
+        nq = std::max(1, std::min(nq, kTileQ));
+        const int64_t tiles = tvz::ceil_div(Q, nq);
+        // one 1024-thread block per CU (LDS): aim at just under two full rounds of 256 blocks (a
+        // third, mostly empty round costs a whole block time), but >= 2 rows per 16-lane group so
+        // that building the tile's table (per block) stays a small part of the block's life
+        int64_t chunks = std::max<int64_t>(1, 512 / tiles);
+        chunks = std::min(chunks, std::max<int64_t>(1, n_rows / (2 * kTileGroups)));
+        const int64_t rpb = tvz::round_up(tvz::ceil_div(n_rows, chunks), kTileGroups);
+        chunks = tvz::ceil_div(n_rows, rpb);
+        if (tiles > 65535)
+            return tvz::fail(TVZ_ERR_UNSUPPORTED, "too many query tiles (%lld)", (long long)tiles);
+        if (min_match <= 2)
+            hipLaunchKernelGGL(ts_match_tile_kernel<false>, dim3((unsigned)chunks, (unsigned)tiles),
+                               dim3(kTileBlock), kTileLds, st, c->rows.p, n_rows, c->keys.p, d_queries,
+                               d_q_offsets, Q, nq, min_match, d_exclude_ids, cap, d_hits, d_hits_n,
+                               (int32_t)rpb);
+        else
+            hipLaunchKernelGGL(ts_match_tile_kernel<true>, dim3((unsigned)chunks, (unsigned)tiles),
+                               dim3(kTileBlock), kTileLds, st, c->rows.p, n_rows, c->keys.p, d_queries,
+                               d_q_offsets, Q, nq, min_match, d_exclude_ids, cap, d_hits, d_hits_n,
+                               (int32_t)rpb);
+        TVZ_HIP(hipGetLastError());
+    }
+    if (min_match > kTop) {
+        hipLaunchKernelGGL(ts_kth_fixup_kernel, dim3((unsigned)Q), dim3(kBlock), 0, st, c->rows.p,
+                           c->keys.p, d_queries, d_q_offsets, min_match, cap, d_hits, d_hits_n);
+        TVZ_HIP(hipGetLastError());
+    }
+    return TVZ_OK;
+}
+
+int launch_topk_local(const int32_t *d_hits, const int32_t *d_hits_n, int32_t Q, int32_t cap,
+                      int32_t k, int32_t *d_out, int mode, hipStream_t st) {
+    hipLaunchKernelGGL(ts_topk_select_kernel, dim3((unsigned)Q), dim3(kBlock), 0, st, d_hits, d_hits_n,
+                       Q, cap, k, d_out, mode);
+    TVZ_HIP(hipGetLastError());
+    return TVZ_OK;
+}
+
+int check_batch_args(tvz_corpus *c, const double *d_queries, const int64_t *d_q_offsets, int32_t Q,
+                     int32_t max_query_len, int32_t cap) {
+    TVZ_REQUIRE(c != nullptr, "corpus is NULL");
+    TVZ_REQUIRE(Q >= 0 && Q <= 65535, "Q=%d out of range [0, 65535]", Q);
+    TVZ_REQUIRE(max_query_len >= 0 && cap >= 0, "negative size");
+    TVZ_REQUIRE(Q == 0 || d_q_offsets, "NULL query offsets");
+    TVZ_REQUIRE(d_queries || max_query_len == 0 || Q == 0, "d_queries is NULL");
+    return TVZ_OK;
 }
 
 }  // namespace
+
+// used by tvz_comm.hip (same shared object, not exported)
+int tvz_match_topk_local(tvz_corpus *c, const double *d_queries, const int64_t *d_q_offsets,
+                         int32_t Q, int32_t max_query_len, int32_t min_match,
+                         const int32_t *d_exclude_ids, int32_t cap, int32_t k, int32_t *d_out,
+                         void *d_workspace, size_t workspace_bytes, int32_t n_ranks, int32_t algo,
+                         void *hip_stream, int32_t **gathered_out) {
+    if (int rc = check_batch_args(c, d_queries, d_q_offsets, Q, max_query_len, cap)) return rc;
+    TVZ_REQUIRE(k >= 1 && k <= kSortCap / 2, "k=%d out of range [1, %d]", k, kSortCap / 2);
+    if (Q == 0) return TVZ_OK;
+    TVZ_REQUIRE(d_workspace != nullptr, "d_workspace is NULL");
+    const WsLayout w = ws_layout(d_workspace, Q, max_query_len, cap, k, n_ranks);
+    if (workspace_bytes < w.total)
+        return tvz::fail(TVZ_ERR_WORKSPACE, "workspace of %zu bytes, need %zu", workspace_bytes, w.total);
+    if (d_out == nullptr) d_out = w.local;
+    if (gathered_out) *gathered_out = w.gathered;
+    DeviceGuard dg(c->device);
+    hipStream_t st = reinterpret_cast<hipStream_t>(hip_stream);
+    std::shared_lock<std::shared_mutex> lk(c->mu);
+    if (int rc = launch_match(c, d_queries, d_q_offsets, Q, max_query_len, min_match, d_exclude_ids,
+                              cap, w.hits, w.hits_n, w.join, w.join_bytes, algo, st))
+        return rc;
+    if (int rc = launch_topk_local(w.hits, w.hits_n, Q, cap, k, d_out, 1, st)) return rc;
+    return record(c, st);
+}
+
+int32_t *tvz_ws_local_block(void *d_workspace, int32_t Q, int32_t max_query_len, int32_t cap,
+                            int32_t k, int32_t n_ranks) {
+    return ws_layout(d_workspace, Q, max_query_len, cap, k, n_ranks).local;
+}
 
 static int tvz_corpus_create_impl(tvz_corpus **out, int device) {
     TVZ_REQUIRE(out != nullptr, "out is NULL");
@@ -1110,15 +541,40 @@ static int tvz_corpus_create_impl(tvz_corpus **out, int device) {
     DeviceGuard dg(device);
     tvz_corpus *c = new tvz_corpus();
     c->device = device;
+    struct Guard { tvz_corpus *c; ~Guard() { if (c) (void)tvz_corpus_destroy(c); } } g{c};
     for (int i = 0; i < tvz_corpus::kEvents; ++i)
         TVZ_HIP(hipEventCreateWithFlags(&c->events[i], hipEventDisableTiming));
+    TVZ_HIP(hipStreamCreateWithFlags(&c->mstream, hipStreamNonBlocking));
+    TVZ_HIP(hipEventCreateWithFlags(&c->mut_done, hipEventDisableTiming));
+    for (RingSlot &s : c->ring) {
+        TVZ_HIP(hipHostMalloc(&s.h, (size_t)kRingSlotKeys * 8, hipHostMallocDefault));
+        TVZ_HIP(hipEventCreateWithFlags(&s.ev, hipEventDisableTiming));
+    }
     TVZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(ts_match_tile_kernel<false>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)kTileLds));
     TVZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(ts_match_tile_kernel<true>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)kTileLds));
     TVZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(ts_match_join_kernel),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)kJoinLds));
-    if (int rc = upload_all(c)) { delete c; return rc; }
+    const int q1max = (int)q1_lds_bytes(kQ1MaxLog2);
+#define TVZ_Q1_ATTR(M, H)                                                                     \
+    TVZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(ts_match_q1_kernel<M, H>),       \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, q1max))
+    TVZ_Q1_ATTR(kQ1ModeM2, false); TVZ_Q1_ATTR(kQ1ModeM2, true);
+    TVZ_Q1_ATTR(kQ1ModeTop5, false); TVZ_Q1_ATTR(kQ1ModeTop5, true);
+    TVZ_Q1_ATTR(kQ1ModeCount, false); TVZ_Q1_ATTR(kQ1ModeCount, true);
+#undef TVZ_Q1_ATTR
+    // default reservation: 64 Ki rows / 2 Mi keys (16 MiB) and two single-query stagings, so a
+    // fresh service handles its first uploads without allocating on the hot calls
+    c->stage_rows = 1 << 16;
+    if (int rc = ensure(c->keys, (int64_t)1 << 21, 0)) return rc;
+    if (int rc = ensure(c->rows, (int64_t)1 << 16, 0)) return rc;
+    for (int i = 0; i < 2; ++i) {
+        Staging *s = nullptr;
+        if (int rc = staging_new(c, &s)) return rc;
+        c->free_staging.push_back(s);
+    }
+    g.c = nullptr;
     *out = c;
     return TVZ_OK;
 }
@@ -1128,22 +584,30 @@ static int tvz_corpus_destroy_impl(tvz_corpus *c) {
     DeviceGuard dg(c->device);
     {
         std::unique_lock<std::shared_mutex> lk(c->mu);
-        (void)drain(c);
+        if (c->mstream) (void)drain(c);
         for (Staging *s : c->free_staging) staging_free(s);
         c->free_staging.clear();
-        for (JoinWs *w : c->join_ws) {
-            if (w->done) { (void)hipEventSynchronize(w->done); (void)hipEventDestroy(w->done); }
-            if (w->base) (void)hipFree(w->base);
-            delete w;
+        for (RingSlot &s : c->ring) {
+            if (s.h) (void)hipHostFree(s.h);
+            if (s.ev) (void)hipEventDestroy(s.ev);
         }
-        c->join_ws.clear();
         if (c->keys.p) (void)hipFree(c->keys.p);
         if (c->rows.p) (void)hipFree(c->rows.p);
         for (int i = 0; i < tvz_corpus::kEvents; ++i)
             if (c->events[i]) (void)hipEventDestroy(c->events[i]);
+        if (c->mut_done) (void)hipEventDestroy(c->mut_done);
+        if (c->mstream) (void)hipStreamDestroy(c->mstream);
     }
     delete c;
     return TVZ_OK;
+}
+
+static int tvz_corpus_reserve_impl(tvz_corpus *c, int64_t n_rows, int64_t n_keys) {
+    TVZ_REQUIRE(c != nullptr, "corpus is NULL");
+    TVZ_REQUIRE(n_rows >= 0 && n_keys >= 0, "negative size");
+    DeviceGuard dg(c->device);
+    std::unique_lock<std::shared_mutex> lk(c->mu);
+    return reserve_locked(c, n_rows, n_keys + n_rows /* padding to even row lengths */);
 }
 
 static int tvz_corpus_upload_impl(tvz_corpus *c, const int32_t *h_video_ids,
@@ -1151,6 +615,7 @@ static int tvz_corpus_upload_impl(tvz_corpus *c, const int32_t *h_video_ids,
                                  int64_t n_keys) {
     TVZ_REQUIRE(c != nullptr, "corpus is NULL");
     TVZ_REQUIRE(n_rows >= 0 && n_keys >= 0, "negative size");
+    TVZ_REQUIRE(n_rows < INT32_MAX - 2, "too many rows");
     TVZ_REQUIRE(n_rows == 0 || (h_video_ids && h_offsets), "NULL row arrays");
     TVZ_REQUIRE(n_keys == 0 || h_keys, "NULL keys");
     for (int64_t r = 0; r < n_rows; ++r) {
@@ -1158,6 +623,9 @@ static int tvz_corpus_upload_impl(tvz_corpus *c, const int32_t *h_video_ids,
                         h_offsets[r + 1] <= n_keys,
                     "offsets of row %lld are not monotone within [0, n_keys]", (long long)r);
         TVZ_REQUIRE(h_offsets[r + 1] - h_offsets[r] <= INT32_MAX, "row %lld too long", (long long)r);
+        // videos.id is a Postgres serial (db.py:14); negative ids mark padding in the top-k lists
+        TVZ_REQUIRE(h_video_ids[r] >= 0, "row %lld has a negative video_id (%d)", (long long)r,
+                    h_video_ids[r]);
     }
     DeviceGuard dg(c->device);
     std::unique_lock<std::shared_mutex> lk(c->mu);
@@ -1177,41 +645,95 @@ static int tvz_corpus_upload_impl(tvz_corpus *c, const int32_t *h_video_ids,
         c->h_rows.push_back(row);
         c->live_keys += row.len;
     }
-    return upload_all(c);
+    // room for the table to double before anything has to grow
+    const int64_t want_rows = 2 * n_rows + 1024, want_keys = 2 * (int64_t)c->h_keys.size() + 65536;
+    if (int rc = upload_all(c, want_rows, want_keys)) return rc;
+    return reserve_locked(c, want_rows, want_keys);
 }
 
 static int tvz_corpus_upsert_impl(tvz_corpus *c, int32_t video_id, const double *h_keys, int64_t n) {
     TVZ_REQUIRE(c != nullptr, "corpus is NULL");
     TVZ_REQUIRE(n >= 0 && n <= INT32_MAX && (n == 0 || h_keys), "bad key array");
+    TVZ_REQUIRE(video_id >= 0, "negative video_id (%d)", video_id);
     DeviceGuard dg(c->device);
+    // canonicalise + sort outside the lock
+    thread_local std::vector<int64_t> tmp;
+    tmp.clear();
+    const int64_t len = canon_row(h_keys, n, tmp);
+    const int64_t added = (int64_t)tmp.size();
     std::unique_lock<std::shared_mutex> lk(c->mu);
-    if (int rc = drain(c)) return rc;
     const int64_t off = (int64_t)c->h_keys.size();
-    const int64_t len = canon_row(h_keys, n, c->h_keys);
-    const int64_t added = (int64_t)c->h_keys.size() - off;
-    auto it = c->first_row.find(video_id);
     const int64_t rows_before = (int64_t)c->h_rows.size();
-    int64_t r;
-    if (it == c->first_row.end()) {
-        r = rows_before;
-        c->h_rows.push_back(Row{off, (int32_t)len, video_id});
+    auto it = c->first_row.find(video_id);
+    const bool is_new = it == c->first_row.end();
+    const int64_t r = is_new ? rows_before : it->second;
+    TVZ_REQUIRE(rows_before < INT32_MAX - 3, "too many rows");
+    // host mirror first; every failure below leaves host and device consistent again through
+    // the full re-upload of the slow path, or rolls the host mirror back
+    const Row old_row = is_new ? Row{0, 0, 0} : c->h_rows[r];
+    c->h_keys.insert(c->h_keys.end(), tmp.begin(), tmp.end());
+    const Row new_row{off, (int32_t)len, video_id};
+    if (is_new) {
+        c->h_rows.push_back(new_row);
         c->first_row.emplace(video_id, r);
     } else {
-        r = it->second;
-        c->live_keys -= c->h_rows[r].len;
-        c->h_rows[r].off = off;
-        c->h_rows[r].len = (int32_t)len;
+        c->h_rows[r] = new_row;
     }
-    c->live_keys += len;
-    // garbage-collect the arena when more than half of it is dead
-    if ((int64_t)c->h_keys.size() > 2 * (c->live_keys + (int64_t)c->h_rows.size()) + 4096)
-        return compact(c);
-    if (int rc = ensure(c->keys, (int64_t)c->h_keys.size() + 2, off)) return rc;
-    if (int rc = ensure(c->rows, (int64_t)c->h_rows.size() + 1, rows_before)) return rc;
-    if (added)
-        TVZ_HIP(hipMemcpy(c->keys.p + off, c->h_keys.data() + off, (size_t)added * 8,
-                          hipMemcpyHostToDevice));
-    TVZ_HIP(hipMemcpy(c->rows.p + r, &c->h_rows[r], sizeof(Row), hipMemcpyHostToDevice));
+    c->live_keys += len - (is_new ? 0 : old_row.len);
+    auto rollback = [&]() {
+        c->h_keys.resize((size_t)off);
+        c->live_keys -= len - (is_new ? 0 : old_row.len);
+        if (is_new) { c->h_rows.pop_back(); c->first_row.erase(video_id); }
+        else c->h_rows[r] = old_row;
+    };
+    // garbage-collect the arena when more than half of it is dead, or grow what is full: the only
+    // paths that wait for matches in flight (amortised: reservations double)
+    const bool gc = (int64_t)c->h_keys.size() > 2 * (c->live_keys + (int64_t)c->h_rows.size()) + 4096;
+    const bool full = (int64_t)c->h_keys.size() + 2 > c->keys.cap || (int64_t)c->h_rows.size() + 1 > c->rows.cap;
+    if (gc || full) {
+        int rc = drain(c);
+        if (!rc) rc = gc ? compact(c) : TVZ_OK;
+        if (!rc && !gc) rc = upload_all(c, 2 * (int64_t)c->h_rows.size() + 1024,
+                                        2 * (int64_t)c->h_keys.size() + 65536);
+        if (!rc) rc = reserve_locked(c, 2 * (int64_t)c->h_rows.size() + 1024, 0);
+        if (rc) rollback();
+        return rc;
+    }
+    // fast path: payload -> pinned ring slot -> async copy into FRESH arena space -> 16-byte row
+    // swap, all on the mutation stream; no wait for the host or for running matches
+    if (added > kRingSlotKeys) {
+        // a row too long for a ring slot (> 8192 cuts): copy straight from the mirror, synchronously
+        hipError_t e = hipMemcpyAsync(c->keys.p + off, c->h_keys.data() + off, (size_t)added * 8,
+                                      hipMemcpyHostToDevice, c->mstream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->mstream);
+        if (e != hipSuccess) {
+            rollback();
+            return tvz::fail(TVZ_ERR_HIP, "upsert copy failed: %s", hipGetErrorString(e));
+        }
+    } else if (added) {
+        RingSlot &s = c->ring[c->ring_next];
+        c->ring_next = (c->ring_next + 1) % kRingSlots;
+        hipError_t e = hipSuccess;
+        if (s.pending) e = hipEventSynchronize(s.ev);      // 16 upserts ago: long done
+        if (e == hipSuccess) {
+            memcpy(s.h, tmp.data(), (size_t)added * 8);
+            e = hipMemcpyAsync(c->keys.p + off, s.h, (size_t)added * 8, hipMemcpyHostToDevice, c->mstream);
+        }
+        if (e == hipSuccess) e = hipEventRecord(s.ev, c->mstream);
+        if (e != hipSuccess) {
+            rollback();
+            return tvz::fail(TVZ_ERR_HIP, "upsert copy failed: %s", hipGetErrorString(e));
+        }
+        s.pending = true;
+    }
+    hipLaunchKernelGGL(ts_row_write_kernel, dim3(1), dim3(1), 0, c->mstream, c->rows.p + r, new_row);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipEventRecord(c->mut_done, c->mstream);
+    if (e != hipSuccess) {
+        rollback();
+        return tvz::fail(TVZ_ERR_HIP, "upsert row swap failed: %s", hipGetErrorString(e));
+    }
+    c->mut_any = true;
     return TVZ_OK;
 }
 
@@ -1219,7 +741,7 @@ static int tvz_corpus_clear_impl(tvz_corpus *c) {
     TVZ_REQUIRE(c != nullptr, "corpus is NULL");
     DeviceGuard dg(c->device);
     std::unique_lock<std::shared_mutex> lk(c->mu);
-    if (int rc = drain(c)) return rc;
+    // matches in flight keep sweeping the rows they were launched with (the memory stays valid)
     c->h_keys.clear();
     c->h_rows.clear();
     c->first_row.clear();
@@ -1240,20 +762,35 @@ static int tvz_corpus_stats_impl(tvz_corpus *c, int64_t *n_rows, int64_t *n_keys
 static int tvz_match_impl(tvz_corpus *c, const double *d_queries, const int64_t *d_q_offsets,
                          int32_t Q, int32_t max_query_len, int32_t min_match,
                          const int32_t *d_exclude_ids, int32_t cap, int32_t *d_hits,
-                         int32_t *d_hits_n, void *hip_stream) {
-    TVZ_REQUIRE(c != nullptr, "corpus is NULL");
-    TVZ_REQUIRE(Q >= 0 && Q <= 65535, "Q=%d out of range [0, 65535]", Q);
-    TVZ_REQUIRE(max_query_len >= 0 && cap >= 0, "negative size");
+                         int32_t *d_hits_n, void *d_workspace, size_t workspace_bytes, int32_t algo,
+                         void *hip_stream) {
+    if (int rc = check_batch_args(c, d_queries, d_q_offsets, Q, max_query_len, cap)) return rc;
     if (Q == 0) return TVZ_OK;
-    TVZ_REQUIRE(d_q_offsets && d_hits_n && (cap == 0 || d_hits), "NULL output / offsets");
-    TVZ_REQUIRE(d_queries || max_query_len == 0, "d_queries is NULL");
+    TVZ_REQUIRE(d_hits_n && (cap == 0 || d_hits), "NULL output");
     DeviceGuard dg(c->device);
     hipStream_t st = reinterpret_cast<hipStream_t>(hip_stream);
+    unsigned char *ws = nullptr;
+    size_t ws_bytes = 0;
+    if (d_workspace) {
+        const uintptr_t p = (reinterpret_cast<uintptr_t>(d_workspace) + 255) & ~(uintptr_t)255;
+        const size_t lost = p - reinterpret_cast<uintptr_t>(d_workspace);
+        if (workspace_bytes > lost) { ws = reinterpret_cast<unsigned char *>(p); ws_bytes = workspace_bytes - lost; }
+    }
     std::shared_lock<std::shared_mutex> lk(c->mu);
     if (int rc = launch_match(c, d_queries, d_q_offsets, Q, max_query_len, min_match,
-                              d_exclude_ids, cap, d_hits, d_hits_n, st))
+                              d_exclude_ids, cap, d_hits, d_hits_n, ws, ws_bytes, algo, st))
         return rc;
     return record(c, st);
+}
+
+static int tvz_match_topk_impl(tvz_corpus *c, const double *d_queries, const int64_t *d_q_offsets,
+                              int32_t Q, int32_t max_query_len, int32_t min_match,
+                              const int32_t *d_exclude_ids, int32_t cap, int32_t k, int32_t *d_out,
+                              void *d_workspace, size_t workspace_bytes, int32_t algo,
+                              void *hip_stream) {
+    TVZ_REQUIRE(d_out != nullptr || Q == 0, "d_out is NULL");
+    return tvz_match_topk_local(c, d_queries, d_q_offsets, Q, max_query_len, min_match, d_exclude_ids,
+                                cap, k, d_out, d_workspace, workspace_bytes, 1, algo, hip_stream, nullptr);
 }
 
 static int tvz_find_duplicates_impl(tvz_corpus *c, const double *h_query, int64_t n,
@@ -1269,101 +806,165 @@ static int tvz_find_duplicates_impl(tvz_corpus *c, const double *h_query, int64_
     Staging *s = nullptr;
     if (int rc = staging_get(c, &s)) return rc;
     struct Put { tvz_corpus *c; Staging *s; ~Put() { staging_put(c, s); } } put{c, s};
-    if (n > s->query_cap) {
-        if (s->d_query) (void)hipFree(s->d_query);
-        s->query_cap = std::max<int64_t>(n, 256);
-        TVZ_HIP(hipMalloc(&s->d_query, (size_t)s->query_cap * 8));
-    }
-    if (cap > s->hits_cap) {
-        if (s->d_hits) (void)hipFree(s->d_hits);
-        if (s->h_hits) (void)hipHostFree(s->h_hits);
-        s->hits_cap = std::max<int64_t>(cap, 1024);
-        TVZ_HIP(hipMalloc(&s->d_hits, (size_t)s->hits_cap * 12));
-        TVZ_HIP(hipHostMalloc(&s->h_hits, (size_t)s->hits_cap * 12));
-    }
-    s->h_small[0] = 0;
-    s->h_small[1] = n;
-    TVZ_HIP(hipMemcpyAsync(s->d_qoff, s->h_small, 16, hipMemcpyHostToDevice, s->stream));
-    if (n) TVZ_HIP(hipMemcpyAsync(s->d_query, h_query, (size_t)n * 8, hipMemcpyHostToDevice, s->stream));
-    int32_t *d_excl = nullptr;  // exclusion is applied on the host for the single-query form
-    if (n <= kMaxQueryLen) {
-        std::shared_lock<std::shared_mutex> lk(c->mu);
-        if (int rc = launch_match(c, s->d_query, s->d_qoff, 1, (int32_t)n, min_match, d_excl,
-                                  (int32_t)cap, s->d_hits, s->d_hits_n, s->stream))
-            return rc;
-        if (int rc = record(c, s->stream)) return rc;
-    } else {
-        // longer than a query tile: sorted distinct keys + multiplicities, searched per row key
-        std::vector<int64_t> sk;
-        sk.reserve((size_t)n);
-        for (int64_t i = 0; i < n; ++i) {
-            int64_t k;
-            if (canon_key(h_query[i], k)) sk.push_back(k);
-        }
-        std::sort(sk.begin(), sk.end());
-        std::vector<int64_t> uq;
-        std::vector<int32_t> mult;
-        for (size_t i = 0; i < sk.size(); ++i) {
-            if (!uq.empty() && uq.back() == sk[i]) ++mult.back();
-            else { uq.push_back(sk[i]); mult.push_back(1); }
-        }
-        const int64_t m = (int64_t)uq.size();
-        if (m + 1 > s->sq_cap) {
-            if (s->d_sq) (void)hipFree(s->d_sq);
-            if (s->d_smult) (void)hipFree(s->d_smult);
-            s->sq_cap = m + 1;
-            TVZ_HIP(hipMalloc(&s->d_sq, (size_t)s->sq_cap * 8));
-            TVZ_HIP(hipMalloc(&s->d_smult, (size_t)s->sq_cap * 4));
-        }
-        if (m) {
-            TVZ_HIP(hipMemcpyAsync(s->d_sq, uq.data(), (size_t)m * 8, hipMemcpyHostToDevice, s->stream));
-            TVZ_HIP(hipMemcpyAsync(s->d_smult, mult.data(), (size_t)m * 4, hipMemcpyHostToDevice, s->stream));
-        }
-        TVZ_HIP(hipMemsetAsync(s->d_hits_n, 0, sizeof(int32_t), s->stream));
-        std::shared_lock<std::shared_mutex> lk(c->mu);
-        const int64_t n_rows = (int64_t)c->h_rows.size();
-        if (n_rows) {
-            hipLaunchKernelGGL(ts_match_longq_kernel, dim3((unsigned)tvz::ceil_div(n_rows, kGroupsPerBlock)),
-                               dim3(kBlock), 0, s->stream, c->rows.p, n_rows, c->keys.p, s->d_sq,
-                               s->d_smult, (int32_t)m, min_match, (int32_t)cap, s->d_hits, s->d_hits_n);
-            TVZ_HIP(hipGetLastError());
-            if (min_match > 0) {
-                hipLaunchKernelGGL(ts_kth_fixup_kernel, dim3(1), dim3(kBlock), 0, s->stream, c->rows.p,
-                                   c->keys.p, s->d_query, s->d_qoff, min_match, (int32_t)cap, s->d_hits,
-                                   s->d_hits_n);
-                TVZ_HIP(hipGetLastError());
+    struct Hit { int32_t vid, cnt, kth; };
+    std::vector<Hit> long_hits;            // only the rare paths below use it
+    const Hit *found = nullptr;
+    int64_t n_found = 0;                   // hits the device reported (before the cap)
+    int64_t n_have = 0;                    // hits available in `found`
+    const int32_t excl = exclude_id >= 0 ? exclude_id : -1;
+    const bool one_launch = n <= kMaxQueryLen && min_match <= kTop;
+    if (one_launch) {
+        // ---- ONE launch + ONE synchronisation: the kernel writes its hits to pinned host memory
+        s->h_query[0] = 0;
+        s->h_query[1] = n;
+        if (n) memcpy(s->h_query + 2, h_query, (size_t)n * 8);
+        TVZ_HIP(hipMemcpyAsync(s->d_query, s->h_query, (size_t)(n + 2) * 8, hipMemcpyHostToDevice, s->stream));
+        int blocks = 0, region = 0;
+        {
+            std::shared_lock<std::shared_mutex> lk(c->mu);
+            const int64_t n_rows = (int64_t)c->h_rows.size();
+            if (n_rows) {
+                if (n_rows > c->stage_rows || n_rows + (int64_t)kQ1MaxBlocks * kQ1Groups > s->hit_slots) {
+                    // the corpus outgrew its reservation (see tvz_corpus_reserve): grow this staging
+                    if (int rc = staging_size(s, std::max<int64_t>(2 * n_rows, c->stage_rows))) return rc;
+                }
+                if (int rc = wait_mutations(c, s->stream)) return rc;
+                blocks = q1_blocks(n_rows, 1);
+                region = (int)(tvz::ceil_div(n_rows, (int64_t)blocks * kQ1Groups) * kQ1Groups);
+                const HostOut ho{s->dh_hits, s->dh_counts, region};
+                if (int rc = launch_q1<true>(c, reinterpret_cast<const double *>(s->d_query + 2), s->d_query,
+                                             1, (int32_t)n, min_match, nullptr, excl, 0, nullptr, nullptr,
+                                             blocks, ho, s->stream))
+                    return rc;
+                if (int rc = record(c, s->stream)) return rc;
             }
         }
-        // the staging stream reads the vectors above asynchronously: finish before they go away
         TVZ_HIP(hipStreamSynchronize(s->stream));
-        if (int rc = record(c, s->stream)) return rc;
+        // compact the per-block regions in place (block order; sorted below anyway)
+        Hit *hh = reinterpret_cast<Hit *>(s->h_hits);
+        int64_t w = 0;
+        for (int b = 0; b < blocks; ++b) {
+            const int32_t nb = s->h_counts[b];
+            if (nb < 0) return tvz::fail(TVZ_ERR_INVALID, "internal: query table overflow");
+            const Hit *src = hh + (int64_t)b * region;
+            if (src != hh + w) memmove(hh + w, src, (size_t)nb * sizeof(Hit));
+            w += nb;
+        }
+        found = hh;
+        n_found = n_have = w;
+    } else {
+        // ---- rare paths (min_match > 5, or a query longer than a tile): device hit list, a
+        // fix-up pass for kth, explicit copies back
+        const int64_t want = std::max<int64_t>(cap, 1);
+        if (want > s->d_hit_slots) {
+            if (s->d_hits) (void)hipFree(s->d_hits);
+            s->d_hits = nullptr;
+            s->d_hit_slots = 0;
+            TVZ_HIP(hipMalloc(&s->d_hits, (size_t)want * 12));
+            s->d_hit_slots = want;
+        }
+        std::vector<int64_t> uq;
+        std::vector<int32_t> mult;
+        const bool longq = n > kMaxQueryLen;
+        int64_t *d_q = s->d_query;
+        if (longq) {
+            // sorted distinct keys + multiplicities, searched per row key; the raw query (for the
+            // fix-up walk) travels behind them
+            std::vector<int64_t> sk;
+            sk.reserve((size_t)n);
+            for (int64_t i = 0; i < n; ++i) {
+                int64_t k;
+                if (canon_key(h_query[i], k)) sk.push_back(k);
+            }
+            std::sort(sk.begin(), sk.end());
+            for (size_t i = 0; i < sk.size(); ++i) {
+                if (!uq.empty() && uq.back() == sk[i]) ++mult.back();
+                else { uq.push_back(sk[i]); mult.push_back(1); }
+            }
+            const int64_t m = (int64_t)uq.size();
+            if (m + n + 3 > s->sq_cap) {
+                if (s->d_sq) (void)hipFree(s->d_sq);
+                if (s->d_smult) (void)hipFree(s->d_smult);
+                s->d_sq = nullptr; s->d_smult = nullptr; s->sq_cap = 0;
+                TVZ_HIP(hipMalloc(&s->d_sq, (size_t)(m + n + 3) * 8));
+                TVZ_HIP(hipMalloc(&s->d_smult, (size_t)(m + 1) * 4));
+                s->sq_cap = m + n + 3;
+            }
+            d_q = s->d_sq + m;                                   // {0, n} + raw query
+            const int64_t qoff[2] = {0, n};
+            TVZ_HIP(hipMemcpyAsync(d_q, qoff, 16, hipMemcpyHostToDevice, s->stream));
+            TVZ_HIP(hipMemcpyAsync(d_q + 2, h_query, (size_t)n * 8, hipMemcpyHostToDevice, s->stream));
+            if (m) {
+                TVZ_HIP(hipMemcpyAsync(s->d_sq, uq.data(), (size_t)m * 8, hipMemcpyHostToDevice, s->stream));
+                TVZ_HIP(hipMemcpyAsync(s->d_smult, mult.data(), (size_t)m * 4, hipMemcpyHostToDevice, s->stream));
+            }
+        } else {
+            s->h_query[0] = 0;
+            s->h_query[1] = n;
+            if (n) memcpy(s->h_query + 2, h_query, (size_t)n * 8);
+            TVZ_HIP(hipMemcpyAsync(s->d_query, s->h_query, (size_t)(n + 2) * 8, hipMemcpyHostToDevice, s->stream));
+        }
+        {
+            std::shared_lock<std::shared_mutex> lk(c->mu);
+            const int64_t n_rows = (int64_t)c->h_rows.size();
+            if (int rc = wait_mutations(c, s->stream)) return rc;
+            if (int rc = launch_prep(s->d_hits_n, 1, nullptr, 0, nullptr, 0, s->stream)) return rc;
+            if (n_rows) {
+                if (longq) {
+                    hipLaunchKernelGGL(ts_match_longq_kernel, dim3((unsigned)tvz::ceil_div(n_rows, kGroupsPerBlock)),
+                                       dim3(kBlock), 0, s->stream, c->rows.p, n_rows, c->keys.p, s->d_sq,
+                                       s->d_smult, (int32_t)uq.size(), min_match, (int32_t)want, s->d_hits,
+                                       s->d_hits_n);
+                    TVZ_HIP(hipGetLastError());
+                } else {
+                    if (int rc = launch_q1<false>(c, reinterpret_cast<const double *>(d_q + 2), d_q, 1, (int32_t)n,
+                                                  min_match, nullptr, -1, (int32_t)want, s->d_hits, s->d_hits_n,
+                                                  q1_blocks(n_rows, 1), HostOut{nullptr, nullptr, 0}, s->stream))
+                        return rc;
+                }
+                if (min_match > 0) {
+                    hipLaunchKernelGGL(ts_kth_fixup_kernel, dim3(1), dim3(kBlock), 0, s->stream, c->rows.p,
+                                       c->keys.p, reinterpret_cast<const double *>(d_q + 2), d_q, min_match,
+                                       (int32_t)want, s->d_hits, s->d_hits_n);
+                    TVZ_HIP(hipGetLastError());
+                }
+            }
+            if (int rc = record(c, s->stream)) return rc;
+        }
+        int32_t h_n = 0;
+        TVZ_HIP(hipMemcpyAsync(&h_n, s->d_hits_n, 4, hipMemcpyDeviceToHost, s->stream));
+        TVZ_HIP(hipStreamSynchronize(s->stream));   // also: uq / mult / h_query were read by now
+        n_found = h_n;
+        n_have = std::min<int64_t>(n_found, want);
+        long_hits.resize((size_t)n_have);
+        if (n_have) {
+            TVZ_HIP(hipMemcpyAsync(long_hits.data(), s->d_hits, (size_t)n_have * 12, hipMemcpyDeviceToHost, s->stream));
+            TVZ_HIP(hipStreamSynchronize(s->stream));
+        }
+        // the exclusion is applied here on these paths
+        if (excl >= 0) {
+            const size_t before = long_hits.size();
+            long_hits.erase(std::remove_if(long_hits.begin(), long_hits.end(),
+                                           [&](const Hit &h) { return h.vid == excl; }), long_hits.end());
+            n_found -= (int64_t)(before - long_hits.size());
+            n_have = (int64_t)long_hits.size();
+        }
+        found = long_hits.data();
     }
-    int32_t *h_n = reinterpret_cast<int32_t *>(s->h_small + 2);
-    TVZ_HIP(hipMemcpyAsync(h_n, s->d_hits_n, 4, hipMemcpyDeviceToHost, s->stream));
-    TVZ_HIP(hipStreamSynchronize(s->stream));
-    int64_t found = *h_n;
-    int64_t stored = std::min<int64_t>(found, cap);
-    if (stored) {
-        TVZ_HIP(hipMemcpyAsync(s->h_hits, s->d_hits, (size_t)stored * 12, hipMemcpyDeviceToHost, s->stream));
-        TVZ_HIP(hipStreamSynchronize(s->stream));
-    }
-    struct Hit { int32_t vid, cnt, kth; };
-    Hit *hh = reinterpret_cast<Hit *>(s->h_hits);
-    std::sort(hh, hh + stored, [](const Hit &a, const Hit &b) {
+    Hit *hh = const_cast<Hit *>(found);
+    std::sort(hh, hh + n_have, [](const Hit &a, const Hit &b) {
         if (a.vid != b.vid) return a.vid < b.vid;
         if (a.cnt != b.cnt) return a.cnt < b.cnt;
         return a.kth < b.kth;
     });
-    int64_t w = 0;
-    for (int64_t i = 0; i < stored; ++i) {
-        if (hh[i].vid == exclude_id && exclude_id >= 0) { --found; continue; }
-        h_out_ids[w] = hh[i].vid;
-        h_out_counts[w] = hh[i].cnt;
-        if (h_out_kth) h_out_kth[w] = hh[i].kth;
-        ++w;
+    const int64_t w = std::min<int64_t>(n_have, cap);
+    for (int64_t i = 0; i < w; ++i) {
+        h_out_ids[i] = hh[i].vid;
+        h_out_counts[i] = hh[i].cnt;
+        if (h_out_kth) h_out_kth[i] = hh[i].kth;
     }
-    // truncated: report the device count so the caller can retry with cap >= *n_out
-    *n_out = (*h_n > cap) ? found : w;
+    // truncated: report the true count so the caller can retry with cap >= *n_out
+    *n_out = n_found;
     return TVZ_OK;
 }
 
@@ -1373,9 +974,10 @@ static int tvz_topk_impl(const int32_t *d_lists, const int32_t *d_lists_n, int32
     TVZ_REQUIRE(k >= 1 && k <= kSortCap / 2, "k=%d out of range [1, %d]", k, kSortCap / 2);
     if (Q == 0) return TVZ_OK;
     TVZ_REQUIRE((d_lists || cap == 0) && d_topk, "NULL argument");
-    hipLaunchKernelGGL(ts_topk_kernel, dim3((unsigned)Q), dim3(kBlock), 0,
-                       reinterpret_cast<hipStream_t>(hip_stream), d_lists, d_lists_n, n_lists, Q,
-                       cap, k, d_topk, 0, nullptr);
+    hipStream_t st = reinterpret_cast<hipStream_t>(hip_stream);
+    if (n_lists == 1) return launch_topk_local(d_lists, d_lists_n, Q, cap, k, d_topk, 0, st);
+    hipLaunchKernelGGL(ts_topk_kernel, dim3((unsigned)Q), dim3(kBlock), 0, st, d_lists, d_lists_n,
+                       n_lists, Q, cap, k, d_topk, 0, nullptr);
     TVZ_HIP(hipGetLastError());
     return TVZ_OK;
 }
@@ -1386,11 +988,7 @@ static int tvz_topk_shard_impl(const int32_t *d_hits, const int32_t *d_hits_n, i
     TVZ_REQUIRE(k >= 1 && k <= kSortCap / 2, "k=%d out of range [1, %d]", k, kSortCap / 2);
     if (Q == 0) return TVZ_OK;
     TVZ_REQUIRE((d_hits || cap == 0) && d_hits_n && d_out, "NULL argument");
-    hipLaunchKernelGGL(ts_topk_kernel, dim3((unsigned)Q), dim3(kBlock), 0,
-                       reinterpret_cast<hipStream_t>(hip_stream), d_hits, d_hits_n, 1, Q, cap, k,
-                       d_out, 1, nullptr);
-    TVZ_HIP(hipGetLastError());
-    return TVZ_OK;
+    return launch_topk_local(d_hits, d_hits_n, Q, cap, k, d_out, 1, reinterpret_cast<hipStream_t>(hip_stream));
 }
 
 static int tvz_topk_merge_impl(const int32_t *d_gathered, int32_t n_ranks, int32_t Q, int32_t k,
@@ -1421,6 +1019,7 @@ static int tvz_align_impl(tvz_corpus *c, const double *d_query, int32_t n, doubl
     const int64_t n_rows = (int64_t)c->h_rows.size();
     if (n_rows == 0) return TVZ_OK;
     TVZ_REQUIRE(d_out != nullptr, "d_out is NULL");
+    if (int rc = wait_mutations(c, st)) return rc;
     const int64_t blocks = std::min<int64_t>(tvz::ceil_div(n_rows, kBlock / 64), 256 * 8);
     hipLaunchKernelGGL(ts_align_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, st, c->rows.p, n_rows,
                        c->keys.p, d_query, n, eps, (int32_t)nb, d_out);
@@ -1428,10 +1027,10 @@ static int tvz_align_impl(tvz_corpus *c, const double *d_query, int32_t n, doubl
     return record(c, st);
 }
 
-// Not part of the stable ABI: 0 = LDS tile kernel only, 1 = dispatch rule, 2 = hash join whenever legal.
-static int tvz_match_set_tuning_impl(int use_join) {
-    g_use_join = use_join < 0 ? 0 : (use_join > 2 ? 2 : use_join);
-    return TVZ_OK;
+TVZ_EXPORT size_t tvz_match_workspace_bytes(int32_t Q, int32_t max_query_len, int32_t cap, int32_t k,
+                                            int32_t n_ranks) {
+    if (Q < 0 || max_query_len < 0 || cap < 0 || k < 0) return 0;
+    return ws_layout(nullptr, Q, max_query_len, cap, k, n_ranks).total;
 }
 
 TVZ_EXPORT int tvz_corpus_create(tvz_corpus **out, int device) {
@@ -1440,6 +1039,10 @@ TVZ_EXPORT int tvz_corpus_create(tvz_corpus **out, int device) {
 
 TVZ_EXPORT int tvz_corpus_destroy(tvz_corpus *c) {
     TVZ_GUARDED(tvz_corpus_destroy_impl(c));
+}
+
+TVZ_EXPORT int tvz_corpus_reserve(tvz_corpus *c, int64_t n_rows, int64_t n_keys) {
+    TVZ_GUARDED(tvz_corpus_reserve_impl(c, n_rows, n_keys));
 }
 
 TVZ_EXPORT int tvz_corpus_upload(tvz_corpus *c, const int32_t *h_video_ids,
@@ -1464,8 +1067,17 @@ TVZ_EXPORT int tvz_corpus_stats(tvz_corpus *c, int64_t *n_rows, int64_t *n_keys,
 TVZ_EXPORT int tvz_match(tvz_corpus *c, const double *d_queries, const int64_t *d_q_offsets,
                          int32_t Q, int32_t max_query_len, int32_t min_match,
                          const int32_t *d_exclude_ids, int32_t cap, int32_t *d_hits,
-                         int32_t *d_hits_n, void *hip_stream) {
-    TVZ_GUARDED(tvz_match_impl(c, d_queries, d_q_offsets, Q, max_query_len, min_match, d_exclude_ids, cap, d_hits, d_hits_n, hip_stream));
+                         int32_t *d_hits_n, void *d_workspace, size_t workspace_bytes, int32_t algo,
+                         void *hip_stream) {
+    TVZ_GUARDED(tvz_match_impl(c, d_queries, d_q_offsets, Q, max_query_len, min_match, d_exclude_ids, cap, d_hits, d_hits_n, d_workspace, workspace_bytes, algo, hip_stream));
+}
+
+TVZ_EXPORT int tvz_match_topk(tvz_corpus *c, const double *d_queries, const int64_t *d_q_offsets,
+                              int32_t Q, int32_t max_query_len, int32_t min_match,
+                              const int32_t *d_exclude_ids, int32_t cap, int32_t k, int32_t *d_out,
+                              void *d_workspace, size_t workspace_bytes, int32_t algo,
+                              void *hip_stream) {
+    TVZ_GUARDED(tvz_match_topk_impl(c, d_queries, d_q_offsets, Q, max_query_len, min_match, d_exclude_ids, cap, k, d_out, d_workspace, workspace_bytes, algo, hip_stream));
 }
 
 TVZ_EXPORT int tvz_find_duplicates(tvz_corpus *c, const double *h_query, int64_t n,
@@ -1493,8 +1105,4 @@ TVZ_EXPORT int tvz_topk_merge(const int32_t *d_gathered, int32_t n_ranks, int32_
 TVZ_EXPORT int tvz_align(tvz_corpus *c, const double *d_query, int32_t n, double eps,
                          double max_offset, int32_t *d_out, void *hip_stream) {
     TVZ_GUARDED(tvz_align_impl(c, d_query, n, eps, max_offset, d_out, hip_stream));
-}
-
-TVZ_EXPORT int tvz_match_set_tuning(int use_join) {
-    TVZ_GUARDED(tvz_match_set_tuning_impl(use_join));
 }

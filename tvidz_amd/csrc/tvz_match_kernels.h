@@ -1,0 +1,1143 @@
+// tvz_match_kernels.h — device kernels of the timestamp-corpus matcher (gfx950, wave64).
+// Included by tvz_match.hip only.  See that file for the semantics (db.py:85-91) and the device
+// image of `video_timestamps`.
+//
+// ts_match_q1_kernel     one query per block column: the query's keys in a small LDS multimap,
+//                        a 16-lane group per row, per-lane counters, no per-row LDS state.
+//                        HBM/MALL-stream-bound: the single-query and small-batch path.
+// ts_match_tile_kernel   one LDS hash table per tile of <= 16 queries, ring/drain slow path.
+// ts_join_build_kernel + ts_match_join_kernel   device-memory hash join per 128-query tile.
+// ts_match_longq_kernel  single queries longer than a tile (> 4095 timestamps).
+// ts_kth_fixup_kernel    kth for min_match > 5.
+// ts_topk_select_kernel  per-query k best of a long hit list: kth histogram in LDS picks the
+//                        threshold, only the candidates are sorted.
+// ts_topk_kernel         bitonic k best over short / gathered lists (merge side).
+// ts_prep_kernel         zeroes hit counters and clears hash-join tables in ONE launch.
+// ts_row_write_kernel    stream-ordered 16-byte swap of one row entry (upsert).
+// ts_align_kernel        opt-in shift/tolerance score (never the verdict).
+#pragma once
+#include <climits>
+#include <cstring>
+
+#include "tvz_common.h"
+
+#ifndef TVZ_MATCH_STEP
+#define TVZ_MATCH_STEP 2   // 16-byte key loads per lane and sweep step (4 keys); 3/4/6 measured no faster
+#endif
+
+namespace {
+
+constexpr int kBlock = 256;
+constexpr int kGroup = 16;                  // lanes per corpus row
+constexpr int kGroupsPerBlock = kBlock / kGroup;
+constexpr int64_t kEmpty = 0x7ff8dead00000000LL;  // a NaN pattern: never a canonical key
+constexpr int kMaxQueryLen = 4095;          // positions 0..4094 fit 12 bits with 0xfff as "none"
+
+// One row entry = ONE 16-byte load / store (global_load_dwordx4): an upsert swaps it with a single
+// store while matches may be reading it, so a reader sees the old or the new entry, never a mix.
+struct alignas(16) Row {
+    int64_t off;
+    int32_t len;
+    int32_t vid;
+};
+static_assert(sizeof(Row) == 16, "Row must be 16 bytes");
+
+__device__ __forceinline__ Row load_row(const Row *p) {
+    const int4 v = *reinterpret_cast<const int4 *>(p);
+    Row r;
+    r.off = (int64_t)(((uint64_t)(uint32_t)v.y << 32) | (uint32_t)v.x);
+    r.len = v.z;
+    r.vid = v.w;
+    return r;
+}
+
+// LDS counters updated by other lanes of the SAME wave are read back by plain loads: make the
+// compiler keep the order (the hardware completes a wave's LDS operations in order).
+__device__ __forceinline__ void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// ---- canonical key: integer-only so subnormals / signed zero never meet FP modes ----
+__host__ __device__ inline bool canon_key(double x, int64_t &k) {
+    int64_t b;
+    memcpy(&b, &x, 8);
+    const uint64_t mag = (uint64_t)b & 0x7fffffffffffffffULL;
+    if (mag > 0x7ff0000000000000ULL) return false;  // NaN: == is always false
+    k = (mag == 0) ? 0 : b;                         // -0.0 == +0.0
+    return true;
+}
+
+// ---- query tile: up to 16 queries share ONE hash table in LDS -----------------------------
+// One probe of a corpus key serves every query of the tile, and each corpus row is read once
+// per tile instead of once per query.
+//   slots   : 16384 x u32 = (16-bit tag << 16) | (head entry index); 0xffffffff = empty.
+//             Probed two at a time (one aligned ds_read_b64); load factor <= 0.25, so a probe
+//             almost never needs a second read - what matters on a 64-lane wave is the LONGEST
+//             probe of the wave, not the average.
+//   entries : one per query element of the tile: full canonical key (verification) and
+//             (position, query-in-tile, next entry with the same slot).  Query multiplicity is
+//             therefore exact: every occurrence is its own entry.
+constexpr int kTileBlock = 1024;                      // 16 waves, 64 row groups
+constexpr int kTileGroups = kTileBlock / kGroup;
+constexpr int kTileQ = kGroup;                        // lane <-> query mapping at emission
+constexpr int kTileSlots = 16384;
+constexpr int kTilePairs = kTileSlots / 2;
+constexpr int kTileMaxEntries = 4096;                 // load factor <= 0.25
+constexpr uint32_t kEnd = 0xffffu;
+constexpr uint32_t kFree = 0xffffffffu;
+static_assert(kTileMaxEntries >= kMaxQueryLen, "a single maximal query must fit one tile");
+constexpr int kRing = 128;                            // per-wave slow-path ring (entries)
+constexpr size_t kTileLds = (size_t)kTileSlots * 4 + (size_t)kTileMaxEntries * 8 +
+                            (size_t)kTileMaxEntries * 4 + (size_t)kTileGroups * kTileQ * 3 * 4 +
+                            (size_t)(kTileBlock / 64) * kRing * 12;
+
+// Per (row group, query of the tile) state in LDS: a hit counter and the FIVE smallest matching
+// query positions, packed as 5 x 12 bits (ascending from bit 0, 0xfff = none) in one 64-bit word
+// updated with a CAS loop.  kth for min_match <= 5 (the reference's default and the driver's 2)
+// is read straight from it.
+constexpr int kTop = 5;
+constexpr unsigned long long kTopNone = 0x0fffffffffffffffULL;   // 5 fields of 0xfff
+
+__device__ __forceinline__ unsigned long long top5_insert(unsigned long long p, uint32_t x) {
+    uint32_t a[kTop];
+#pragma unroll
+    for (int i = 0; i < kTop; ++i) a[i] = (uint32_t)(p >> (12 * i)) & 0xfffu;
+#pragma unroll
+    for (int i = 0; i < kTop; ++i) {      // insertion network: keep the smaller, carry the larger
+        const uint32_t lo = a[i] < x ? a[i] : x;
+        x = a[i] < x ? x : a[i];
+        a[i] = lo;
+    }
+    unsigned long long r = 0;
+#pragma unroll
+    for (int i = 0; i < kTop; ++i) r |= (unsigned long long)a[i] << (12 * i);
+    return r;
+}
+
+// pair index (13 bits) and tag (16 bits) from one mix of the key: 9 full-rate VALU ops (one
+// v_mul_u32_u24, no quarter-rate v_mul_lo_u32).  Quality only affects speed: every tag match is
+// verified against the full key.  A tag of 0xffff may "match" a free slot's upper half; the slow
+// path then finds an empty chain (head 0xffff = kEnd), which is the right answer.
+__device__ __forceinline__ void hash_pair_tag(int64_t k, uint32_t &pair, uint32_t &tag) {
+    const uint32_t lo = (uint32_t)k, hi = (uint32_t)((uint64_t)k >> 32);
+    uint32_t x = lo ^ (hi + (hi << 3)) ^ (hi >> 9);
+    x ^= x >> 20;                                   // fold the bits v_mul_u32_u24 ignores
+    const uint32_t y = __umul24(x, 0x9E3779u);
+    pair = y >> (32 - 13);
+    tag = (y >> 3) & 0xffffu;
+}
+static_assert((1 << 13) == kTilePairs, "pair bits must match kTilePairs");
+
+// one matching (query, position) entry: count it and keep the two smallest positions
+// TOP5 = false (min_match <= 2, the streaming driver's case): the 8-byte word holds the smallest
+// and second smallest position as two u32 updated with two LDS atomicMin (7 % faster).
+template <bool TOP5>
+__device__ __forceinline__ void account(uint32_t *cnt, unsigned long long *top, uint32_t ent) {
+    const uint32_t q = (ent >> 12) & 15u;
+    const uint32_t pos = ent & 0xfffu;
+    atomicAdd(&cnt[q], 1u);
+    if constexpr (!TOP5) {
+        uint32_t *m = reinterpret_cast<uint32_t *>(&top[q]);
+        const uint32_t old = atomicMin(&m[0], pos);
+        atomicMin(&m[1], old > pos ? old : pos);   // the larger of two distinct hits: >= 2nd smallest
+        return;
+    }
+    unsigned long long seen = top[q];
+    while (true) {
+        if (((uint32_t)(seen >> (12 * (kTop - 1))) & 0xfffu) <= pos) break;   // not among the 5 smallest
+        const unsigned long long old = atomicCAS(&top[q], seen, top5_insert(seen, pos));
+        if (old == seen) break;
+        seen = old;
+    }
+}
+
+template <bool TOP5>
+__global__ __launch_bounds__(kTileBlock) void ts_match_tile_kernel(
+    const Row *__restrict__ rows, int64_t n_rows, const int64_t *__restrict__ keys,
+    const double *__restrict__ queries, const int64_t *__restrict__ q_offsets, int32_t Q,
+    int32_t nq_tile, int32_t min_match, const int32_t *__restrict__ exclude_ids, int32_t cap,
+    int32_t *__restrict__ hits, int32_t *__restrict__ hits_n, int32_t rows_per_block) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint32_t *slots = reinterpret_cast<uint32_t *>(smem);
+    int64_t *ekey = reinterpret_cast<int64_t *>(smem + (size_t)kTileSlots * 4);
+    uint32_t *epack = reinterpret_cast<uint32_t *>(ekey + kTileMaxEntries);
+    unsigned long long *top = reinterpret_cast<unsigned long long *>(epack + kTileMaxEntries);
+    uint32_t *cnt = reinterpret_cast<uint32_t *>(top + kTileGroups * kTileQ);
+    __shared__ int64_t s_qoff[kTileQ + 1];
+
+    const int q0 = blockIdx.y * nq_tile;
+    const int nq = (Q - q0 < nq_tile) ? Q - q0 : nq_tile;
+    if (threadIdx.x <= nq) s_qoff[threadIdx.x] = q_offsets[q0 + threadIdx.x];
+    for (int i = threadIdx.x; i < kTileSlots; i += kTileBlock) slots[i] = kFree;
+    for (int i = threadIdx.x; i < kTileGroups * kTileQ; i += kTileBlock) {
+        top[i] = TOP5 ? kTopNone : ~0ULL;
+        cnt[i] = 0;
+    }
+    __syncthreads();
+    const int64_t qbase = s_qoff[0];
+    if (s_qoff[nq] - qbase > kTileMaxEntries) {
+        // the caller's max_query_len was not an upper bound: poison the affected counters instead
+        // of returning silently truncated matches (every row chunk of this tile takes this exit)
+        if (threadIdx.x < nq) hits_n[q0 + threadIdx.x] = INT32_MIN;
+        return;
+    }
+    const int total = (int)(s_qoff[nq] - qbase);
+    for (int e = threadIdx.x; e < total; e += kTileBlock) {
+        int ql = 0;
+        while (ql + 1 < nq && s_qoff[ql + 1] - qbase <= e) ++ql;
+        const uint32_t pos = (uint32_t)(e - (int)(s_qoff[ql] - qbase));
+        int64_t k;
+        if (!canon_key(queries[qbase + e], k)) continue;   // NaN never matches
+        ekey[e] = k;
+        uint32_t pair, tag;
+        hash_pair_tag(k, pair, tag);
+        // first slot of the probe sequence that is free or already carries this tag
+        uint32_t s = pair * 2, prev = kEnd;
+        while (true) {
+            uint32_t w = slots[s];
+            if (w == kFree) {
+                w = atomicCAS(&slots[s], kFree, (tag << 16) | (uint32_t)e);
+                if (w == kFree) break;                      // claimed an empty slot
+            }
+            if ((w >> 16) == tag) {                         // push on this tag's chain
+                uint32_t seen = w;
+                while (true) {
+                    const uint32_t old = atomicCAS(&slots[s], seen, (seen & 0xffff0000u) | (uint32_t)e);
+                    if (old == seen) break;
+                    seen = old;
+                }
+                prev = seen & 0xffffu;
+                break;
+            }
+            s = (s + 1) & (kTileSlots - 1);
+        }
+        epack[e] = pos | ((uint32_t)ql << 12) | (prev << 16);
+    }
+    __syncthreads();
+
+    const int gl = threadIdx.x & (kGroup - 1);
+    const int g = threadIdx.x / kGroup;
+    uint32_t *gcnt = cnt + g * kTileQ;
+    unsigned long long *gtop = top + g * kTileQ;
+    const bool my_q = gl < nq;
+    const int32_t excl = (exclude_ids && my_q) ? exclude_ids[q0 + gl] : -1;
+    const bool use_excl = exclude_ids != nullptr;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    int64_t r1 = r0 + rows_per_block;
+    if (r1 > n_rows) r1 = n_rows;
+    const uint2 *pairs = reinterpret_cast<const uint2 *>(slots);
+
+    // ---- sweep -------------------------------------------------------------------------------
+    // SIMT rule that shapes this loop: an event that is rare per LANE (a corpus key that is in
+    // the tile, ~6 % on the synthetic corpora; a displaced key) still happens in almost every
+    // 64-lane wave-instruction, so handling it inline costs every probe the full slow path.
+    // Instead the per-key fast path is branch-free (hash, one aligned 8-byte LDS read of the home
+    // slot pair, tag compares) and lanes that need more push (key, pair|tag|group) into a per-wave
+    // LDS ring with a ballot/mbcnt compaction; whenever 64 entries are pending the whole wave
+    // drains them with every lane busy on the exact probe + chain verification + accounting.
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const uint32_t gw = (threadIdx.x >> 4) & 3u;                 // group within the wave
+    const uint32_t gwbits = gw << 29;
+    int64_t *qbase_k = reinterpret_cast<int64_t *>(cnt + kTileGroups * kTileQ);
+    int64_t *qk = qbase_k + wave * kRing;
+    uint32_t *qm = reinterpret_cast<uint32_t *>(qbase_k + (kTileBlock / 64) * kRing) + wave * kRing;
+    uint32_t *wcnt = cnt + wave * 4 * kTileQ;                     // the wave's 4 groups
+    unsigned long long *wtop = top + wave * 4 * kTileQ;
+    uint32_t qhead = 0, qtail = 0;                                // wave-uniform
+
+    auto drain = [&](uint32_t n) {                                // n <= 64 pending entries
+        if ((uint32_t)lane < n) {
+            const uint32_t idx = (qhead + lane) & (kRing - 1);
+            const int64_t k = qk[idx];
+            const uint32_t m = qm[idx];
+            const uint32_t tag = m & 0xffffu;
+            uint32_t pair = (m >> 16) & (uint32_t)(kTilePairs - 1);
+            uint32_t *scnt = wcnt + (m >> 29) * kTileQ;
+            unsigned long long *stop = wtop + (m >> 29) * kTileQ;
+            uint32_t e = kEnd;
+            while (true) {      // first slot of the probe sequence that is free or carries the tag
+                const uint2 w = pairs[pair];
+                if ((w.x >> 16) == tag) { e = w.x & 0xffffu; break; }
+                if (w.x == kFree) break;
+                if ((w.y >> 16) == tag) { e = w.y & 0xffffu; break; }
+                if (w.y == kFree) break;
+                pair = (pair + 1) & (uint32_t)(kTilePairs - 1);
+            }
+            while (e != kEnd) {  // every (query, position) entry of that slot; verify the full key
+                const uint32_t ent = epack[e];
+                if (ekey[e] == k) account<TOP5>(scnt, stop, ent);
+                e = ent >> 16;
+            }
+        }
+        qhead += n;
+    };
+
+    const int64_t rw0 = r0 + (int64_t)wave * 4;                   // first row of the wave's groups
+    for (int64_t rr = rw0; rr < r1; rr += kTileGroups) {          // wave-uniform trip count
+        const int64_t r = rr + gw;
+        const bool live = r < r1;
+        Row row = Row{0, 0, -1};
+        if (live) row = load_row(rows + r);
+        const int64_t *rk = keys + row.off + gl * 2;
+        const int nmine = row.len - gl * 2;                       // keys at or after this lane's first
+        // kStep 16-byte loads (2 keys each) per lane and step, the next step's loads in flight
+        constexpr int kStep = TVZ_MATCH_STEP;
+        constexpr int kStride = kGroup * 2;                       // keys between a lane's loads
+        longlong2 v[kStep];
+#pragma unroll
+        for (int j = 0; j < kStep; ++j)
+            v[j] = (nmine > j * kStride) ? *reinterpret_cast<const longlong2 *>(rk + j * kStride)
+                                         : make_longlong2(0, 0);
+        for (int i = 0; __ballot(i < nmine) != 0ull; i += kStep * kStride) {
+            int64_t kk[2 * kStep];
+#pragma unroll
+            for (int j = 0; j < kStep; ++j) {
+                kk[2 * j] = v[j].x;
+                kk[2 * j + 1] = v[j].y;
+            }
+            const int in = i + kStep * kStride;
+#pragma unroll
+            for (int j = 0; j < kStep; ++j)
+                if (in + j * kStride < nmine) v[j] = *reinterpret_cast<const longlong2 *>(rk + in + j * kStride);
+            uint32_t pr[2 * kStep], tg[2 * kStep];
+            uint2 w[2 * kStep];
+#pragma unroll
+            for (int j = 0; j < 2 * kStep; ++j) {
+                hash_pair_tag(kk[j], pr[j], tg[j]);
+                w[j] = pairs[pr[j]];
+            }
+#pragma unroll
+            for (int j = 0; j < 2 * kStep; ++j) {
+                const bool valid = i + (j / 2) * kStride + (j & 1) < nmine;
+                // needs the slow path: tag present in the home pair, or the pair is full
+                const bool slow = valid & (((w[j].x >> 16) == tg[j]) | (w[j].y != kFree));
+                const unsigned long long bal = __ballot(slow);
+                if (bal) {                                        // wave-uniform
+                    const uint32_t ofs = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32),
+                                         __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+                    if (slow) {
+                        const uint32_t idx = (qtail + ofs) & (kRing - 1);
+                        qk[idx] = kk[j];
+                        qm[idx] = tg[j] | (pr[j] << 16) | gwbits;
+                    }
+                    qtail += (uint32_t)__popcll(bal);
+                    if (qtail - qhead >= 64u) drain(64u);
+                }
+            }
+        }
+        if (qtail != qhead) drain(qtail - qhead);                 // row boundary: settle the counts
+        // lane q of the group owns query q of the tile (LDS ops of a wave complete in order)
+        wave_lds_fence();
+        if (my_q & live) {
+            const uint32_t c = gcnt[gl];
+            const unsigned long long t5 = gtop[gl];
+            if (c) {
+                gcnt[gl] = 0;
+                gtop[gl] = TOP5 ? kTopNone : ~0ULL;
+            }
+            if ((int64_t)c >= (int64_t)min_match && !(use_excl && row.vid == excl)) {
+                int32_t kth;
+                if (min_match <= 0) kth = -1;
+                else if (!TOP5) kth = (int32_t)(uint32_t)(min_match == 1 ? t5 : t5 >> 32);
+                else if (min_match <= kTop) kth = (int32_t)((t5 >> (12 * (min_match - 1))) & 0xfffu);
+                else kth = -2 - (int32_t)r;          // resolved by ts_kth_fixup_kernel
+                const int slot = atomicAdd(&hits_n[q0 + gl], 1);
+                if (slot < cap) {
+                    int32_t *h = hits + ((int64_t)(q0 + gl) * cap + slot) * 3;
+                    h[0] = row.vid;
+                    h[1] = (int32_t)c;
+                    h[2] = kth;
+                }
+            }
+        }
+    }
+}
+
+// ---- hash join for large query batches (Q >= 32, min_match <= 2) ----------------------------
+// The LDS tile kernel probes every corpus key once per 16 queries.  For big batches against big
+// corpora a database hash JOIN does less work: build one multimap per tile of 128 queries in device
+// memory (sized to stay in one XCD's 4 MiB L2), then sweep the corpus once per tile - one probe of a
+// corpus key serves 128 queries, 8x fewer probes than the LDS tile.  Blocks of one tile are mapped
+// to one XCD (blockIdx % 8) so its table is served from that XCD's L2.  What it buys is bounded by
+// the L2: a random 16-byte probe moves a whole cache line, and the measured probe rate (~180 G/s)
+// is the L2's random-line rate - LDS has no line granularity, which is why the LDS tile stays
+// competitive with 8x the probes (1.18 vs 2.30 ms at C=100k, Q=1024).  An LDS presence bitmap of
+// the tile's keys (64 KiB) keeps ~70 % of the corpus keys from touching the L2 at all.  Per (row group, query) state lives in LDS: a u16 hit
+// counter and the two smallest matching positions (u16 + u16 in one CAS word); after a row each
+// lane scans 8 of the tile's 128 queries and emits the hits.
+constexpr int kJoinQ = 128;
+constexpr int kJoinBlock = 1024;
+constexpr int kJoinGroups = kJoinBlock / kGroup;
+constexpr int kJoinBloomBits = 1 << 19;                           // 64 KiB presence bitmap per tile
+constexpr size_t kJoinLds = (size_t)kJoinGroups * kJoinQ * 10 + kJoinBloomBits / 8;   // 80 + 64 KiB
+constexpr int64_t kJEmpty = -1;                                    // 0xff..ff: a NaN pattern
+
+__device__ __forceinline__ uint32_t hash32(int64_t k) {
+    const uint32_t lo = (uint32_t)k, hi = (uint32_t)((uint64_t)k >> 32);
+    uint32_t x = lo ^ (hi + (hi << 3)) ^ (hi >> 9);
+    x ^= x >> 20;
+    const uint32_t y = __umul24(x, 0x9E3779u);
+    return y ^ (y >> 15);
+}
+
+// Table layout: keys int64[S] and packs u32[S] apart, so ONE 16-byte load fetches the two keys of a
+// slot pair; the (position | query-in-tile << 12) pack is only loaded on a match.  Random global
+// accesses cost the CU's address pipeline ~1 lane-address per cycle, so loads per probe are what
+// bounds this kernel (an array-of-structs slot needed two loads per probe: 1.6x slower).
+
+// The table is a MULTIMAP: every query element takes its own slot (the first free one of its key's
+// probe sequence), so a lookup needs no dependent chain loads - it walks the probe sequence up to
+// the first free slot and accounts every slot that carries the key.  (A chained layout was tried:
+// on a 64-lane wave some lane almost always has a chain to follow, and each hop is a dependent
+// ~1 us L2 access.)
+__global__ __launch_bounds__(kBlock) void ts_join_build_kernel(
+    const double *__restrict__ queries, const int64_t *__restrict__ q_offsets, int32_t Q,
+    int32_t max_len, int32_t s_log2, unsigned long long *__restrict__ tkeys,
+    uint32_t *__restrict__ tpack, uint32_t *__restrict__ tbloom, int32_t *__restrict__ hits_n) {
+    const int q = blockIdx.y;
+    const int64_t o = q_offsets[q];
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    const int64_t len = q_offsets[q + 1] - o;
+    if (len > max_len) {
+        // max_query_len was not an upper bound (the table is sized from it): nothing of this
+        // query is inserted and its counter is poisoned instead (stays negative)
+        if (i == 0) hits_n[q] = INT32_MIN;
+        return;
+    }
+    if (i >= (int)len) return;
+    int64_t k;
+    if (!canon_key(queries[o + i], k)) return;                     // NaN never matches
+    const uint32_t smask = (1u << s_log2) - 1u;
+    const size_t tb = (size_t)(q / kJoinQ) << s_log2;
+    const uint32_t hv = hash32(k);
+    const uint32_t bit = hv & (uint32_t)(kJoinBloomBits - 1);      // presence bit (low hash bits)
+    atomicOr(&tbloom[(size_t)(q / kJoinQ) * (kJoinBloomBits / 32) + (bit >> 5)], 1u << (bit & 31));
+    uint32_t h = (hv >> (32 - s_log2)) & ~1u;                      // home pair (high hash bits)
+    while (true) {
+        const unsigned long long old = atomicCAS(&tkeys[tb + h], (unsigned long long)kJEmpty,
+                                                 (unsigned long long)k);
+        if (old == (unsigned long long)kJEmpty) break;             // claimed a free slot
+        h = (h + 1) & smask;
+    }
+    tpack[tb + h] = (uint32_t)i | ((uint32_t)(q % kJoinQ) << 12);
+}
+
+__global__ __launch_bounds__(kJoinBlock) void ts_match_join_kernel(
+    const Row *__restrict__ rows, int64_t n_rows, const int64_t *__restrict__ keys,
+    const int64_t *__restrict__ tkeys, const uint32_t *__restrict__ tpack,
+    const uint32_t *__restrict__ tbloom, int32_t s_log2, int32_t Q, int32_t n_tiles, int32_t n_chunks,
+    int32_t min_match, const int32_t *__restrict__ exclude_ids, int32_t cap,
+    int32_t *__restrict__ hits, int32_t *__restrict__ hits_n, int32_t rows_per_block) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint32_t *m1_all = reinterpret_cast<uint32_t *>(smem);                     // [groups][128] smallest pos
+    uint32_t *m2_all = m1_all + kJoinGroups * kJoinQ;                          // [groups][128] 2nd smallest
+    uint32_t *cnt_all = m2_all + kJoinGroups * kJoinQ;                         // [groups][64] 2 x u16
+    uint32_t *bloom = cnt_all + kJoinGroups * (kJoinQ / 2);                    // [2^19 bits]
+    // block -> (tile, chunk): blocks of one tile share blockIdx % 8, i.e. (observed) one XCD and its L2
+    const int b = blockIdx.x;
+    int tile, chunk;
+    if (8 % n_tiles == 0) {
+        const int g = 8 / n_tiles;                                             // XCDs per tile
+        tile = (b % 8) / g;
+        chunk = (b / 8) * g + (b % 8) % g;
+    } else if (n_tiles % 8 == 0) {
+        tile = (b % 8) + 8 * ((b / 8) % (n_tiles / 8));
+        chunk = (b / 8) / (n_tiles / 8);
+    } else {
+        tile = b / n_chunks;
+        chunk = b % n_chunks;
+    }
+    if (tile >= n_tiles || chunk >= n_chunks) return;
+    const int gl = threadIdx.x & (kGroup - 1);
+    const int g = threadIdx.x / kGroup;
+    uint32_t *m1 = m1_all + g * kJoinQ;
+    uint32_t *m2 = m2_all + g * kJoinQ;
+    uint32_t *cntw = cnt_all + g * (kJoinQ / 2);
+    for (int i = gl; i < kJoinQ; i += kGroup) { m1[i] = 0xffffffffu; m2[i] = 0xffffffffu; }
+    {   // the tile's presence bitmap: 64 KiB copied from device memory into LDS once per block
+        const uint4 *src = reinterpret_cast<const uint4 *>(tbloom + (size_t)tile * (kJoinBloomBits / 32));
+        uint4 *dst = reinterpret_cast<uint4 *>(bloom);
+        for (int i = threadIdx.x; i < kJoinBloomBits / 128; i += kJoinBlock) dst[i] = src[i];
+    }
+    __syncthreads();
+    for (int i = gl; i < kJoinQ / 2; i += kGroup) cntw[i] = 0;
+    const int q0 = tile * kJoinQ;
+    const uint32_t smask = (1u << s_log2) - 1u;
+    const int64_t *tk = tkeys + ((size_t)tile << s_log2);
+    const uint32_t *tp = tpack + ((size_t)tile << s_log2);
+    const int64_t r0 = (int64_t)chunk * rows_per_block;
+    int64_t r1 = r0 + rows_per_block;
+    if (r1 > n_rows) r1 = n_rows;
+
+    auto account = [&](uint32_t pk) {                    // one matching (query, position) entry
+        const uint32_t ql = pk >> 12, pos = pk & 0xfffu;
+        atomicAdd(&cntw[ql >> 1], 1u << (16 * (ql & 1)));
+        const uint32_t old = atomicMin(&m1[ql], pos);    // two plain LDS atomics, no CAS loop
+        atomicMin(&m2[ql], old > pos ? old : pos);       // larger of two distinct hits >= 2nd smallest
+    };
+
+    constexpr int kK = 4;                                // keys per lane and step: 8 table loads in flight
+    for (int64_t r = r0 + g; r < r1; r += kJoinGroups) {
+        const Row row = load_row(rows + r);
+        const int64_t *rk = keys + row.off;
+        for (int i0 = gl * 2; i0 < row.len; i0 += kGroup * kK) {
+            int64_t kk[kK];
+            bool valid[kK];
+#pragma unroll
+            for (int j = 0; j < kK / 2; ++j) {
+                const int i = i0 + j * kGroup * 2;
+                longlong2 v = make_longlong2(0, 0);
+                if (i < row.len) v = *reinterpret_cast<const longlong2 *>(rk + i);
+                kk[2 * j] = v.x;
+                kk[2 * j + 1] = v.y;
+                valid[2 * j] = i < row.len;
+                valid[2 * j + 1] = i + 1 < row.len;
+            }
+            uint32_t h[kK];
+            longlong2 sk[kK];
+#pragma unroll
+            for (int j = 0; j < kK; ++j) {               // independent L2 reads, all in flight
+                // LDS presence filter first: a random probe of the table costs a whole L2 line,
+                // and ~70 % of the corpus keys are in no query of the tile
+                const uint32_t hv = hash32(kk[j]);
+                const uint32_t bit = hv & (uint32_t)(kJoinBloomBits - 1);
+                h[j] = (hv >> (32 - s_log2)) & ~1u;
+                sk[j] = make_longlong2(kJEmpty, kJEmpty);
+                if (valid[j] && ((bloom[bit >> 5] >> (bit & 31)) & 1u))
+                    sk[j] = *reinterpret_cast<const longlong2 *>(tk + h[j]);
+            }
+#pragma unroll
+            for (int j = 0; j < kK; ++j) {
+                if (!valid[j]) continue;
+                if (sk[j].x == kk[j]) account(tp[h[j]]);
+                if (sk[j].x == kJEmpty) continue;
+                if (sk[j].y == kk[j]) account(tp[h[j] + 1]);
+                if (sk[j].y == kJEmpty) continue;
+                uint32_t hh = h[j];                      // home pair full: keep walking (rare)
+                while (true) {
+                    hh = (hh + 2) & smask;
+                    const longlong2 a = *reinterpret_cast<const longlong2 *>(tk + hh);
+                    if (a.x == kk[j]) account(tp[hh]);
+                    if (a.x == kJEmpty) break;
+                    if (a.y == kk[j]) account(tp[hh + 1]);
+                    if (a.y == kJEmpty) break;
+                }
+            }
+        }
+        // lane gl owns queries gl*8 .. gl*8+7 of the tile (4 counter words of 2 x u16)
+        wave_lds_fence();
+        const uint4 cw = *reinterpret_cast<const uint4 *>(cntw + gl * 4);
+        if ((cw.x | cw.y | cw.z | cw.w) == 0 && min_match > 0) continue;      // nothing matched
+        const uint32_t w[4] = {cw.x, cw.y, cw.z, cw.w};
+        uint32_t todo = 0;                               // bit j: query gl*8+j reaches min_match
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int c = (int)((w[j >> 1] >> (16 * (j & 1))) & 0xffffu);
+            todo |= (uint32_t)(c >= min_match && q0 + gl * 8 + j < Q) << j;
+        }
+        while (todo) {                                   // usually 0 or 1 iterations
+            const int j = __ffs(todo) - 1;
+            todo &= todo - 1;
+            const int ql = gl * 8 + j;
+            const int q = q0 + ql;
+            const uint32_t c = (w[j >> 1] >> (16 * (j & 1))) & 0xffffu;
+            if (!(exclude_ids && exclude_ids[q] == row.vid)) {
+                const int32_t kth = min_match <= 0 ? -1 : (int32_t)(min_match == 1 ? m1[ql] : m2[ql]);
+                const int slot = atomicAdd(&hits_n[q], 1);
+                if (slot < cap) {
+                    int32_t *hp = hits + ((int64_t)q * cap + slot) * 3;
+                    hp[0] = row.vid;
+                    hp[1] = (int32_t)c;
+                    hp[2] = kth;
+                }
+            }
+        }
+        // unconditional reset of this lane's 8 queries: 5 wide LDS stores, no per-query branches
+        const uint4 ones = make_uint4(0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu);
+        *reinterpret_cast<uint4 *>(cntw + gl * 4) = make_uint4(0, 0, 0, 0);
+        *reinterpret_cast<uint4 *>(m1 + gl * 8) = ones;
+        *reinterpret_cast<uint4 *>(m1 + gl * 8 + 4) = ones;
+        *reinterpret_cast<uint4 *>(m2 + gl * 8) = ones;
+        *reinterpret_cast<uint4 *>(m2 + gl * 8 + 4) = ones;
+        wave_lds_fence();
+    }
+}
+
+// ---- queries longer than a tile (> 4095 timestamps): counts by searching the SORTED query ----
+// Rare (a video with thousands of cuts), so simple beats fast: a 16-lane group owns a row, every
+// row key is binary-searched in the query's sorted distinct keys (sq, with multiplicities) and the
+// hit (video_id, count) is emitted with kth = -2 - row, which ts_kth_fixup_kernel resolves.
+template <int CTRL>
+__device__ __forceinline__ int dpp_row16(int v) {
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true);
+}
+
+__global__ __launch_bounds__(kBlock) void ts_match_longq_kernel(
+    const Row *__restrict__ rows, int64_t n_rows, const int64_t *__restrict__ keys,
+    const int64_t *__restrict__ sq, const int32_t *__restrict__ smult, int32_t m, int32_t min_match,
+    int32_t cap, int32_t *__restrict__ hits, int32_t *__restrict__ hits_n) {
+    const int gl = threadIdx.x & (kGroup - 1);
+    const int64_t r = (int64_t)blockIdx.x * kGroupsPerBlock + threadIdx.x / kGroup;
+    if (r >= n_rows) return;                       // whole 16-lane groups leave together
+    const Row row = load_row(rows + r);
+    const int64_t *rk = keys + row.off;
+    int cnt = 0;
+    for (int i = gl; i < row.len; i += kGroup) {
+        const int64_t k = rk[i];
+        int lo = 0, hi = m;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (sq[mid] < k) lo = mid + 1; else hi = mid;
+        }
+        if (lo < m && sq[lo] == k) cnt += smult[lo];
+    }
+    cnt += dpp_row16<0xB1>(cnt);    // quad_perm [1,0,3,2]
+    cnt += dpp_row16<0x4E>(cnt);    // quad_perm [2,3,0,1]
+    cnt += dpp_row16<0x141>(cnt);   // row_half_mirror
+    cnt += dpp_row16<0x140>(cnt);   // row_mirror
+    if (gl == 0 && cnt >= min_match) {
+        const int slot = atomicAdd(&hits_n[0], 1);
+        if (slot < cap) {
+            hits[slot * 3 + 0] = row.vid;
+            hits[slot * 3 + 1] = cnt;
+            hits[slot * 3 + 2] = (min_match <= 0) ? -1 : -2 - (int32_t)r;
+        }
+    }
+}
+
+// kth for min_match > 5: per stored hit, walk the query in order and binary-search the row.
+__global__ __launch_bounds__(kBlock) void ts_kth_fixup_kernel(
+    const Row *__restrict__ rows, const int64_t *__restrict__ keys,
+    const double *__restrict__ queries, const int64_t *__restrict__ q_offsets, int32_t min_match,
+    int32_t cap, int32_t *__restrict__ hits, const int32_t *__restrict__ hits_n) {
+    const int q = blockIdx.x;
+    const int gl = threadIdx.x & (kGroup - 1);
+    const int g = threadIdx.x / kGroup;
+    const int gshift = (threadIdx.x & 63) & ~(kGroup - 1);
+    int n = hits_n[q];
+    if (n > cap) n = cap;
+    const int64_t qo = q_offsets[q];
+    const int32_t qlen = (int32_t)(q_offsets[q + 1] - qo);
+    const double *qv = queries + qo;
+    for (int j = g; j < n; j += kGroupsPerBlock) {
+        int32_t *h = hits + ((int64_t)q * cap + j) * 3;
+        const int32_t code = h[2];
+        if (code > -2) continue;
+        const Row row = load_row(rows + (-2 - code));
+        const int64_t *rk = keys + row.off;
+        int kth = TVZ_KTH_NEVER;
+        int running = 0;
+        for (int base = 0; base < qlen && kth == TVZ_KTH_NEVER; base += kGroup) {
+            const int i = base + gl;
+            bool hit = false;
+            int64_t k;
+            if (i < qlen && canon_key(qv[i], k)) {
+                int lo = 0, hi = row.len;
+                while (lo < hi) {
+                    const int mid = (lo + hi) >> 1;
+                    if (rk[mid] < k) lo = mid + 1; else hi = mid;
+                }
+                hit = lo < row.len && rk[lo] == k;
+            }
+            const uint32_t m16 = (uint32_t)(__ballot(hit) >> gshift) & 0xffffu;
+            const int c = __popc(m16);
+            if (running + c >= min_match) {
+                uint32_t m = m16;
+                for (int need = min_match - running; need > 1; --need) m &= m - 1;
+                kth = base + (__ffs(m) - 1);
+            }
+            running += c;
+        }
+        if (gl == 0) h[2] = kth;
+    }
+}
+
+// ---------------------------------------------------------------- top-k
+constexpr int kSortCap = 2048;
+
+__device__ __forceinline__ uint64_t sort_key(int32_t vid, int32_t kth) {
+    return ((uint64_t)((uint32_t)kth + 1u) << 32) | (uint32_t)vid;   // NEVER + 1 wraps in unsigned
+}
+
+__device__ void bitonic_sort(uint64_t *key, int32_t *cnt, int n /* power of two */) {
+    for (int size = 2; size <= n; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            __syncthreads();
+            for (int i = threadIdx.x; i < n / 2; i += blockDim.x) {
+                const int lo = 2 * i - (i & (stride - 1));
+                const int hi = lo + stride;
+                const bool up = (lo & size) == 0;
+                const uint64_t a = key[lo], b = key[hi];
+                const int32_t ca = cnt[lo], cb = cnt[hi];
+                const bool gt = (a > b) || (a == b && ca > cb);
+                if (gt == up) {
+                    key[lo] = b; key[hi] = a;
+                    cnt[lo] = cb; cnt[hi] = ca;
+                }
+            }
+        }
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(kBlock) void ts_topk_kernel(const int32_t *__restrict__ lists,
+                                                         const int32_t *__restrict__ lists_n,
+                                                         int32_t n_lists, int32_t Q, int32_t cap,
+                                                         int32_t k, int32_t *__restrict__ topk,
+                                                         int32_t mode, int32_t *__restrict__ totals) {
+    // mode 0: plain.  mode 1 (shard side): the output has k+1 rows per query, row k carries the
+    // true number of hits as (-1, n, NEVER) so one all-gather moves lists and totals together; n is
+    // NEGATED when the shard's hit list overflowed its capacity (its top-k may then be inexact).
+    // mode 2 (merge side): every input list ends with such a row; |n| is summed into totals[q], and
+    // the sum is negated if any shard overflowed, so the caller knows to re-run with a larger cap.
+    __shared__ uint64_t key[kSortCap];
+    __shared__ int32_t cnt[kSortCap];
+    const int q = blockIdx.x;
+    int pos = 0;  // block-uniform fill level
+    long long total = 0;
+    bool overflow = false;
+    auto sort_and_keep = [&]() {
+        int P = 2;
+        while (P < pos) P <<= 1;
+        for (int i = pos + threadIdx.x; i < P; i += kBlock) { key[i] = ~0ULL; cnt[i] = 0; }
+        bitonic_sort(key, cnt, P);
+        if (pos > k) pos = k;
+    };
+    for (int l = 0; l < n_lists; ++l) {
+        int n = lists_n ? lists_n[(int64_t)l * Q + q] : cap;
+        const int32_t *src = lists + ((int64_t)l * Q + q) * (int64_t)cap * 3;
+        if (mode == 1) {
+            total += n;
+            if (n > cap) overflow = true;          // this shard's list was truncated
+        }
+        if (n > cap) n = cap;
+        if (mode == 2) {
+            n = cap - 1;
+            const int32_t t = src[(cap - 1) * 3 + 1];   // negative: that shard overflowed
+            total += t < 0 ? -(long long)t : t;
+            if (t < 0) overflow = true;
+        }
+        int j = 0;
+        while (j < n) {
+            int m = n - j;
+            if (m > kSortCap - pos) m = kSortCap - pos;
+            for (int i = threadIdx.x; i < m; i += kBlock) {
+                const int32_t vid = src[(j + i) * 3 + 0];
+                key[pos + i] = vid < 0 ? ~0ULL : sort_key(vid, src[(j + i) * 3 + 2]);
+                cnt[pos + i] = src[(j + i) * 3 + 1];
+            }
+            pos += m;
+            j += m;
+            __syncthreads();
+            if (pos == kSortCap) sort_and_keep();
+        }
+    }
+    __syncthreads();
+    sort_and_keep();
+    const int orows = (mode == 1) ? k + 1 : k;
+    if (threadIdx.x == 0) {
+        int32_t t = total > 0x7fffffffLL ? 0x7fffffff : (int32_t)total;
+        if (overflow) t = (t == 0) ? INT32_MIN : -t;   // negative total = some hit list was truncated
+        if (mode == 1) {
+            int32_t *o = topk + ((int64_t)q * orows + k) * 3;
+            o[0] = -1; o[1] = t; o[2] = TVZ_KTH_NEVER;
+        } else if (mode == 2 && totals) {
+            totals[q] = t;
+        }
+    }
+    for (int i = threadIdx.x; i < k; i += kBlock) {
+        int32_t *o = topk + ((int64_t)q * orows + i) * 3;
+        const uint64_t kk = (i < pos) ? key[i] : ~0ULL;
+        if (kk == ~0ULL) {
+            o[0] = -1; o[1] = 0; o[2] = TVZ_KTH_NEVER;
+        } else {
+            o[0] = (int32_t)(uint32_t)kk;
+            o[1] = cnt[i];
+            o[2] = (int32_t)(uint32_t)(kk >> 32) - 1;
+        }
+    }
+}
+
+// ---------------------------------------------------------------- opt-in alignment score
+// NOT the reference's verdict (db.py:79 is exact-only); north_star's "alignment/Jaccard" and the
+// stale README.md:291 ("0.1 s tolerance") ask for a shift/tolerance-aware score, reported alongside.
+// One wave per row: every (query_i, row_j) difference votes into an LDS histogram of bins of
+// width eps over [-max_offset, +max_offset]; output = best bin (ties: smaller |bin|, then the
+// negative one), its votes, and the votes of bin 0 (tolerant count without shift).
+constexpr int kAlignMaxBins = 4096;   // 16 KB of u32 per wave, 4 waves per block
+
+__global__ __launch_bounds__(kBlock) void ts_align_kernel(
+    const Row *__restrict__ rows, int64_t n_rows, const int64_t *__restrict__ keys,
+    const double *__restrict__ query, int32_t n, double eps, int32_t B,
+    int32_t *__restrict__ out) {
+    __shared__ uint32_t hist_all[kBlock / 64][kAlignMaxBins];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    uint32_t *hist = hist_all[wave];
+    const int nbins = 2 * B + 1;
+    for (int64_t r = (int64_t)blockIdx.x * (kBlock / 64) + wave; r < n_rows;
+         r += (int64_t)gridDim.x * (kBlock / 64)) {
+        const Row row = load_row(rows + r);
+        for (int b = lane; b < nbins; b += 64) hist[b] = 0;
+        const int64_t *rk = keys + row.off;
+        for (int j = lane; j < row.len; j += 64) {
+            const double c = __longlong_as_double(rk[j]);
+            for (int i = 0; i < n; ++i) {
+                const double q = query[i];
+                if (q != q) continue;                              // NaN never aligns
+                const double d = floor((c - q) / eps + 0.5);
+                if (d >= -(double)B && d <= (double)B) atomicAdd(&hist[(int)d + B], 1u);
+            }
+        }
+        // LDS ops of one wave complete in order: the votes above are visible to the scan below
+        wave_lds_fence();
+        unsigned long long best = 0;
+        for (int b = lane; b < nbins; b += 64) {
+            const int bin = b - B;
+            const uint32_t order = 2u * (uint32_t)(bin < 0 ? -bin : bin) + (bin > 0 ? 1u : 0u);
+            const unsigned long long key = ((unsigned long long)hist[b] << 14) | (16383u - order);
+            best = key > best ? key : best;
+        }
+        for (int off = 32; off > 0; off >>= 1) {
+            const unsigned long long o = __shfl_xor(best, off);
+            best = o > best ? o : best;
+        }
+        if (lane == 0) {
+            const uint32_t order = 16383u - (uint32_t)(best & 16383u);
+            const int mag = (int)(order >> 1);
+            int32_t *o = out + r * 5;
+            o[0] = row.vid;
+            o[1] = row.len;
+            o[2] = (order & 1u) ? mag : -mag;
+            o[3] = (int32_t)(best >> 14);
+            o[4] = (int32_t)hist[B];
+        }
+    }
+}
+
+
+// ---- single-query sweep: the streaming driver's per-micro-batch call and small batches -------
+// One query per block column (blockIdx.y).  Every block rebuilds the query's keys as a small
+// multimap in LDS (8-byte keys, load factor <= 0.5, usually 0.2; every query element takes its own
+// slot, so multiplicity is exact and a lookup walks slot PAIRS - one aligned ds_read_b128 - up to
+// the first free slot).  A 16-lane group owns one corpus row at a time and streams its keys with
+// 16-byte loads; hits are accounted in PER-LANE registers (count + the smallest matching query
+// positions), reduced over the 16 lanes once per row with DPP.  No per-row LDS state, no clears,
+// no atomics on the hot path; rows are spread over up to 2048 blocks, so the sweep is bounded by
+// how fast the corpus streams out of HBM / Infinity Cache: algorithmic bytes = 16 B row entry +
+// 8 B per key, each read once per query.
+constexpr int kQ1Block = 256;
+constexpr int kQ1Groups = kQ1Block / kGroup;          // rows in flight per block
+constexpr int kQ1MinLog2 = 8, kQ1MaxLog2 = 13;        // 256 .. 8192 slots (2 KiB .. 64 KiB of keys)
+constexpr int kQ1ModeM2 = 0;                          // min_match 1..2: two smallest positions
+constexpr int kQ1ModeTop5 = 1;                        // min_match 3..5: five smallest positions
+constexpr int kQ1ModeCount = 2;                       // min_match <= 0 (kth = -1) or > 5 (fix-up)
+
+struct HostOut {           // tvz_find_duplicates: hits go straight to pinned host memory
+    int32_t *hits;         // [blocks][region][3]
+    int32_t *counts;       // [blocks]
+    int32_t region;        // hit slots per block = rows one block can sweep
+};
+
+inline size_t q1_lds_bytes(int s_log2) { return ((size_t)8 + 2) << s_log2; }
+
+inline int q1_slots_log2(int64_t n) {
+    int s = kQ1MinLog2;
+    while (s < kQ1MaxLog2 && ((int64_t)1 << s) < 4 * n) ++s;
+    return s;
+}
+
+template <int CTRL>
+__device__ __forceinline__ uint32_t dpp16(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, true);
+}
+template <int CTRL>
+__device__ __forceinline__ unsigned long long dpp16_64(unsigned long long v) {
+    return ((unsigned long long)dpp16<CTRL>((uint32_t)(v >> 32)) << 32) | dpp16<CTRL>((uint32_t)v);
+}
+
+// butterfly over a 16-lane DPP row: after the four steps every lane holds the reduction of all
+// 16; each step combines two DISJOINT sets of lanes (needed for the second-smallest merge)
+#define TVZ_ROW16_BUTTERFLY(STEP) \
+    STEP(0xB1)  /* quad_perm [1,0,3,2] */ \
+    STEP(0x4E)  /* quad_perm [2,3,0,1] */ \
+    STEP(0x141) /* row_half_mirror     */ \
+    STEP(0x140) /* row_mirror          */
+
+template <int MODE, bool HOSTOUT>
+__global__ __launch_bounds__(kQ1Block) void ts_match_q1_kernel(
+    const Row *__restrict__ rows, int64_t n_rows, const int64_t *__restrict__ keys,
+    const double *__restrict__ queries, const int64_t *__restrict__ q_offsets, int32_t min_match,
+    const int32_t *__restrict__ exclude_ids, int32_t exclude_one, int32_t cap,
+    int32_t *__restrict__ hits, int32_t *__restrict__ hits_n, int32_t s_log2, HostOut ho) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int S = 1 << s_log2;
+    int64_t *skey = reinterpret_cast<int64_t *>(smem);
+    uint16_t *spos = reinterpret_cast<uint16_t *>(skey + S);
+    __shared__ int32_t s_nhits;
+    const int q = blockIdx.y;
+    const int64_t qo = q_offsets[q];
+    const int64_t n = q_offsets[q + 1] - qo;
+    if (threadIdx.x == 0) s_nhits = 0;
+    if (2 * n > S) {
+        // the caller's max_query_len was not an upper bound (the table is sized from it)
+        if (!HOSTOUT && threadIdx.x == 0) hits_n[q] = INT32_MIN;
+        if (HOSTOUT && threadIdx.x == 0) ho.counts[blockIdx.x] = INT32_MIN;
+        return;
+    }
+    for (int i = threadIdx.x * 2; i < S; i += kQ1Block * 2)
+        *reinterpret_cast<longlong2 *>(skey + i) = make_longlong2(kEmpty, kEmpty);
+    __syncthreads();
+    const int pair_shift = 33 - s_log2;               // home PAIR from the top hash bits
+    const uint32_t smask = (uint32_t)S - 1u;
+    auto home = [&](int64_t k) -> uint32_t {
+        const uint32_t lo = (uint32_t)k, hi = (uint32_t)((uint64_t)k >> 32);
+        uint32_t x = lo ^ (hi + (hi << 3)) ^ (hi >> 9);
+        x ^= x >> 20;
+        const uint32_t y = __umul24(x, 0x9E3779u);      // __umul24 returns int: shift the UNSIGNED copy
+        return (y >> pair_shift) << 1;
+    };
+    for (int e = threadIdx.x; e < (int)n; e += kQ1Block) {
+        int64_t k;
+        if (!canon_key(queries[qo + e], k)) continue;           // NaN never matches
+        uint32_t h = home(k);
+        while (atomicCAS(reinterpret_cast<unsigned long long *>(&skey[h]), (unsigned long long)kEmpty,
+                         (unsigned long long)k) != (unsigned long long)kEmpty)
+            h = (h + 1) & smask;
+        spos[h] = (uint16_t)e;
+    }
+    __syncthreads();
+
+    const int gl = threadIdx.x & (kGroup - 1);
+    const int g = threadIdx.x / kGroup;
+    const int32_t excl = exclude_ids ? exclude_ids[q] : exclude_one;
+    const int64_t stride = (int64_t)gridDim.x * kQ1Groups;
+    for (int64_t r = (int64_t)blockIdx.x * kQ1Groups + g; r < n_rows; r += stride) {
+        const Row row = load_row(rows + r);
+        const int64_t *rk = keys + row.off;
+        uint32_t cnt = 0, m1 = 0xffffffffu, m2 = 0xffffffffu;
+        unsigned long long top = kTopNone;
+        auto acc = [&](uint32_t pos) {
+            ++cnt;
+            if constexpr (MODE == kQ1ModeM2) {
+                const uint32_t lo = m1 < pos ? m1 : pos, hi = m1 < pos ? pos : m1;
+                m1 = lo;
+                m2 = m2 < hi ? m2 : hi;
+            } else if constexpr (MODE == kQ1ModeTop5) {
+                top = top5_insert(top, pos);
+            }
+        };
+        for (int i0 = gl * 2; i0 < row.len; i0 += 4 * kGroup) {
+            const bool second = i0 + 2 * kGroup < row.len;
+            const longlong2 a = *reinterpret_cast<const longlong2 *>(rk + i0);
+            longlong2 b = make_longlong2(kEmpty, kEmpty);
+            if (second) b = *reinterpret_cast<const longlong2 *>(rk + i0 + 2 * kGroup);
+            const int64_t kk[4] = {a.x, a.y, b.x, b.y};
+            const bool valid[4] = {true, i0 + 1 < row.len, second, i0 + 2 * kGroup + 1 < row.len};
+            uint32_t hp[4];
+            longlong2 w[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                hp[j] = home(kk[j]);
+                w[j] = *reinterpret_cast<const longlong2 *>(skey + hp[j]);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                // in the table, or its home pair is full (the probe sequence goes on)
+                const bool slow = valid[j] & ((w[j].x == kk[j]) | ((w[j].x != kEmpty) & (w[j].y != kEmpty)) |
+                                              (w[j].y == kk[j]));
+                if (slow) {
+                    uint32_t h = hp[j];
+                    longlong2 ww = w[j];
+                    while (true) {
+                        if (ww.x == kEmpty) break;
+                        if (ww.x == kk[j]) acc(spos[h]);
+                        if (ww.y == kEmpty) break;
+                        if (ww.y == kk[j]) acc(spos[h + 1]);
+                        h = (h + 2) & smask;
+                        ww = *reinterpret_cast<const longlong2 *>(skey + h);
+                    }
+                }
+            }
+        }
+        // the group's totals (every lane ends up with them)
+#define TVZ_SUM_STEP(C) cnt += dpp16<C>(cnt);
+        TVZ_ROW16_BUTTERFLY(TVZ_SUM_STEP)
+#undef TVZ_SUM_STEP
+        const bool hit = (int64_t)cnt >= (int64_t)min_match && row.vid != excl;
+        if constexpr (MODE == kQ1ModeM2) {
+#define TVZ_M2_STEP(C) { const uint32_t p1 = dpp16<C>(m1), p2 = dpp16<C>(m2); \
+            const uint32_t lo = m1 < p1 ? m1 : p1, hi = m1 < p1 ? p1 : m1, r2 = m2 < p2 ? m2 : p2; \
+            m1 = lo; m2 = hi < r2 ? hi : r2; }
+            TVZ_ROW16_BUTTERFLY(TVZ_M2_STEP)
+#undef TVZ_M2_STEP
+        } else if constexpr (MODE == kQ1ModeTop5) {
+            if (__ballot(hit) != 0ull) {                // rare: most rows never reach min_match
+#define TVZ_T5_STEP(C) { const unsigned long long p = dpp16_64<C>(top); \
+                _Pragma("unroll") for (int i = 0; i < kTop; ++i) top = top5_insert(top, (uint32_t)(p >> (12 * i)) & 0xfffu); }
+                TVZ_ROW16_BUTTERFLY(TVZ_T5_STEP)
+#undef TVZ_T5_STEP
+            }
+        }
+        if (hit && gl == 0) {
+            int32_t kth;
+            if (min_match <= 0) kth = -1;
+            else if constexpr (MODE == kQ1ModeM2) kth = (int32_t)(min_match == 1 ? m1 : m2);
+            else if constexpr (MODE == kQ1ModeTop5) kth = (int32_t)((top >> (12 * (min_match - 1))) & 0xfffu);
+            else kth = -2 - (int32_t)r;                 // resolved by ts_kth_fixup_kernel
+            if constexpr (HOSTOUT) {
+                const int slot = atomicAdd(&s_nhits, 1);
+                int32_t *h = ho.hits + ((int64_t)blockIdx.x * ho.region + slot) * 3;
+                h[0] = row.vid;
+                h[1] = (int32_t)cnt;
+                h[2] = kth;
+            } else {
+                const int slot = atomicAdd(&hits_n[q], 1);
+                if (slot < cap) {
+                    int32_t *h = hits + ((int64_t)q * cap + slot) * 3;
+                    h[0] = row.vid;
+                    h[1] = (int32_t)cnt;
+                    h[2] = kth;
+                }
+            }
+        }
+    }
+    if constexpr (HOSTOUT) {
+        __syncthreads();
+        if (threadIdx.x == 0) ho.counts[blockIdx.x] = s_nhits;
+    }
+}
+
+// ---- per-query k best of a (long) hit list -------------------------------------------------
+// Order: (kth, video_id, count) ascending.  A full bitonic sort of ~2,000 hits per query to keep
+// 16 was most of the fixed cost of a sharded batch; instead a histogram of kth (LDS, 4098 bins)
+// gives the smallest bin B whose prefix holds k hits, and only the hits in bins <= B (k plus the
+// ties of one bin) are sorted.  Lists that are short anyway skip the histogram.
+//   mode 0: plain.  mode 1 (shard side): the output has k+1 rows per query, row k carries the
+//   true number of hits as (-1, n, NEVER) so one all-gather moves lists and totals together; n is
+//   NEGATED when the shard's hit list overflowed its capacity (its top-k may then be inexact).
+constexpr int kSelBins = 4098;                // kth -1 .. 4095 exactly, everything above shares the last
+constexpr int kSelMin = 1024;                 // lists up to this long are sorted directly
+constexpr int kSelChunk = 1024;
+
+__device__ __forceinline__ int sel_bin(int32_t kth) {
+    const uint32_t b = (uint32_t)kth + 1u;    // -1 -> 0, NEVER -> 0x80000000
+    return b < (uint32_t)(kSelBins - 1) ? (int)b : kSelBins - 1;
+}
+
+__global__ __launch_bounds__(kBlock) void ts_topk_select_kernel(
+    const int32_t *__restrict__ lists, const int32_t *__restrict__ lists_n, int32_t Q, int32_t cap,
+    int32_t k, int32_t *__restrict__ topk, int32_t mode) {
+    __shared__ uint64_t key[kSortCap];
+    __shared__ int32_t cnt[kSortCap];
+    __shared__ uint32_t hist[kSelBins];
+    __shared__ uint32_t part[kBlock];
+    __shared__ int32_t s_pos, s_bin;
+    const int q = blockIdx.x;
+    const int32_t total = lists_n ? lists_n[q] : cap;
+    const bool overflow = total > cap;
+    const int n = total > cap ? cap : (total < 0 ? 0 : total);
+    const int32_t *src = lists + (int64_t)q * cap * 3;
+    int limit = kSelBins - 1;                 // keep hits whose bin is <= limit
+    if (threadIdx.x == 0) s_pos = 0;
+    if (n > kSelMin) {
+        for (int i = threadIdx.x; i < kSelBins; i += kBlock) hist[i] = 0;
+        __syncthreads();
+        for (int i = threadIdx.x; i < n; i += kBlock)
+            if (src[i * 3] >= 0) atomicAdd(&hist[sel_bin(src[i * 3 + 2])], 1u);
+        __syncthreads();
+        constexpr int kPer = (kSelBins + kBlock - 1) / kBlock;      // bins per thread
+        uint32_t s = 0;
+        for (int b = threadIdx.x * kPer; b < (threadIdx.x + 1) * kPer && b < kSelBins; ++b) s += hist[b];
+        part[threadIdx.x] = s;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t cum = 0;
+            int t = 0;
+            while (t < kBlock - 1 && cum + part[t] < (uint32_t)k) cum += part[t++];
+            int b = t * kPer;
+            while (b < kSelBins - 1 && cum + hist[b] < (uint32_t)k) cum += hist[b++];
+            s_bin = b;
+        }
+        __syncthreads();
+        limit = s_bin;
+    }
+    int pos = 0;                              // block-uniform fill level
+    auto sort_and_keep = [&]() {
+        int P = 2;
+        while (P < pos) P <<= 1;
+        for (int i = pos + threadIdx.x; i < P; i += kBlock) { key[i] = ~0ULL; cnt[i] = 0; }
+        bitonic_sort(key, cnt, P);
+        if (pos > k) pos = k;
+    };
+    __syncthreads();
+    for (int j0 = 0; j0 < n; j0 += kSelChunk) {
+        const int i = j0 + threadIdx.x;
+#pragma unroll
+        for (int u = 0; u < kSelChunk / kBlock; ++u) {
+            const int ii = i + u * kBlock;
+            if (ii < n && ii < j0 + kSelChunk) {
+                const int32_t vid = src[ii * 3], kth = src[ii * 3 + 2];
+                if (vid >= 0 && sel_bin(kth) <= limit) {
+                    const int p = atomicAdd(&s_pos, 1);
+                    key[p] = sort_key(vid, kth);
+                    cnt[p] = src[ii * 3 + 1];
+                }
+            }
+        }
+        __syncthreads();
+        pos = s_pos;
+        if (pos > kSortCap - kSelChunk) {     // no room for another chunk: reduce to the k best
+            sort_and_keep();
+            if (threadIdx.x == 0) s_pos = pos;
+            __syncthreads();
+        }
+    }
+    __syncthreads();
+    pos = s_pos;
+    sort_and_keep();
+    const int orows = (mode == 1) ? k + 1 : k;
+    if (mode == 1 && threadIdx.x == 0) {
+        int32_t t = total;
+        if (overflow) t = -t;                 // negative total = the hit list was truncated
+        int32_t *o = topk + ((int64_t)q * orows + k) * 3;
+        o[0] = -1; o[1] = t; o[2] = TVZ_KTH_NEVER;
+    }
+    for (int i = threadIdx.x; i < k; i += kBlock) {
+        int32_t *o = topk + ((int64_t)q * orows + i) * 3;
+        const uint64_t kk = (i < pos) ? key[i] : ~0ULL;
+        if (kk == ~0ULL) {
+            o[0] = -1; o[1] = 0; o[2] = TVZ_KTH_NEVER;
+        } else {
+            o[0] = (int32_t)(uint32_t)kk;
+            o[1] = cnt[i];
+            o[2] = (int32_t)(uint32_t)(kk >> 32) - 1;
+        }
+    }
+}
+
+// ---- small helpers launched around the sweeps ------------------------------------------------
+// hit counters = 0, hash-join key tables = 0xff.. (kJEmpty), presence bitmaps = 0: one launch
+__global__ __launch_bounds__(kBlock) void ts_prep_kernel(int32_t *__restrict__ hits_n, int32_t Q,
+                                                         uint4 *__restrict__ ones16, size_t n_ones16,
+                                                         uint4 *__restrict__ zero16, size_t n_zero16) {
+    const size_t i0 = (size_t)blockIdx.x * kBlock + threadIdx.x, step = (size_t)gridDim.x * kBlock;
+    for (size_t i = i0; i < (size_t)Q; i += step) hits_n[i] = 0;
+    for (size_t i = i0; i < n_ones16; i += step) ones16[i] = make_uint4(~0u, ~0u, ~0u, ~0u);
+    for (size_t i = i0; i < n_zero16; i += step) zero16[i] = make_uint4(0, 0, 0, 0);
+}
+
+// upsert: the row entry is swapped by ONE 16-byte store, ordered on the mutation stream behind
+// the copy of the row's new keys
+__global__ void ts_row_write_kernel(Row *dst, Row v) {
+    int4 w;
+    w.x = (int32_t)(uint32_t)(uint64_t)v.off;
+    w.y = (int32_t)(uint32_t)((uint64_t)v.off >> 32);
+    w.z = v.len;
+    w.w = v.vid;
+    *reinterpret_cast<int4 *>(dst) = w;
+}
+
+}  // namespace

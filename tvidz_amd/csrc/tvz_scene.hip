@@ -17,6 +17,15 @@
 //   the get_scene_score epilogue (mafd, diff, float32 clip, threshold).
 // Kernel 1g luma_sad_generic_kernel   same structure on 4-byte granules for padded
 //   rows / unaligned planes (slower, identical results).
+// Kernel 3  scene_tail_kernel         one block: compacts the selected frame indices into the
+//   caller's cut list and advances the device-resident stream state.
+//
+// Stream state (tvz.h tvz_scene_state_*): what get_scene_score carries between frames lives in
+// caller-owned DEVICE memory: {prev_mafd, have_prev, parity} + two frame buffers.  The SAD kernel
+// reads the predecessor frame from buffer[parity] and the waves that reach the batch's last
+// frame store their strip of it into buffer[parity ^ 1] (the bytes are in registers anyway);
+// the tail kernel flips parity.  No host value crosses a batch boundary, so a chain of
+// micro-batches is one stream-ordered (graph-capturable) sequence of launches.
 #include <algorithm>
 
 #include "tvz_common.h"
@@ -30,12 +39,48 @@ constexpr int kWave = 64;
 constexpr int kBlock = TVZ_SCENE_BLOCK;  // waves per block x 64
 constexpr int kWavesPerBlock = kBlock / kWave;
 
+// per-call kernel shape (tvz.h TVZ_SHAPE): there is no process-global knob
 struct Tuning {
     int U = 0;     // 16-byte loads per lane per frame on the flat path (1,2,4,8); 0 = auto
-    int tc = 0;    // frames per time chunk (multiple of 64); 0 = auto
+    int tc = 0;    // frames per time chunk (8, 16, 32 or a multiple of 64); 0 = auto
     int nt = 1;    // non-temporal loads on the flat path (+8..12 % on MI355X, profiles/r1_tune_scene.txt)
 };
-Tuning g_tune;
+
+// device-resident stream state: header + two tightly packed frame buffers
+struct StateHdr {
+    double prev_mafd;      // mafd of the last frame scored so far (0 before any)
+    int32_t have_prev;     // 0 right after a reset: the next frame is the first of the stream
+    int32_t parity;        // which frame buffer holds the predecessor frame
+    int64_t frames_seen;
+};
+constexpr size_t kStateHdrBytes = 256;
+// first 256 bytes of the (aligned) workspace
+struct WsHdr {
+    double last_mafd;      // mafd of the batch's last frame (finalize -> tail kernel)
+};
+constexpr size_t kWsHdrBytes = 256;
+
+struct StateArgs {
+    StateHdr *hdr;         // nullptr: self-contained batch
+    uint8_t *buf0, *buf1;
+};
+
+// predecessor of frame 0, where to keep this batch's last frame, first scored frame
+struct Carry {
+    const uint8_t *prev0;
+    uint8_t *tail;
+    int32_t t_first;
+};
+__device__ __forceinline__ Carry read_carry(const StateArgs &sa) {
+    Carry c{nullptr, nullptr, 1};
+    if (sa.hdr) {                      // wave-uniform scalar loads
+        const int32_t have = sa.hdr->have_prev, par = sa.hdr->parity;
+        c.prev0 = par ? sa.buf1 : sa.buf0;
+        c.tail = par ? sa.buf0 : sa.buf1;
+        c.t_first = have ? 0 : 1;
+    }
+    return c;
+}
 
 // ---- wave64 sum to lane 63 with DPP (row_shr within 16-lane rows, then row_bcast) ----
 template <int CTRL, int ROW_MASK>
@@ -102,16 +147,16 @@ __device__ __forceinline__ uint4 load16(const uint4 *p) {
 
 template <int U, bool NT, bool S16>
 __global__ __launch_bounds__(kBlock) void luma_sad_flat_kernel(
-    const uint8_t *__restrict__ luma, const uint8_t *__restrict__ prev0, int64_t T,
-    int64_t frame_stride, int64_t n16, int32_t n_strips, int32_t tc, int32_t t_first,
-    uint32_t *__restrict__ partial, int64_t Tpad) {
+    const uint8_t *__restrict__ luma, StateArgs sa, int64_t T, int64_t frame_stride, int64_t n16,
+    int32_t n_strips, int32_t tc, uint32_t *__restrict__ partial, int64_t Tpad) {
     const int lane = threadIdx.x & 63;
     const int strip = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
     if (strip >= n_strips) return;  // wave-uniform
+    const Carry cy = read_carry(sa);
     int64_t t0 = (int64_t)blockIdx.y * tc;
     const int64_t t1 = (t0 + tc < T) ? t0 + tc : T;
-    if (t0 < t_first) t0 = t_first;
-    if (t0 >= t1) return;
+    if (t0 < cy.t_first) t0 = cy.t_first;
+    const bool keep_tail = cy.tail != nullptr && t1 == T;      // this chunk ends the batch
 
     int64_t idx[U];
     bool ok[U];
@@ -121,10 +166,21 @@ __global__ __launch_bounds__(kBlock) void luma_sad_flat_kernel(
         ok[u] = i < n16;
         idx[u] = ok[u] ? i : 0;
     }
-    const uint4 *pp = (t0 == 0) ? reinterpret_cast<const uint4 *>(prev0)
+    uint4 prev[U], cur[U], nxt[U];
+    if (t0 >= t1) {
+        // nothing to score (a one-frame batch that starts a stream): only the tail frame moves
+        if (keep_tail) {
+            const uint4 *pl = reinterpret_cast<const uint4 *>(luma + (T - 1) * frame_stride);
+            uint4 *pt = reinterpret_cast<uint4 *>(cy.tail);
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (ok[u]) pt[idx[u]] = load16<NT>(pl + idx[u]);
+        }
+        return;
+    }
+    const uint4 *pp = (t0 == 0) ? reinterpret_cast<const uint4 *>(cy.prev0)
                                 : reinterpret_cast<const uint4 *>(luma + (t0 - 1) * frame_stride);
     const uint4 *pc = reinterpret_cast<const uint4 *>(luma + t0 * frame_stride);
-    uint4 prev[U], cur[U], nxt[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) prev[u] = load16<NT>(pp + idx[u]);
 #pragma unroll
@@ -157,6 +213,12 @@ __global__ __launch_bounds__(kBlock) void luma_sad_flat_kernel(
         }
     }
     score(t1 - 1);
+    if (keep_tail) {            // cur[] is the strip of frame T-1: the next batch's predecessor
+        uint4 *pt = reinterpret_cast<uint4 *>(cy.tail);
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (ok[u]) pt[idx[u]] = cur[u];
+    }
 }
 
 // 4-byte granules, arbitrary row stride / alignment.  granule g -> row g / gpr, x = 4*(g % gpr)
@@ -170,18 +232,27 @@ __device__ __forceinline__ uint32_t load_granule(const uint8_t *p, int nb) {
     return v;
 }
 
+__device__ __forceinline__ void store_granule(uint8_t *p, uint32_t v, int nb) {
+    if (nb == 4) {
+        __builtin_memcpy(p, &v, 4);
+    } else {
+        for (int i = 0; i < nb; ++i) p[i] = (uint8_t)(v >> (8 * i));
+    }
+}
+
 template <int U, bool S16>
 __global__ __launch_bounds__(kBlock) void luma_sad_generic_kernel(
-    const uint8_t *__restrict__ luma, const uint8_t *__restrict__ prev0, int64_t T,
-    int64_t frame_stride, int64_t row_stride, int32_t H, int32_t W /* row BYTES */, int32_t gpr, int64_t n_gran,
-    int32_t n_strips, int32_t tc, int32_t t_first, uint32_t *__restrict__ partial, int64_t Tpad) {
+    const uint8_t *__restrict__ luma, StateArgs sa, int64_t T, int64_t frame_stride,
+    int64_t row_stride, int32_t H, int32_t W /* row BYTES */, int32_t gpr, int64_t n_gran,
+    int32_t n_strips, int32_t tc, uint32_t *__restrict__ partial, int64_t Tpad) {
     const int lane = threadIdx.x & 63;
     const int strip = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
     if (strip >= n_strips) return;
+    const Carry cy = read_carry(sa);
     int64_t t0 = (int64_t)blockIdx.y * tc;
     const int64_t t1 = (t0 + tc < T) ? t0 + tc : T;
-    if (t0 < t_first) t0 = t_first;
-    if (t0 >= t1) return;
+    if (t0 < cy.t_first) t0 = cy.t_first;
+    const bool keep_tail = cy.tail != nullptr && t1 == T;
 
     int64_t off[U], off0[U];
     int nb[U];
@@ -193,7 +264,7 @@ __global__ __launch_bounds__(kBlock) void luma_sad_generic_kernel(
             const int32_t x = (int32_t)(g - y * gpr) * 4;
             nb[u] = (W - x < 4) ? (W - x) : 4;
             off[u] = y * row_stride + x;
-            off0[u] = y * (int64_t)W + x;  // prev0 is tightly packed
+            off0[u] = y * (int64_t)W + x;  // the state's frame buffers are tightly packed
         } else {
             nb[u] = 0;
             off[u] = 0;
@@ -201,9 +272,17 @@ __global__ __launch_bounds__(kBlock) void luma_sad_generic_kernel(
         }
     }
     uint32_t prev[U], cur[U];
+    if (t0 >= t1) {
+        if (keep_tail) {
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                store_granule(cy.tail + off0[u], load_granule(luma + (T - 1) * frame_stride + off[u], nb[u]), nb[u]);
+        }
+        return;
+    }
 #pragma unroll
     for (int u = 0; u < U; ++u)
-        prev[u] = (t0 == 0) ? load_granule(prev0 + off0[u], nb[u])
+        prev[u] = (t0 == 0) ? load_granule(cy.prev0 + off0[u], nb[u])
                             : load_granule(luma + (t0 - 1) * frame_stride + off[u], nb[u]);
     uint32_t *row = partial + (int64_t)strip * Tpad;
     Stash stash;
@@ -220,6 +299,10 @@ __global__ __launch_bounds__(kBlock) void luma_sad_generic_kernel(
         stash.put(lane, t, total);
         stash.maybe_flush(lane, t, t0, t1 - 1, row);
     }
+    if (keep_tail) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) store_granule(cy.tail + off0[u], prev[u], nb[u]);
+    }
 }
 
 // ---- get_scene_score epilogue (f_select.c): same operation order, true divisions ----
@@ -227,7 +310,6 @@ struct SelectParams {
     double count;      // (double)(W*H)
     double depth_div;  // (double)(1ULL << (bitdepth-8))
     double threshold;
-    double prev_mafd_in;
 };
 
 __device__ __forceinline__ double mafd_of(uint64_t sad, const SelectParams &p) {
@@ -255,13 +337,20 @@ __device__ __forceinline__ void scene_epilogue(uint64_t sad, bool first, double 
 constexpr int kFinT = 64;   // frames per finalize block
 constexpr int kFinG = 16;   // strip groups per finalize block
 
-// sum partial[s][t] over strips, then (optionally) the epilogue.  t_first = first scored frame
-// (1 when the batch starts a stream, 0 when a previous frame was supplied).
+// sum partial[s][t] over strips, then (optionally) the epilogue.  The first scored frame and the
+// predecessor's mafd come from the device-resident state (or: frame 1, 0.0 without one).
 __global__ __launch_bounds__(kFinT *kFinG) void scene_finalize_kernel(
     const uint32_t *__restrict__ partial, int32_t n_strips, int64_t Tpad, int64_t T,
-    int32_t t_first, SelectParams sp, uint64_t *__restrict__ sad_out, double *__restrict__ mafd_out,
-    double *__restrict__ score_out, uint8_t *__restrict__ sel_out) {
+    const StateHdr *__restrict__ st, SelectParams sp, uint64_t *__restrict__ sad_out,
+    double *__restrict__ mafd_out, double *__restrict__ score_out, uint8_t *__restrict__ sel_out,
+    WsHdr *__restrict__ wh) {
     __shared__ uint64_t red[kFinG][kFinT + 1];
+    int32_t t_first = 1;
+    double prev_mafd_in = 0.0;
+    if (st && st->have_prev) {
+        t_first = 0;
+        prev_mafd_in = st->prev_mafd;
+    }
     const int tl = threadIdx.x & (kFinT - 1);
     const int sg = threadIdx.x / kFinT;
     const int64_t bt = (int64_t)blockIdx.x * kFinT;
@@ -284,30 +373,31 @@ __global__ __launch_bounds__(kFinT *kFinG) void scene_finalize_kernel(
     if (sg == 0 && t < T) {
         const uint64_t sad = red[0][tl];
         if (sad_out) sad_out[t] = sad;
-        if (sel_out || score_out || mafd_out) {
-            const bool first = t < t_first;
-            double prev_mafd = sp.prev_mafd_in;
-            if (t - 1 >= t_first) prev_mafd = mafd_of(tl ? red[0][tl - 1] : red[0][kFinT], sp);
-            double mafd, score;
-            uint8_t sel;
-            scene_epilogue(sad, first, prev_mafd, sp, mafd, score, sel);
-            if (mafd_out) mafd_out[t] = mafd;
-            if (score_out) score_out[t] = score;
-            if (sel_out) sel_out[t] = sel;
-        }
+        const bool first = t < t_first;
+        double prev_mafd = prev_mafd_in;
+        if (t - 1 >= t_first) prev_mafd = mafd_of(tl ? red[0][tl - 1] : red[0][kFinT], sp);
+        double mafd, score;
+        uint8_t sel;
+        scene_epilogue(sad, first, prev_mafd, sp, mafd, score, sel);
+        if (mafd_out) mafd_out[t] = mafd;
+        if (score_out) score_out[t] = score;
+        if (sel_out) sel_out[t] = sel;
+        // an unscored first frame reports mafd 0 == ffmpeg's zero-initialised prev_mafd
+        if (t == T - 1) wh->last_mafd = mafd;
     }
 }
 
 __global__ __launch_bounds__(256) void scene_select_kernel(const uint64_t *__restrict__ sad,
-                                                           int64_t T, int32_t have_prev,
+                                                           int64_t T,
+                                                           const double *__restrict__ d_prev_mafd,
                                                            SelectParams sp,
                                                            uint8_t *__restrict__ sel_out,
                                                            double *__restrict__ score_out,
                                                            double *__restrict__ mafd_out) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= T) return;
-    const int64_t t_first = have_prev ? 0 : 1;
-    double prev_mafd = sp.prev_mafd_in;
+    const int64_t t_first = d_prev_mafd ? 0 : 1;
+    double prev_mafd = d_prev_mafd ? *d_prev_mafd : 0.0;
     if (t - 1 >= t_first) prev_mafd = mafd_of(sad[t - 1], sp);
     double mafd, score;
     uint8_t sel;
@@ -315,6 +405,55 @@ __global__ __launch_bounds__(256) void scene_select_kernel(const uint64_t *__res
     sel_out[t] = sel;
     if (score_out) score_out[t] = score;
     if (mafd_out) mafd_out[t] = mafd;
+}
+
+// One block: ascending indices of the selected frames -> cuts[1..], their number -> cuts[0];
+// then the stream state moves to the end of this batch (runs after the SAD + finalize kernels
+// of the batch and before those of the next one: stream order is the only synchronisation).
+constexpr int kTailBlock = 1024;
+__global__ __launch_bounds__(kTailBlock) void scene_tail_kernel(
+    const uint8_t *__restrict__ sel, int64_t T, int32_t *__restrict__ cuts, int32_t cuts_cap,
+    StateHdr *__restrict__ st, const WsHdr *__restrict__ wh) {
+    __shared__ int32_t wsum[kTailBlock / 64];
+    __shared__ int32_t s_base;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) s_base = 0;
+    __syncthreads();
+    if (cuts) {
+        for (int64_t b = 0; b < T; b += kTailBlock) {
+            const int64_t t = b + threadIdx.x;
+            const bool f = t < T && sel[t] != 0;
+            const unsigned long long bal = __ballot(f);
+            const int before = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32),
+                                                         __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+            if (lane == 0) wsum[wave] = __popcll(bal);
+            __syncthreads();
+            int ofs = s_base;
+            for (int w = 0; w < wave; ++w) ofs += wsum[w];
+            if (f && ofs + before < cuts_cap) cuts[1 + ofs + before] = (int32_t)t;
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                int tot = 0;
+                for (int w = 0; w < kTailBlock / 64; ++w) tot += wsum[w];
+                s_base += tot;
+            }
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) cuts[0] = s_base;
+    }
+    if (st && threadIdx.x == 0) {
+        st->prev_mafd = wh->last_mafd;
+        st->have_prev = 1;
+        st->parity ^= 1;
+        st->frames_seen += T;
+    }
+}
+
+__global__ void scene_state_reset_kernel(StateHdr *st) {
+    st->prev_mafd = 0.0;
+    st->have_prev = 0;
+    st->parity = 0;
+    st->frames_seen = 0;
 }
 
 // ---------------------------------------------------------------- host side
@@ -327,7 +466,6 @@ struct Plan {
     int32_t gpr;
     int32_t n_strips;
     int64_t Tpad;
-    int32_t tail;     // flat: bytes of H*W not covered by 16-byte chunks (always 0 here)
 };
 
 constexpr int kGenericU = 8;
@@ -350,17 +488,30 @@ void auto_shape(int64_t T, int64_t n16, int &U, int &tc) {
     while (tc < 256 && tc < want) tc *= 2;
 }
 
-Plan make_plan(bool flat, int64_t T, int32_t H, int32_t W, int bps) {
+int decode_shape(uint32_t shape, Tuning &tn) {
+    tn = Tuning{};
+    if (shape == TVZ_SHAPE_AUTO) return TVZ_OK;
+    tn.nt = (shape & TVZ_SHAPE_NO_NT) ? 0 : 1;
+    tn.U = (int)(shape & 0xffu);
+    tn.tc = (int)((shape >> 8) & 0xfffffu);
+    TVZ_REQUIRE(tn.U == 0 || tn.U == 1 || tn.U == 2 || tn.U == 4 || tn.U == 8,
+                "shape: U must be 0 (auto), 1, 2, 4 or 8");
+    TVZ_REQUIRE(tn.tc == 0 || tn.tc == 8 || tn.tc == 16 || tn.tc == 32 || tn.tc % 64 == 0,
+                "shape: tc must be 0 (auto), 8, 16, 32 or a multiple of 64");
+    return TVZ_OK;
+}
+
+Plan make_plan(bool flat, int64_t T, int32_t H, int32_t W, int bps, const Tuning &tn) {
     Plan p{};
     p.flat = flat;
-    p.tc = g_tune.tc ? g_tune.tc : 128;
+    p.tc = tn.tc ? tn.tc : 128;
     p.Tpad = tvz::round_up(T > 0 ? T : 1, 64);
     if (flat) {
         p.n16 = (int64_t)H * W * bps / 16;
         int aU = 4, atc = 128;
         auto_shape(T > 0 ? T : 1, p.n16, aU, atc);
-        p.U = g_tune.U ? g_tune.U : aU;
-        p.tc = g_tune.tc ? g_tune.tc : atc;
+        p.U = tn.U ? tn.U : aU;
+        p.tc = tn.tc ? tn.tc : atc;
         p.n_strips = (int32_t)tvz::ceil_div(p.n16, (int64_t)kWave * p.U);
     } else {
         p.U = kGenericU;
@@ -381,10 +532,13 @@ int check_dims(int64_t T, int32_t H, int32_t W) {
     return TVZ_OK;
 }
 
-int launch_sad(const uint8_t *d_luma, const uint8_t *d_prev0, int64_t T, int32_t H, int32_t W,
-               int64_t fs, int64_t rs, const Plan &p, uint32_t *partial, int bps, hipStream_t st) {
-    const int32_t t_first = d_prev0 ? 0 : 1;
-    if (T <= t_first) return TVZ_OK;
+size_t state_frame_bytes(int32_t H, int32_t W, int bps) {
+    return (size_t)tvz::round_up((int64_t)H * W * bps, 256);
+}
+
+int launch_sad(const uint8_t *d_luma, const StateArgs &sa, int64_t T, int32_t H, int32_t W,
+               int64_t fs, int64_t rs, const Plan &p, uint32_t *partial, int bps, int nt,
+               hipStream_t st) {
     dim3 grid((unsigned)tvz::ceil_div(p.n_strips, kWavesPerBlock), (unsigned)tvz::ceil_div(T, p.tc));
     if (grid.y > 65535u)
         return tvz::fail(TVZ_ERR_UNSUPPORTED, "batch of %lld frames needs more than 65535 time chunks",
@@ -392,11 +546,11 @@ int launch_sad(const uint8_t *d_luma, const uint8_t *d_prev0, int64_t T, int32_t
     if (p.flat) {
 #define TVZ_FLAT_(UU, NTV, S16V)                                                               \
     hipLaunchKernelGGL((luma_sad_flat_kernel<UU, NTV, S16V>), grid, dim3(kBlock), 0, st, d_luma,   \
-                       d_prev0, T, fs, p.n16, p.n_strips, p.tc, t_first, partial, p.Tpad)
+                       sa, T, fs, p.n16, p.n_strips, p.tc, partial, p.Tpad)
 #define TVZ_FLAT(UU)                                                                           \
     do {                                                                                       \
-        if (bps == 2) { if (g_tune.nt) TVZ_FLAT_(UU, true, true); else TVZ_FLAT_(UU, false, true); }   \
-        else          { if (g_tune.nt) TVZ_FLAT_(UU, true, false); else TVZ_FLAT_(UU, false, false); } \
+        if (bps == 2) { if (nt) TVZ_FLAT_(UU, true, true); else TVZ_FLAT_(UU, false, true); }   \
+        else          { if (nt) TVZ_FLAT_(UU, true, false); else TVZ_FLAT_(UU, false, false); } \
     } while (0)
         switch (p.U) {
             case 1: TVZ_FLAT(1); break;
@@ -410,55 +564,56 @@ int launch_sad(const uint8_t *d_luma, const uint8_t *d_prev0, int64_t T, int32_t
     } else {
         if (bps == 2)
             hipLaunchKernelGGL((luma_sad_generic_kernel<kGenericU, true>), grid, dim3(kBlock), 0, st,
-                               d_luma, d_prev0, T, fs, rs, H, W * 2, p.gpr, p.n_gran, p.n_strips,
-                               p.tc, t_first, partial, p.Tpad);
+                               d_luma, sa, T, fs, rs, H, W * 2, p.gpr, p.n_gran, p.n_strips,
+                               p.tc, partial, p.Tpad);
         else
             hipLaunchKernelGGL((luma_sad_generic_kernel<kGenericU, false>), grid, dim3(kBlock), 0, st,
-                               d_luma, d_prev0, T, fs, rs, H, W, p.gpr, p.n_gran, p.n_strips, p.tc,
-                               t_first, partial, p.Tpad);
+                               d_luma, sa, T, fs, rs, H, W, p.gpr, p.n_gran, p.n_strips, p.tc,
+                               partial, p.Tpad);
     }
     TVZ_HIP(hipGetLastError());
     return TVZ_OK;
 }
 
-SelectParams make_sp(int32_t H, int32_t W, int32_t bitdepth, double thr, double prev_mafd) {
+SelectParams make_sp(int32_t H, int32_t W, int32_t bitdepth, double thr) {
     SelectParams sp;
     sp.count = (double)((uint64_t)W * (uint64_t)H);
     sp.depth_div = (double)(1ULL << (bitdepth - 8));
     sp.threshold = thr;
-    sp.prev_mafd_in = prev_mafd;
     return sp;
 }
 
 }  // namespace
-
-// Not part of the stable ABI: kernel-shape knobs for A/B runs inside one process.
-TVZ_EXPORT int tvz_scene_set_tuning(int U, int tc, int nt) {
-    TVZ_REQUIRE(U == 0 || U == 1 || U == 2 || U == 4 || U == 8, "U must be 0 (auto), 1, 2, 4 or 8");
-    TVZ_REQUIRE(tc == 0 || tc == 8 || tc == 16 || tc == 32 || (tc > 0 && tc % 64 == 0),
-                "tc must be 0 (auto), 8, 16, 32 or a positive multiple of 64");
-    g_tune.U = U;
-    g_tune.tc = tc;
-    g_tune.nt = nt ? 1 : 0;
-    return TVZ_OK;
-}
 
 TVZ_EXPORT size_t tvz_scene_workspace_bytes(int64_t T, int32_t H, int32_t W) {
     if (T < 0 || H <= 0 || W <= 0) return 0;
     // worst case over every shape the launcher may pick: U=1 strips on the flat path
     // (16-bit samples double the plane: sized for them so one workspace serves both depths)
     const size_t a = (size_t)tvz::ceil_div((int64_t)H * W * 2 / 16 + 1, kWave) * (size_t)tvz::round_up(T > 0 ? T : 1, 64) * sizeof(uint32_t);
-    const size_t b = plan_bytes(make_plan(false, T, H, W, 2));
-    return (a > b ? a : b) + 256;
+    const size_t b = plan_bytes(make_plan(false, T, H, W, 2, Tuning{}));
+    return (a > b ? a : b) + kWsHdrBytes + 256;
+}
+
+TVZ_EXPORT size_t tvz_scene_state_bytes(int32_t H, int32_t W, int32_t bytes_per_sample) {
+    if (H <= 0 || W <= 0 || (bytes_per_sample != 1 && bytes_per_sample != 2)) return 0;
+    return kStateHdrBytes + 2 * state_frame_bytes(H, W, bytes_per_sample);
+}
+
+TVZ_EXPORT int tvz_scene_state_reset(void *d_state, void *hip_stream) {
+    TVZ_REQUIRE(d_state != nullptr, "d_state is NULL");
+    TVZ_REQUIRE(reinterpret_cast<uintptr_t>(d_state) % 256 == 0, "d_state must be 256-byte aligned");
+    hipLaunchKernelGGL(scene_state_reset_kernel, dim3(1), dim3(1), 0,
+                       reinterpret_cast<hipStream_t>(hip_stream), reinterpret_cast<StateHdr *>(d_state));
+    TVZ_HIP(hipGetLastError());
+    return TVZ_OK;
 }
 
 namespace {
 int scene_scores_impl(const uint8_t *d_luma, int bps, int64_t T, int32_t H, int32_t W,
-                      int64_t frame_stride_bytes, int64_t row_stride_bytes,
-                      const uint8_t *d_prev_frame, double prev_mafd_in, int32_t bitdepth,
-                      double threshold, uint64_t *d_sad_out, double *d_mafd, double *d_score,
-                      uint8_t *d_selected, void *d_workspace, size_t workspace_bytes,
-                      void *hip_stream) {
+                      int64_t frame_stride_bytes, int64_t row_stride_bytes, void *d_state,
+                      int32_t bitdepth, double threshold, uint64_t *d_sad_out, double *d_mafd,
+                      double *d_score, uint8_t *d_selected, int32_t *d_cuts, int32_t cuts_cap,
+                      void *d_workspace, size_t workspace_bytes, uint32_t shape, void *hip_stream) {
     if (int rc = check_dims(T, H, W)) return rc;
     if (T == 0) return TVZ_OK;
     TVZ_REQUIRE(d_luma != nullptr, "d_luma is NULL");
@@ -473,52 +628,71 @@ int scene_scores_impl(const uint8_t *d_luma, int bps, int64_t T, int32_t H, int3
                         reinterpret_cast<uintptr_t>(d_luma) % 2 == 0,
                     "16-bit planes must be 2-byte aligned");
     }
-    TVZ_REQUIRE(d_sad_out || d_selected || d_score || d_mafd, "nothing to compute: every output is NULL");
+    TVZ_REQUIRE(d_sad_out || d_selected || d_score || d_mafd || d_state,
+                "nothing to compute: every output is NULL");
+    TVZ_REQUIRE(d_cuts == nullptr || (d_selected != nullptr && cuts_cap >= 0),
+                "d_cuts needs d_selected and cuts_cap >= 0");
     TVZ_REQUIRE(d_workspace != nullptr, "d_workspace is NULL");
+    TVZ_REQUIRE(d_state == nullptr || reinterpret_cast<uintptr_t>(d_state) % 256 == 0,
+                "d_state must be 256-byte aligned");
+    Tuning tn;
+    if (int rc = decode_shape(shape, tn)) return rc;
     hipStream_t st = reinterpret_cast<hipStream_t>(hip_stream);
-    bool flat = flat_ok(d_luma, frame_stride_bytes, row_stride_bytes, H, W, bps);
-    if (d_prev_frame && (reinterpret_cast<uintptr_t>(d_prev_frame) % 16) != 0) flat = false;
-    const Plan p = make_plan(flat, T, H, W, bps);
+    const bool flat = flat_ok(d_luma, frame_stride_bytes, row_stride_bytes, H, W, bps);
+    const Plan p = make_plan(flat, T, H, W, bps, tn);
     uintptr_t ws = (reinterpret_cast<uintptr_t>(d_workspace) + 255) & ~(uintptr_t)255;
     const size_t lost = ws - reinterpret_cast<uintptr_t>(d_workspace);
-    if (workspace_bytes < lost + plan_bytes(p))
+    if (workspace_bytes < lost + kWsHdrBytes + plan_bytes(p))
         return tvz::fail(TVZ_ERR_WORKSPACE, "workspace of %zu bytes, need %zu", workspace_bytes,
-                         lost + plan_bytes(p));
-    uint32_t *partial = reinterpret_cast<uint32_t *>(ws);
-    if (int rc = launch_sad(d_luma, d_prev_frame, T, H, W, frame_stride_bytes, row_stride_bytes, p,
-                            partial, bps, st))
+                         lost + kWsHdrBytes + plan_bytes(p));
+    WsHdr *wh = reinterpret_cast<WsHdr *>(ws);
+    uint32_t *partial = reinterpret_cast<uint32_t *>(ws + kWsHdrBytes);
+    StateArgs sa{nullptr, nullptr, nullptr};
+    if (d_state) {
+        sa.hdr = reinterpret_cast<StateHdr *>(d_state);
+        sa.buf0 = reinterpret_cast<uint8_t *>(d_state) + kStateHdrBytes;
+        sa.buf1 = sa.buf0 + state_frame_bytes(H, W, bps);
+    }
+    if (int rc = launch_sad(d_luma, sa, T, H, W, frame_stride_bytes, row_stride_bytes, p, partial,
+                            bps, tn.nt, st))
         return rc;
-    const SelectParams sp = make_sp(H, W, bitdepth, threshold, prev_mafd_in);
+    const SelectParams sp = make_sp(H, W, bitdepth, threshold);
     hipLaunchKernelGGL(scene_finalize_kernel, dim3((unsigned)tvz::ceil_div(T, kFinT)),
-                       dim3(kFinT * kFinG), 0, st, partial, p.n_strips, p.Tpad, T,
-                       d_prev_frame ? 0 : 1, sp, d_sad_out, d_mafd, d_score, d_selected);
+                       dim3(kFinT * kFinG), 0, st, partial, p.n_strips, p.Tpad, T, sa.hdr, sp,
+                       d_sad_out, d_mafd, d_score, d_selected, wh);
     TVZ_HIP(hipGetLastError());
+    if (d_cuts || d_state) {
+        hipLaunchKernelGGL(scene_tail_kernel, dim3(1), dim3(kTailBlock), 0, st, d_selected, T, d_cuts,
+                           cuts_cap, sa.hdr, wh);
+        TVZ_HIP(hipGetLastError());
+    }
     return TVZ_OK;
 }
 }  // namespace
 
 TVZ_EXPORT int tvz_scene_scores_u8(const uint8_t *d_luma, int64_t T, int32_t H, int32_t W,
                                    int64_t frame_stride_bytes, int64_t row_stride_bytes,
-                                   const uint8_t *d_prev_frame, double prev_mafd_in,
-                                   int32_t bitdepth, double threshold, uint64_t *d_sad_out,
-                                   double *d_mafd, double *d_score, uint8_t *d_selected,
-                                   void *d_workspace, size_t workspace_bytes, void *hip_stream) {
-    return scene_scores_impl(d_luma, 1, T, H, W, frame_stride_bytes, row_stride_bytes, d_prev_frame,
-                             prev_mafd_in, bitdepth, threshold, d_sad_out, d_mafd, d_score,
-                             d_selected, d_workspace, workspace_bytes, hip_stream);
+                                   void *d_state, int32_t bitdepth, double threshold,
+                                   uint64_t *d_sad_out, double *d_mafd, double *d_score,
+                                   uint8_t *d_selected, int32_t *d_cuts, int32_t cuts_cap,
+                                   void *d_workspace, size_t workspace_bytes, uint32_t shape,
+                                   void *hip_stream) {
+    return scene_scores_impl(d_luma, 1, T, H, W, frame_stride_bytes, row_stride_bytes, d_state,
+                             bitdepth, threshold, d_sad_out, d_mafd, d_score, d_selected, d_cuts,
+                             cuts_cap, d_workspace, workspace_bytes, shape, hip_stream);
 }
 
 TVZ_EXPORT int tvz_scene_scores_u16(const uint16_t *d_luma, int64_t T, int32_t H, int32_t W,
                                     int64_t frame_stride_bytes, int64_t row_stride_bytes,
-                                    const uint16_t *d_prev_frame, double prev_mafd_in,
-                                    int32_t bitdepth, double threshold, uint64_t *d_sad_out,
-                                    double *d_mafd, double *d_score, uint8_t *d_selected,
-                                    void *d_workspace, size_t workspace_bytes, void *hip_stream) {
+                                    void *d_state, int32_t bitdepth, double threshold,
+                                    uint64_t *d_sad_out, double *d_mafd, double *d_score,
+                                    uint8_t *d_selected, int32_t *d_cuts, int32_t cuts_cap,
+                                    void *d_workspace, size_t workspace_bytes, uint32_t shape,
+                                    void *hip_stream) {
     return scene_scores_impl(reinterpret_cast<const uint8_t *>(d_luma), 2, T, H, W,
-                             frame_stride_bytes, row_stride_bytes,
-                             reinterpret_cast<const uint8_t *>(d_prev_frame), prev_mafd_in, bitdepth,
-                             threshold, d_sad_out, d_mafd, d_score, d_selected, d_workspace,
-                             workspace_bytes, hip_stream);
+                             frame_stride_bytes, row_stride_bytes, d_state, bitdepth, threshold,
+                             d_sad_out, d_mafd, d_score, d_selected, d_cuts, cuts_cap, d_workspace,
+                             workspace_bytes, shape, hip_stream);
 }
 
 TVZ_EXPORT int tvz_luma_sad_u8(const uint8_t *d_luma, int64_t T, int32_t H, int32_t W,
@@ -526,22 +700,22 @@ TVZ_EXPORT int tvz_luma_sad_u8(const uint8_t *d_luma, int64_t T, int32_t H, int3
                                uint64_t *d_sad_out, void *d_workspace, size_t workspace_bytes,
                                void *hip_stream) {
     TVZ_REQUIRE(d_sad_out != nullptr || T == 0, "d_sad_out is NULL");
-    return tvz_scene_scores_u8(d_luma, T, H, W, frame_stride_bytes, row_stride_bytes, nullptr, 0.0,
-                               8, 0.0, d_sad_out, nullptr, nullptr, nullptr, d_workspace,
-                               workspace_bytes, hip_stream);
+    return tvz_scene_scores_u8(d_luma, T, H, W, frame_stride_bytes, row_stride_bytes, nullptr, 8,
+                               0.0, d_sad_out, nullptr, nullptr, nullptr, nullptr, 0, d_workspace,
+                               workspace_bytes, TVZ_SHAPE_AUTO, hip_stream);
 }
 
 TVZ_EXPORT int tvz_scene_select(const uint64_t *d_sad, int64_t T, int32_t H, int32_t W,
-                                int32_t bitdepth, double threshold, double prev_mafd_in,
-                                int32_t have_prev, uint8_t *d_selected, double *d_score,
-                                double *d_mafd, void *hip_stream) {
+                                int32_t bitdepth, double threshold, const double *d_prev_mafd,
+                                uint8_t *d_selected, double *d_score, double *d_mafd,
+                                void *hip_stream) {
     if (int rc = check_dims(T, H, W)) return rc;
     if (T == 0) return TVZ_OK;
     TVZ_REQUIRE(d_sad && d_selected, "d_sad / d_selected is NULL");
     TVZ_REQUIRE(bitdepth >= 8 && bitdepth <= 16, "bitdepth %d out of range", bitdepth);
-    const SelectParams sp = make_sp(H, W, bitdepth, threshold, prev_mafd_in);
+    const SelectParams sp = make_sp(H, W, bitdepth, threshold);
     hipLaunchKernelGGL(scene_select_kernel, dim3((unsigned)tvz::ceil_div(T, 256)), dim3(256), 0,
-                       reinterpret_cast<hipStream_t>(hip_stream), d_sad, T, have_prev, sp,
+                       reinterpret_cast<hipStream_t>(hip_stream), d_sad, T, d_prev_mafd, sp,
                        d_selected, d_score, d_mafd);
     TVZ_HIP(hipGetLastError());
     return TVZ_OK;

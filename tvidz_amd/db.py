@@ -14,6 +14,15 @@ video_id (the reference's order is unspecified: no ORDER BY at db.py:83).
 
 Unlike the reference there is no import-time connection/DDL (db.py:8,30): call init() — or let
 the first use do it from POSTGRES_URL (db.py:7), default unchanged.
+
+Ownership of the table: the HBM mirror follows THIS process's add_timestamps / clear calls.  The
+reference re-reads `video_timestamps` on every call (db.py:83) and so also sees rows written by
+other workers or by plain SQL; here such writers are detected by a cheap census
+(`SELECT count(*), max(id)`, Store.sync_if_stale - the driver runs it once per upload) that reloads
+the mirror when rows were added or removed behind its back.  An in-place UPDATE of an existing row
+by another writer is NOT detected: run one inspector process per table, or call reload_corpus().
+If the device upsert fails after the SQL commit the mirror is marked dirty and reloaded on the
+next use.
 """
 from __future__ import annotations
 
@@ -69,6 +78,8 @@ class Store:
             corpus = DeviceCorpus(device)
         self.corpus = corpus
         self._write_lock = threading.Lock()
+        self._census = (0, 0)            # (row count, max id) of video_timestamps as this process knows it
+        self._dirty = False
         self.reload_corpus()
 
     # -- device mirror -------------------------------------------------------
@@ -79,10 +90,28 @@ class Store:
             rows = session.query(VideoTimestamps).order_by(VideoTimestamps.id).all()
             data = [(int(r.video_id), [float(x) for x in (r.timestamps or [])]) for r in rows
                     if r.video_id is not None]
+            census = (len(rows), max((int(r.id) for r in rows), default=0))
         finally:
             session.close()
         self.corpus.upload(data)
+        self._census = census
+        self._dirty = False
         return len(data)
+
+    def sync_if_stale(self) -> bool:
+        """Reload the mirror if `video_timestamps` gained or lost rows that this process did not
+        write (another worker, plain SQL), or if a device upsert failed after its SQL commit."""
+        from sqlalchemy import func
+        with self._write_lock:
+            session = self.SessionLocal()
+            try:
+                cnt, mx = session.query(func.count(VideoTimestamps.id), func.max(VideoTimestamps.id)).one()
+            finally:
+                session.close()
+            if self._dirty or (int(cnt or 0), int(mx or 0)) != self._census:
+                self.reload_corpus()
+                return True
+        return False
 
     # -- reference API -------------------------------------------------------
     def add_video(self, filename, thumbnail_path=None):         # db.py:32-41
@@ -106,12 +135,19 @@ class Store:
                           .order_by(VideoTimestamps.id).first())
                 if ts_row:
                     ts_row.timestamps = ts
+                    session.commit()
                 else:
-                    session.add(VideoTimestamps(video_id=video_id, timestamps=ts))
-                session.commit()
+                    ts_row = VideoTimestamps(video_id=video_id, timestamps=ts)
+                    session.add(ts_row)
+                    session.commit()
+                    self._census = (self._census[0] + 1, max(self._census[1], int(ts_row.id)))
             finally:
                 session.close()
-            self.corpus.upsert(int(video_id), ts)
+            try:
+                self.corpus.upsert(int(video_id), ts)
+            except Exception:
+                self._dirty = True          # SQL has the row, the mirror may not: reload on next use
+                raise
 
     def update_duplicates(self, video_id, duplicate_ids):       # db.py:66-74
         session = self.SessionLocal()
@@ -162,6 +198,7 @@ class Store:
             finally:
                 session.close()
             self.corpus.clear()
+            self._census = (0, 0)
 
     def list_videos(self):                                      # app.py:347-366
         session = self.SessionLocal()

@@ -6,10 +6,16 @@ here decode stays on the host (ffmpeg as a raw-video pipe, or a Y4M file) and on
 plane — the only plane ffmpeg's scene score reads for planar YUV — crosses PCIe, batched and
 double-buffered so the copy of batch i+1 overlaps the scoring of batch i.
 
-Readers yield uint8 [H,W] luma planes plus (time_base, total_frames):
-  Y4MReader       YUV4MPEG2 files/streams (no external tool)
-  FFmpegReader    `ffmpeg -i <file> -f rawvideo -` pipe in the stream's native 8-bit planar
-                  YUV format (Y plane sliced out, no colour conversion); needs an ffmpeg binary
+Readers deliver luma planes plus (time_base, total_frames) and the presentation timestamp of
+every frame (`pts_of(n)`, in time_base units: showinfo prints pts * time_base, app.py:230):
+  Y4MReader       YUV4MPEG2 files/streams (no external tool); pts = frame index, time base 1/fps
+  FFmpegReader    `ffmpeg -i <file> -fps_mode passthrough -f rawvideo -` pipe in the stream's native
+                  planar YUV format (Y plane sliced out, no colour conversion) + the stream's real
+                  packet timestamps from ffprobe; needs the host's ffmpeg/ffprobe binaries
+
+SlotPool / FrameFeeder: a bounded, process-wide pool of pinned host slots and device slots of a
+fixed BYTE size shared by all concurrent uploads (a 4K upload gets micro-batches of a few frames,
+a 480p upload of a hundred), filled by one reader thread per upload and copied on a copy stream.
 """
 from __future__ import annotations
 
@@ -115,6 +121,9 @@ class Y4MReader:
             n += 1
         return n
 
+    def pts_of(self, n: int) -> int:
+        return int(n)                            # yuv4mpegpipe: pts = frame number, time base 1/fps
+
     def close(self):
         if self._own:
             self.f.close()
@@ -141,16 +150,32 @@ def write_y4m(path: str, luma: np.ndarray, fps: Tuple[int, int] = (30, 1), chrom
 
 
 class FFmpegReader:
-    """Decode with the host's ffmpeg into a raw planar-YUV pipe and slice the Y plane out."""
+    """Decode with the host's ffmpeg into a raw planar-YUV pipe and slice the Y plane out.
+
+    What the reference's single ffmpeg process does in one go (decode -> select -> showinfo,
+    app.py:202-209) is split here: decode stays in the child, the score moves to the GPU, and the
+    `pts_time` showinfo would have printed is rebuilt from the stream's own timestamps:
+      * `-fps_mode passthrough` (`-vsync 0` before FFmpeg 5.1): the reference's `-f null` muxer
+        passes frames through with their timestamps, whereas `-f rawvideo` defaults to constant
+        frame rate and would duplicate / drop frames of a variable-rate input (a duplicated frame
+        has mafd 0 and inflates the next score);
+      * pts_of(n) = n-th smallest packet pts of the video stream (presentation order), read once
+        with ffprobe without decoding, in units of the STREAM time base (1/15360, 1/90000 ...) -
+        frame index * time_base only holds for Y4M.
+    """
 
     PLANAR8 = {"yuv420p": "420", "yuvj420p": "420", "yuv422p": "422", "yuvj422p": "422",
                "yuv444p": "444", "yuvj444p": "444", "gray": "mono"}
+    PLANAR16 = {"yuv420p10le": ("420", 10), "yuv422p10le": ("422", 10), "yuv444p10le": ("444", 10),
+                "yuv420p12le": ("420", 12), "yuv422p12le": ("422", 12), "yuv444p12le": ("444", 12),
+                "gray10le": ("mono", 10), "gray12le": ("mono", 12), "gray16le": ("mono", 16)}
 
     def __init__(self, path: str, ffmpeg: Optional[str] = None, ffprobe: Optional[str] = None):
         self.ffmpeg = ffmpeg or shutil.which("ffmpeg")
         self.ffprobe = ffprobe or shutil.which("ffprobe")
         if not self.ffmpeg or not self.ffprobe:
             raise RuntimeError("ffmpeg/ffprobe not found on this host")
+        self.proc = None
         out = subprocess.check_output(
             [self.ffprobe, "-v", "error", "-select_streams", "v:0", "-show_entries",
              "stream=width,height,pix_fmt,time_base,nb_frames", "-of", "default=noprint_wrappers=1", path],
@@ -158,24 +183,86 @@ class FFmpegReader:
         info = dict(l.split("=", 1) for l in out.strip().splitlines() if "=" in l)
         self.W, self.H = int(info["width"]), int(info["height"])
         self.pix_fmt = info["pix_fmt"]
-        if self.pix_fmt not in self.PLANAR8:
-            raise RuntimeError(f"pix_fmt {self.pix_fmt} is not 8-bit planar YUV")
+        if self.pix_fmt in self.PLANAR8:
+            chroma, self.bitdepth = self.PLANAR8[self.pix_fmt], 8
+        elif self.pix_fmt in self.PLANAR16:
+            chroma, self.bitdepth = self.PLANAR16[self.pix_fmt]
+        else:
+            raise RuntimeError(f"pix_fmt {self.pix_fmt} is not planar YUV / gray (packed and "
+                               "semi-planar inputs are not supported)")
+        self.bps = 1 if self.bitdepth == 8 else 2
         n, d = info["time_base"].split("/")
         self.time_base = (int(n), int(d))
-        self.total_frames = int(info["nb_frames"]) if info.get("nb_frames", "").isdigit() else 0
-        self.bitdepth, self.bps = 8, 1
-        self._luma = self.W * self.H
-        self._skip = _chroma_bytes(self.PLANAR8[self.pix_fmt], self.W, self.H)
-        self.proc = subprocess.Popen([self.ffmpeg, "-v", "error", "-i", path, "-f", "rawvideo",
-                                      "-pix_fmt", self.pix_fmt, "-"], stdout=subprocess.PIPE)
+        self._pts = self._packet_pts(path)
+        # frame count for the progress bar (app.py:176-188): nb_frames, else the demuxed packet
+        # count, else the reference's own fallback `ffprobe -count_frames` (a full decode), else 0
+        if info.get("nb_frames", "").isdigit():
+            self.total_frames = int(info["nb_frames"])
+        elif self._pts:
+            self.total_frames = len(self._pts)
+        else:
+            self.total_frames = self._count_frames(path)
+        self._luma = self.W * self.H * self.bps
+        self._skip = _chroma_bytes(chroma, self.W, self.H) * self.bps
+        self.proc = subprocess.Popen([self.ffmpeg, "-v", "error", "-i", path] + self._sync_flags() +
+                                     ["-f", "rawvideo", "-pix_fmt", self.pix_fmt, "-"],
+                                     stdout=subprocess.PIPE)
         self.f = self.proc.stdout
+
+    def _sync_flags(self):
+        """Frame pass-through: `-fps_mode passthrough` from FFmpeg 5.1, `-vsync 0` before."""
+        try:
+            first = subprocess.check_output([self.ffmpeg, "-version"], text=True).splitlines()[0]
+            ver = first.split("version", 1)[1].split()[0].lstrip("n")
+            major, minor = (int(x) for x in (ver.split(".") + ["0"])[:2])
+            if (major, minor) < (5, 1):
+                return ["-vsync", "0"]
+        except Exception:
+            pass                                  # git builds ("N-1234-g..."): assume current
+        return ["-fps_mode", "passthrough"]
+
+    def _packet_pts(self, path: str):
+        try:
+            out = subprocess.check_output(
+                [self.ffprobe, "-v", "error", "-select_streams", "v:0", "-show_entries", "packet=pts",
+                 "-of", "csv=p=0", path], text=True)
+        except Exception:
+            return []
+        pts = []
+        for line in out.splitlines():
+            tok = line.strip().strip(",")
+            if tok.lstrip("-").isdigit():
+                pts.append(int(tok))
+        pts.sort()                                # decode order -> presentation order
+        return pts
+
+    def _count_frames(self, path: str) -> int:
+        """app.py:183-188: `ffprobe -count_frames ... stream=nb_read_frames`."""
+        try:
+            out = subprocess.check_output(
+                [self.ffprobe, "-v", "error", "-count_frames", "-select_streams", "v:0",
+                 "-show_entries", "stream=nb_read_frames", "-of",
+                 "default=nokey=1:noprint_wrappers=1", path], text=True)
+            return int(out.strip())
+        except Exception:
+            return 0
+
+    def pts_of(self, n: int) -> int:
+        """Presentation timestamp of frame n in time_base units (frame index when the container
+        carries no packet timestamps, e.g. raw streams)."""
+        return self._pts[n] if n < len(self._pts) else int(n)
 
     def read_into(self, out: np.ndarray) -> int:
         n = 0
-        flat = out.reshape(out.shape[0], -1)
+        flat = out.reshape(out.shape[0], -1).view(np.uint8)
         while n < out.shape[0]:
             got = self.f.readinto(memoryview(flat[n]))
-            if got < self._luma:
+            while got is not None and 0 < got < self._luma:      # a pipe may deliver short reads
+                more = self.f.readinto(memoryview(flat[n])[got:])
+                if not more:
+                    break
+                got += more
+            if not got or got < self._luma:
                 break
             if self._skip:
                 self.f.read(self._skip)
@@ -183,95 +270,212 @@ class FFmpegReader:
         return n
 
     def close(self):
+        """app.py:249-252 stops decoding at the first duplicate: terminate, then reap the child and
+        close the pipe so a long-running service leaves no zombie ffmpeg / open fd behind."""
+        proc, self.proc = self.proc, None
+        if proc is None:
+            return
         try:
-            self.proc.terminate()        # app.py:249-252: stop decoding at the first duplicate
+            proc.terminate()
         except Exception:
             pass
+        try:
+            if proc.stdout:
+                proc.stdout.close()
+        except Exception:
+            pass
+        try:
+            proc.wait(timeout=5)
+        except Exception:
+            try:
+                proc.kill()
+                proc.wait(timeout=5)
+            except Exception:
+                pass
+
+
+def open_reader(path):
+    """Y4M is read natively, anything else through the host's ffmpeg."""
+    with open(path, "rb") as f:
+        magic = f.read(9)
+    return Y4MReader(path) if magic == b"YUV4MPEG2" else FFmpegReader(path)
+
+
+class _Slot:
+    __slots__ = ("pinned", "dev", "free_event")
+
+    def __init__(self, nbytes: int, device: torch.device):
+        self.pinned = torch.empty(nbytes, dtype=torch.uint8, pin_memory=True)
+        self.dev = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        self.free_event = None      # recorded on the consumer's stream when the slot was released
+
+
+class SlotPool:
+    """Bounded pool of (pinned host, device) staging slots of `slot_bytes` each, shared by every
+    concurrent upload of a process.  Slots are created lazily up to `n_slots`; acquire() blocks
+    when all are in use - the back-pressure that keeps N concurrent 4K uploads from page-locking
+    N rings of their own (round 1: 3 x 256 frames per upload, 25 GB pinned at 32 uploads)."""
+
+    def __init__(self, device="cuda:0", slot_bytes: int = 64 << 20, n_slots: int = 34):
+        self.device = torch.device(device)
+        self.slot_bytes = int(slot_bytes)
+        self.n_slots = int(n_slots)
+        self._free: list = []
+        self._made = 0
+        self._cv = threading.Condition()
+        self._closed = False
+
+    def frames_per_slot(self, H: int, W: int, bps: int = 1, batch: int = 256) -> int:
+        per = self.slot_bytes // (H * W * bps)
+        if per < 1:
+            raise RuntimeError(f"a {W}x{H} frame ({H * W * bps} B) does not fit a {self.slot_bytes} B slot")
+        return int(min(per, batch))
+
+    def acquire(self, stop: Optional[threading.Event] = None) -> Optional[_Slot]:
+        """A free slot (blocks while all are in use); None once `stop` is set."""
+        with self._cv:
+            while True:
+                if self._closed:
+                    raise RuntimeError("slot pool is closed")
+                if stop is not None and stop.is_set():
+                    return None
+                if self._free:
+                    slot = self._free.pop()
+                    break
+                if self._made < self.n_slots:
+                    self._made += 1
+                    slot = None
+                    break
+                self._cv.wait(timeout=0.1 if stop is not None else None)
+        if slot is None:
+            slot = _Slot(self.slot_bytes, self.device)        # outside the lock: page-locking is slow
+        if slot.free_event is not None:
+            slot.free_event.synchronize()                     # kernels of its last user are done
+            slot.free_event = None
+        return slot
+
+    def release(self, slot: _Slot, event=None) -> None:
+        slot.free_event = event
+        with self._cv:
+            self._free.append(slot)
+            self._cv.notify()
+
+    def close(self) -> None:
+        with self._cv:
+            self._closed = True
+            self._free.clear()
+            self._cv.notify_all()
 
 
 class FrameFeeder:
-    """reader -> pinned ring (filled by a background thread) -> async H2D on a copy stream.
-    Iterating yields (first_frame_index, device uint8 [n,H,W]) with the current stream already
-    waiting on the copy; a slot is recycled when the consumer asks for the next batch."""
+    """reader -> pinned slot (filled by a background thread) -> async H2D on a copy stream.
+    Iterating yields (first_frame_index, device [n,H,W]) with the current stream already waiting
+    on the copy; a slot goes back to the pool when the consumer asks for the next batch (with an
+    event on the consumer's stream, so its kernels are known to have finished before reuse)."""
 
-    def __init__(self, reader, batch: int = 256, device="cuda:0", n_slots: int = 3):
+    def __init__(self, reader, batch: int = 256, device="cuda:0", n_slots: int = 3,
+                 pool: Optional[SlotPool] = None, depth: int = 2):
         self.reader = reader
         self.H, self.W = reader.H, reader.W
-        self.batch = int(batch)
         self.device = torch.device(device)
-        self.n_slots = n_slots
         self.bitdepth = getattr(reader, "bitdepth", 8)
-        dt = torch.uint8 if self.bitdepth == 8 else torch.int16     # int16 carries the uint16 bits
-        # straight from torch's caching host allocator: freed slots of a finished upload are reused
-        # by the next one (a .pin_memory() copy would page-lock ~0.5 GB per slot every time)
-        self.pinned = [torch.empty((self.batch, self.H, self.W), dtype=dt, pin_memory=True)
-                       for _ in range(n_slots)]
-        self.dev = [torch.empty((self.batch, self.H, self.W), dtype=dt, device=self.device)
-                    for _ in range(n_slots)]
+        self.bps = 1 if self.bitdepth == 8 else 2
+        self.dtype = torch.uint8 if self.bitdepth == 8 else torch.int16     # int16 carries the uint16 bits
+        frame_bytes = self.H * self.W * self.bps
+        self._own_pool = pool is None
+        if pool is None:       # a private ring for a single stream (detect_scene_cuts on a path)
+            pool = SlotPool(self.device, slot_bytes=int(batch) * frame_bytes, n_slots=n_slots)
+        self.pool = pool
+        self.batch = pool.frames_per_slot(self.H, self.W, self.bps, int(batch))
         self.copy_stream = torch.cuda.Stream(self.device)
-        self._released = [None] * n_slots   # event on the consumer's stream: slot's kernels enqueued
-        self._free: "queue.Queue[int]" = queue.Queue()
-        self._full: "queue.Queue[Tuple[int, int]]" = queue.Queue()
-        for i in range(n_slots):
-            self._free.put(i)
+        self._full: "queue.Queue" = queue.Queue(maxsize=max(1, depth))
         self._stop = threading.Event()
         self._err: Optional[BaseException] = None
         self._thread = threading.Thread(target=self._fill, daemon=True)
         self._thread.start()
 
+    def _views(self, slot: _Slot):
+        n = self.batch * self.H * self.W * self.bps
+        return (slot.pinned[:n].view(self.dtype).view(self.batch, self.H, self.W),
+                slot.dev[:n].view(self.dtype).view(self.batch, self.H, self.W))
+
     def _fill(self):
+        slot = None
         try:
             while not self._stop.is_set():
-                slot = self._free.get()
-                if slot < 0:
+                slot = self.pool.acquire(self._stop)
+                if slot is None:
                     break
-                n = self.reader.read_into(self.pinned[slot].numpy())
-                self._full.put((slot, n))
+                host, _ = self._views(slot)
+                n = self.reader.read_into(host.numpy())
+                while not self._stop.is_set():
+                    try:
+                        self._full.put((slot, n), timeout=0.1)
+                        slot = None
+                        break
+                    except queue.Full:
+                        continue
                 if n < self.batch:
                     break
         except BaseException as e:  # surfaced to the consumer
             self._err = e
-            self._full.put((-1, 0))
+            try:
+                self._full.put((None, -1), timeout=1.0)
+            except queue.Full:
+                pass
+        finally:
+            if slot is not None:
+                self.pool.release(slot)
 
     def __iter__(self):
         base = 0
         held = None
-        done_evt = None
+
+        def give_back():
+            # the consumer resumed us: its kernels on this slot are enqueued on its stream
+            nonlocal held
+            if held is not None:
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream(self.device))
+                self.pool.release(held, ev)
+                held = None
         try:
             while True:
                 slot, n = self._full.get()
-                if self._err is not None:
+                if self._err is not None or slot is None:
                     raise RuntimeError(f"frame reader failed: {self._err}") from self._err
-                if n > 0:
-                    if self._released[slot] is not None:    # kernels still reading the old contents
-                        self.copy_stream.wait_event(self._released[slot])
-                    with torch.cuda.stream(self.copy_stream):
-                        self.dev[slot][:n].copy_(self.pinned[slot][:n], non_blocking=True)
-                        ev = torch.cuda.Event()
-                        ev.record(self.copy_stream)
-                    torch.cuda.current_stream(self.device).wait_event(ev)
-                if held is not None:
-                    # the previous batch's kernels were enqueued before we got here; its pinned
-                    # slot is free as soon as its H2D copy has finished
-                    done_evt.synchronize()
-                    rel = torch.cuda.Event()
-                    rel.record(torch.cuda.current_stream(self.device))
-                    self._released[held] = rel
-                    self._free.put(held)
+                held = slot
                 if n == 0:
                     return
-                held, done_evt = slot, ev
-                yield base, self.dev[slot][:n]
+                host, dev = self._views(slot)
+                with torch.cuda.stream(self.copy_stream):
+                    dev[:n].copy_(host[:n], non_blocking=True)
+                    ev = torch.cuda.Event()
+                    ev.record(self.copy_stream)
+                torch.cuda.current_stream(self.device).wait_event(ev)
+                yield base, dev[:n]
+                give_back()
                 base += n
                 if n < self.batch:
                     return
         finally:
+            give_back()
             self.close()
 
     def close(self):
         self._stop.set()
-        self._free.put(-1)
         try:
             self.reader.close()
         except Exception:
             pass
+        # hand back whatever the reader thread had queued
+        self._thread.join(timeout=5)
+        while True:
+            try:
+                slot, _ = self._full.get_nowait()
+            except queue.Empty:
+                break
+            if slot is not None:
+                self.pool.release(slot)
+        if self._own_pool:
+            self.pool.close()

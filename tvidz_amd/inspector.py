@@ -17,6 +17,13 @@ every batch issues ONE match whose `kth` output reproduces the per-prefix loop; 
 true frame progress when the frame count is known (the reference's `n:` parse never succeeds,
 SURVEY.md §3.3); uploads run on a bounded worker pool instead of one unbounded thread each; the
 SQS poller (app.py:417-480) is out of scope (no compute).
+
+Per micro-batch the driver thread does: one H2D copy (copy stream), three kernel launches
+(SAD, finalize, tail: the scene state stays on the device), ONE small device-to-host copy of the
+compacted cut list + one event wait, and - only when the batch produced new cuts - one
+find_duplicates (one launch + one stream sync) and one stream-ordered corpus upsert.  Staging
+memory is a bounded pool shared by all uploads (feeder.SlotPool), sized in bytes, so 64 concurrent
+4K uploads use the same ~2 GiB of pinned memory as 16 uploads of 480p (BASELINE configs[4]).
 """
 from __future__ import annotations
 
@@ -31,7 +38,7 @@ from typing import Callable, Dict, List, Optional
 import torch
 
 from . import scene
-from .feeder import FFmpegReader, FrameFeeder, Y4MReader
+from .feeder import FrameFeeder, SlotPool, open_reader
 
 KTH_NEVER = 0x7FFFFFFF
 
@@ -45,12 +52,6 @@ def split_filenames(key: str):
     if "-" in filename and filename.split("-")[0].isdigit():
         original_filename = "-".join(filename.split("-")[1:])
     return filename, original_filename
-
-
-def open_reader(path: str):
-    with open(path, "rb") as f:
-        magic = f.read(9)
-    return Y4MReader(path) if magic == b"YUV4MPEG2" else FFmpegReader(path)
 
 
 def s3_frame_source(bucket: str, key: str, filename: str, unique_id: str):
@@ -80,7 +81,7 @@ class Inspector:
                  threshold: float = scene.DEFAULT_THRESHOLD, min_match: int = 2,
                  pts_policy: str = scene.PTS_POLICY_G6, batch: int = 256, max_workers: int = 16,
                  near_duplicates: bool = False, near_eps: float = 1.0 / 30, near_max_offset: float = 30.0,
-                 near_jaccard: float = 0.8):
+                 near_jaccard: float = 0.8, slot_bytes: int = 64 << 20, n_slots: Optional[int] = None):
         self.store = store
         self.device = torch.device(device)
         self.frame_source = frame_source or s3_frame_source
@@ -95,6 +96,37 @@ class Inspector:
         self.analysis_results: Dict[str, dict] = {}     # app.py:28
         self.analysis_lock = threading.Lock()           # app.py:29
         self.pool = ThreadPoolExecutor(max_workers=max_workers, thread_name_prefix="analyze")
+        # staging shared by every upload: two slots per worker (one being filled by its reader
+        # thread, one being copied / scored) + slack; created lazily
+        self.slots = SlotPool(self.device, slot_bytes=slot_bytes,
+                              n_slots=n_slots if n_slots is not None else 2 * max_workers + 2)
+        self._scorers: Dict[tuple, list] = {}           # idle SceneScorers by (H, W, bitdepth, frames)
+        self._scorers_lock = threading.Lock()
+        self._tls = threading.local()
+
+    def close(self) -> None:
+        self.pool.shutdown(wait=True)
+        self.slots.close()
+        with self._scorers_lock:
+            self._scorers.clear()
+
+    def _scorer_get(self, H: int, W: int, bitdepth: int, frames: int) -> "scene.SceneScorer":
+        key = (H, W, bitdepth, frames)
+        with self._scorers_lock:
+            idle = self._scorers.get(key)
+            sc = idle.pop() if idle else None
+        if sc is None:
+            sc = scene.SceneScorer(H, W, frames, self.device, self.threshold, keep_scores=False,
+                                   bitdepth=bitdepth)
+        sc.threshold = self.threshold
+        sc.reset()
+        return sc, key
+
+    def _scorer_put(self, key: tuple, sc) -> None:
+        with self._scorers_lock:
+            idle = self._scorers.setdefault(key, [])
+            if len(idle) < 64:
+                idle.append(sc)
 
     # ------------------------------------------------------------------ driver
     def submit(self, bucket: str, key: str):
@@ -106,6 +138,8 @@ class Inspector:
         analysis_key = f"{unique_id}_{filename}"                           # app.py:136
         with self.analysis_lock:
             self.analysis_results.pop(analysis_key, None)
+        if hasattr(self.store, "sync_if_stale"):
+            self.store.sync_if_stale()      # rows written by another process since our last look
         video = self.store.add_video(original_filename)                    # app.py:150
         video_id = video.id
         self._set(analysis_key, {"status": "analyzing", "scene_cuts": [], "progress": 0.0,
@@ -151,45 +185,63 @@ class Inspector:
         """GPU restatement of the hot loop app.py:216-291."""
         time_base = reader.time_base
         total_frames = getattr(reader, "total_frames", 0) or 0
-        scorer = scene.SceneScorer(reader.H, reader.W, self.batch, self.device, self.threshold,
-                                   bitdepth=getattr(reader, "bitdepth", 8))
-        feeder = FrameFeeder(reader, self.batch, self.device)
+        bitdepth = getattr(reader, "bitdepth", 8)
+        pts_of = getattr(reader, "pts_of", None)
+        frames_per_batch = self.slots.frames_per_slot(reader.H, reader.W, 1 if bitdepth == 8 else 2,
+                                                      self.batch)
+        # every worker thread drives its own HIP stream: uploads overlap on the GPU instead of
+        # queueing behind each other on the default stream
+        stream = getattr(self._tls, "stream", None)
+        if stream is None:
+            stream = self._tls.stream = torch.cuda.Stream(self.device)
+        with torch.cuda.stream(stream):
+            scorer, skey = self._scorer_get(reader.H, reader.W, bitdepth, frames_per_batch)
+            feeder = FrameFeeder(reader, frames_per_batch, self.device, pool=self.slots)
+            scene_timestamps, dups_to_report = self._loop(analysis_key, video_id, feeder, scorer, skey,
+                                                          pts_of, time_base, total_frames)
+        return scene_timestamps, dups_to_report
+
+    def _loop(self, analysis_key, video_id, feeder, scorer, skey, pts_of, time_base, total_frames):
         scene_timestamps: List[float] = []
         dups_to_report: List[str] = []
         frames_done = 0
-        for base, d_frames in feeder:
-            _, _, _, sel = scorer.score_batch(d_frames)
-            scorer.remember_tail(d_frames)
-            idx = torch.nonzero(sel, as_tuple=False).flatten().cpu().tolist()
-            frames_done = base + d_frames.shape[0]
-            grew = False
-            for i in idx:
-                ts = scene.pts_time_value(base + i, time_base, self.pts_policy)    # app.py:230
-                if not scene_timestamps or ts != scene_timestamps[-1]:              # app.py:231
-                    scene_timestamps.append(ts)
-                    grew = True
-            if grew:
-                # one match over the whole current list; kth tells on which prefix the
-                # reference's per-cut loop (app.py:234-238) would have stopped
-                hits = self.store.find_duplicates_kth(scene_timestamps, self.min_match,
-                                                      exclude_id=video_id)            # :235-237
-                hits = [h for h in hits if h[2] < KTH_NEVER]
-                if hits:
-                    kstar = min(h[2] for h in hits)
-                    dup_ids = [h[0] for h in hits if h[2] == kstar]
-                    scene_timestamps = scene_timestamps[:max(kstar, 0) + 1]
-                    self.store.add_timestamps(video_id, scene_timestamps)             # :234
-                    self.store.update_duplicates(video_id, dup_ids)                   # :239
-                    for dup_id in dup_ids:                                            # :241-245
-                        dup_video = self.store.get_video_by_id(dup_id)
-                        if dup_video:
-                            dups_to_report.append(dup_video.filename)
-                    self._progress(analysis_key, scene_timestamps, frames_done, total_frames,
-                                   dups_to_report)
-                    feeder.close()                                                    # :249-255
-                    break
-                self.store.add_timestamps(video_id, scene_timestamps)                 # :234
-            self._progress(analysis_key, scene_timestamps, frames_done, total_frames, dups_to_report)
+        try:
+            for base, d_frames in feeder:
+                scorer.score_batch(d_frames)               # state (prev frame, prev mafd) stays in HBM
+                idx = scorer.fetch_cuts()                  # the batch's ONE device-to-host sync
+                frames_done = base + d_frames.shape[0]
+                grew = False
+                for i in idx:
+                    n = base + i
+                    # showinfo prints pts * time_base (app.py:230): the frame's real pts
+                    ts = scene.pts_time_value(pts_of(n) if pts_of else n, time_base, self.pts_policy)
+                    if not scene_timestamps or ts != scene_timestamps[-1]:              # app.py:231
+                        scene_timestamps.append(ts)
+                        grew = True
+                if grew:
+                    # one match over the whole current list; kth tells on which prefix the
+                    # reference's per-cut loop (app.py:234-238) would have stopped
+                    hits = self.store.find_duplicates_kth(scene_timestamps, self.min_match,
+                                                          exclude_id=video_id)            # :235-237
+                    hits = [h for h in hits if h[2] < KTH_NEVER]
+                    if hits:
+                        kstar = min(h[2] for h in hits)
+                        dup_ids = [h[0] for h in hits if h[2] == kstar]
+                        scene_timestamps = scene_timestamps[:max(kstar, 0) + 1]
+                        self.store.add_timestamps(video_id, scene_timestamps)             # :234
+                        self.store.update_duplicates(video_id, dup_ids)                   # :239
+                        for dup_id in dup_ids:                                            # :241-245
+                            dup_video = self.store.get_video_by_id(dup_id)
+                            if dup_video:
+                                dups_to_report.append(dup_video.filename)
+                        self._progress(analysis_key, scene_timestamps, frames_done, total_frames,
+                                       dups_to_report)
+                        break                                                             # :249-255
+                    self.store.add_timestamps(video_id, scene_timestamps)                 # :234
+                self._progress(analysis_key, scene_timestamps, frames_done, total_frames, dups_to_report)
+        finally:
+            feeder.close()                                 # stops the decoder (app.py:249-252)
+            self._scorer_put(skey, scorer)
         return scene_timestamps, dups_to_report
 
     def _near(self, video_id: int, scene_timestamps):

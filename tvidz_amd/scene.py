@@ -69,12 +69,15 @@ def _stream_ptr(stream: Optional[torch.cuda.Stream]) -> int:
 
 
 class SceneScorer:
-    """Owns the scratch + output buffers for batches of up to `max_batch` frames of H x W luma,
-    so the hot call allocates nothing.  Carries (last frame, last mafd) across batches so a
-    stream scored in chunks gives the same scores as one scored whole."""
+    """Owns the scratch, output buffers and the DEVICE-RESIDENT stream state for batches of up to
+    `max_batch` frames of H x W luma, so the hot call allocates nothing and nothing the scorer
+    carries from one batch to the next (previous frame, previous mafd) ever visits the host: a
+    stream scored in chunks gives the same scores as one scored whole, and a chain of chunks can
+    be captured in one HIP graph."""
 
     def __init__(self, H: int, W: int, max_batch: int, device: Union[str, torch.device] = "cuda:0",
-                 threshold: float = DEFAULT_THRESHOLD, keep_scores: bool = True, bitdepth: int = 8):
+                 threshold: float = DEFAULT_THRESHOLD, keep_scores: bool = True, bitdepth: int = 8,
+                 cuts_cap: Optional[int] = None):
         """bitdepth 8: uint8 frames.  bitdepth 9..16 (yuv420p10 ...): samples in 16-bit words,
         passed as torch.int16 or torch.uint16 tensors (bit patterns of uint16)."""
         self.lib = _lib.load()
@@ -87,20 +90,27 @@ class SceneScorer:
             raise RuntimeError("SceneScorer needs a GPU device (there is no CPU fallback)")
         self.H, self.W, self.max_batch = int(H), int(W), int(max_batch)
         self.threshold = float(threshold)
+        self.cuts_cap = int(cuts_cap if cuts_cap is not None else self.max_batch)
         self.ws_bytes = int(self.lib.tvz_scene_workspace_bytes(self.max_batch, self.H, self.W))
+        self.state_bytes = int(self.lib.tvz_scene_state_bytes(self.H, self.W, 1 if self.bitdepth == 8 else 2))
         with torch.cuda.device(self.device):
             self.workspace = torch.empty(self.ws_bytes, dtype=torch.uint8, device=self.device)
             self.sad = torch.empty(self.max_batch, dtype=torch.int64, device=self.device)
             self.selected = torch.empty(self.max_batch, dtype=torch.uint8, device=self.device)
             self.score = torch.empty(self.max_batch, dtype=torch.float64, device=self.device) if keep_scores else None
             self.mafd = torch.empty(self.max_batch, dtype=torch.float64, device=self.device)
-            self.prev_frame = torch.empty((self.H, self.W), dtype=self.dtype, device=self.device)
-        self.have_prev = False
-        self.prev_mafd = 0.0
+            # [0] = number of selected frames of the last batch, then their indices (ascending)
+            self.cuts = torch.zeros(1 + self.cuts_cap, dtype=torch.int32, device=self.device)
+            self.state = torch.empty(self.state_bytes, dtype=torch.uint8, device=self.device)
+            self._cuts_host = torch.empty(1 + self.cuts_cap, dtype=torch.int32, pin_memory=True)
+            self._cuts_event = torch.cuda.Event()
+            self.reset()
 
-    def reset(self) -> None:
-        self.have_prev = False
-        self.prev_mafd = 0.0
+    def reset(self, stream: Optional[torch.cuda.Stream] = None) -> None:
+        """Start a new stream: the next frame scored is a first frame (score 0)."""
+        with torch.cuda.device(self.device):
+            s = stream if stream is not None else torch.cuda.current_stream(self.device)
+            _lib.check(self.lib.tvz_scene_state_reset(self.state.data_ptr(), s.cuda_stream))
 
     def _check(self, frames: torch.Tensor) -> None:
         ok_dtype = frames.dtype == torch.uint8 if self.bitdepth == 8 else frames.element_size() == 2
@@ -115,43 +125,45 @@ class SceneScorer:
             raise RuntimeError("pixels of a row must be contiguous (stride 1)")
 
     def score_batch(self, frames: torch.Tensor, stream: Optional[torch.cuda.Stream] = None,
-                    carry: bool = True):
+                    carry: bool = True, shape: int = _lib.SHAPE_AUTO):
         """Enqueue scoring of one batch on `stream` (default: torch's current stream).
         Returns views (sad, mafd, score, selected) of length T into the scorer's buffers —
-        valid until the next call.  With carry=True the batch continues the stream of the
-        previous call (its last frame and mafd are the predecessor of frames[0])."""
+        valid until the next call; `self.cuts` holds the compacted cut list of the batch.
+        carry=True: the batch continues the scorer's stream (its device-resident state supplies
+        the predecessor of frames[0] and is advanced to this batch's end).  carry=False: a
+        self-contained batch (frames[0] is a first frame; the state is untouched).
+        `shape`: per-call kernel-shape override (_lib.shape(U, tc, nt)); results never depend on it."""
         self._check(frames)
         T = int(frames.shape[0])
         if T == 0:
             return self.sad[:0], self.mafd[:0], (self.score[:0] if self.score is not None else None), self.selected[:0]
-        use_prev = carry and self.have_prev
         es = frames.element_size()
         fn = self.lib.tvz_scene_scores_u8 if self.bitdepth == 8 else self.lib.tvz_scene_scores_u16
         with torch.cuda.device(self.device):          # launch on the frames' GPU, whatever is current
-            rc = self._call(fn, frames, T, es, use_prev, stream)
+            s = stream if stream is not None else torch.cuda.current_stream(self.device)
+            rc = fn(frames.data_ptr(), T, self.H, self.W, frames.stride(0) * es, frames.stride(1) * es,
+                    self.state.data_ptr() if carry else None, self.bitdepth, self.threshold,
+                    self.sad.data_ptr(), self.mafd.data_ptr(),
+                    self.score.data_ptr() if self.score is not None else None,
+                    self.selected.data_ptr(), self.cuts.data_ptr(), self.cuts_cap,
+                    self.workspace.data_ptr(), self.ws_bytes, int(shape), s.cuda_stream)
         _lib.check(rc)
         return (self.sad[:T], self.mafd[:T], self.score[:T] if self.score is not None else None,
                 self.selected[:T])
 
-    def _call(self, fn, frames, T, es, use_prev, stream):
-        return fn(
-            frames.data_ptr(), T, self.H, self.W, frames.stride(0) * es, frames.stride(1) * es,
-            self.prev_frame.data_ptr() if use_prev else None,
-            self.prev_mafd if use_prev else 0.0, self.bitdepth, self.threshold,
-            self.sad.data_ptr(), self.mafd.data_ptr(),
-            self.score.data_ptr() if self.score is not None else None,
-            self.selected.data_ptr(), self.workspace.data_ptr(), self.ws_bytes,
-            (stream if stream is not None else torch.cuda.current_stream(self.device)).cuda_stream)
-
-    def remember_tail(self, frames: torch.Tensor) -> None:
-        """Keep the batch's last frame + mafd as the predecessor of the next batch."""
-        T = int(frames.shape[0])
-        if T == 0:
-            return
-        self.prev_frame.copy_(frames[T - 1].view(self.dtype) if frames.dtype != self.dtype else frames[T - 1])
-        # an unscored first frame reports mafd 0 == ffmpeg's zero-initialised prev_mafd
-        self.prev_mafd = float(self.mafd[T - 1].item())
-        self.have_prev = True
+    def fetch_cuts(self, stream: Optional[torch.cuda.Stream] = None) -> list:
+        """Indices (within the last batch) of the frames the filter selected: ONE small
+        device-to-host copy + one event wait - the only host synchronisation of a micro-batch."""
+        with torch.cuda.device(self.device):
+            s = stream if stream is not None else torch.cuda.current_stream(self.device)
+            with torch.cuda.stream(s):
+                self._cuts_host.copy_(self.cuts, non_blocking=True)
+                self._cuts_event.record(s)
+        self._cuts_event.synchronize()
+        n = int(self._cuts_host[0])
+        if n > self.cuts_cap:
+            raise RuntimeError(f"{n} cuts in one batch exceed cuts_cap={self.cuts_cap}")
+        return self._cuts_host[1:1 + n].tolist()
 
     def luma_sad(self, frames: torch.Tensor, stream: Optional[torch.cuda.Stream] = None) -> torch.Tensor:
         """uint64 SAD per frame against its predecessor (sad[0] = 0), as int64 tensor view."""
@@ -170,11 +182,16 @@ class SceneScorer:
 
 
 def scene_select(sad: torch.Tensor, H: int, W: int, threshold: float = DEFAULT_THRESHOLD,
-                 bitdepth: int = 8, prev_mafd: float = 0.0, have_prev: bool = False,
+                 bitdepth: int = 8, prev_mafd: Optional[torch.Tensor] = None,
                  stream: Optional[torch.cuda.Stream] = None):
-    """get_scene_score epilogue over a device SAD vector -> (selected u8, score f64, mafd f64)."""
+    """get_scene_score epilogue over a device SAD vector -> (selected u8, score f64, mafd f64).
+    prev_mafd: None (the vector starts a stream) or a 1-element float64 DEVICE tensor holding the
+    mafd of the frame before sad[0] (the vector continues a stream; sad[0] is then a real SAD)."""
     if sad.dtype != torch.int64 or sad.device.type != "cuda" or not sad.is_contiguous():
         raise RuntimeError("sad must be a contiguous int64 (uint64 bits) CUDA tensor")
+    if prev_mafd is not None and (prev_mafd.dtype != torch.float64 or prev_mafd.device != sad.device
+                                  or prev_mafd.numel() != 1):
+        raise RuntimeError("prev_mafd must be a 1-element float64 tensor on the same device")
     T = sad.numel()
     sel = torch.empty(T, dtype=torch.uint8, device=sad.device)
     score = torch.empty(T, dtype=torch.float64, device=sad.device)
@@ -182,8 +199,8 @@ def scene_select(sad: torch.Tensor, H: int, W: int, threshold: float = DEFAULT_T
     if T:
         with torch.cuda.device(sad.device):
             _lib.check(_lib.load().tvz_scene_select(sad.data_ptr(), T, H, W, bitdepth, threshold,
-                                                    prev_mafd, int(have_prev), sel.data_ptr(),
-                                                    score.data_ptr(), mafd.data_ptr(),
+                                                    prev_mafd.data_ptr() if prev_mafd is not None else None,
+                                                    sel.data_ptr(), score.data_ptr(), mafd.data_ptr(),
                                                     _stream_ptr(stream)))
     return sel, score, mafd
 
@@ -197,20 +214,22 @@ def detect_scene_cuts(frames: Union[torch.Tensor, Iterable], time_base: Tuple[in
 
     frames: a uint8 [T,H,W] luma tensor (CUDA or CPU), an iterable of such chunks (a frame
             feeder), or the path of a media file (Y4M natively, anything else via the host's
-            ffmpeg; its time base replaces `time_base`); chunks are scored in micro-batches of `batch` frames so a caller can stop
-            early (the reference terminates ffmpeg at the first duplicate, app.py:249-255).
-    pts:    presentation timestamps in time_base units (default: the frame index, i.e. a
-            constant-frame-rate stream with time_base = 1/fps).
+            ffmpeg; the file's time base and per-frame pts then replace `time_base` / `pts`);
+            chunks are scored in micro-batches of `batch` frames so a caller can stop early (the
+            reference terminates ffmpeg at the first duplicate, app.py:249-255).
+    pts:    presentation timestamps in time_base units, indexable by frame number (default: the
+            frame index, i.e. a constant-frame-rate stream with time_base = 1/fps).  showinfo
+            prints pts * time_base, so a container's stream time base (1/15360, 1/90000 ...) needs
+            the real pts, not the frame index.
     """
     dev = torch.device(device)
     if isinstance(frames, (str, bytes)) or hasattr(frames, "__fspath__"):
         # a media file: Y4M is read directly, anything else through the host's ffmpeg as a raw
         # planar-YUV pipe (the decode half of the reference's single ffmpeg process)
-        from .feeder import FFmpegReader, FrameFeeder, Y4MReader
-        with open(frames, "rb") as f:
-            magic = f.read(9)
-        reader = Y4MReader(frames) if magic == b"YUV4MPEG2" else FFmpegReader(frames)
+        from .feeder import FrameFeeder, open_reader
+        reader = open_reader(frames)
         time_base = reader.time_base
+        pts = _ReaderPts(reader)
         frames = (d for _, d in FrameFeeder(reader, batch, dev))
     chunks = [frames] if isinstance(frames, torch.Tensor) else frames
     base = 0
@@ -226,11 +245,20 @@ def detect_scene_cuts(frames: Union[torch.Tensor, Iterable], time_base: Tuple[in
             part = chunk[s:s + scorer.max_batch]
             if part.device != scorer.device:
                 part = part.to(scorer.device, non_blocking=True)
-            _, _, _, sel = scorer.score_batch(part)
-            scorer.remember_tail(part)
-            idx = torch.nonzero(sel, as_tuple=False).flatten().cpu().tolist()
-            for i in idx:
+            scorer.score_batch(part)
+            for i in scorer.fetch_cuts():
                 n = base + s + i
                 p = n if pts is None else int(pts[n])
                 yield n, pts_time_value(p, time_base, pts_policy)
         base += chunk.shape[0]
+
+
+class _ReaderPts:
+    """pts[n] of a reader: its own per-frame pts if it has them, else the frame index."""
+
+    def __init__(self, reader):
+        self.reader = reader
+
+    def __getitem__(self, n: int) -> int:
+        f = getattr(self.reader, "pts_of", None)
+        return int(f(n)) if f is not None else int(n)

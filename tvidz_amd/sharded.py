@@ -50,6 +50,10 @@ class HipBackend:
     def match(self, d_q, d_off, max_len, min_match, cap, d_excl):
         return self.corpus.match(d_q, d_off, max_len, min_match, cap, d_exclude_ids=d_excl)
 
+    def local_topk(self, d_q, d_off, max_len, min_match, cap, k, d_excl):
+        """sweep + per-shard top-k behind one library call (tvz_match_topk)."""
+        return self.corpus.match_topk(d_q, d_off, max_len, min_match, cap, k, d_exclude_ids=d_excl)
+
     def topk_shard(self, hits, hits_n, k):
         return self._tc.topk_shard(hits, hits_n, k)
 
@@ -78,9 +82,13 @@ class ShardedMatcher:
         """Enqueue local match + per-shard top-k and START the all-gather; returns a ticket for
         finish().  Submitting batch i+1 before finishing batch i overlaps the collective of one
         batch with the match kernels of the next (RCCL runs on its own stream)."""
-        hits, n = self.backend.match(d_queries, d_q_offsets, max_query_len, min_match, self.cap,
-                                     d_exclude_ids)
-        local = self.backend.topk_shard(hits, n, self.k)            # [Q, k+1, 3]
+        if hasattr(self.backend, "local_topk"):
+            local = self.backend.local_topk(d_queries, d_q_offsets, max_query_len, min_match, self.cap,
+                                            self.k, d_exclude_ids)     # [Q, k+1, 3]
+        else:
+            hits, n = self.backend.match(d_queries, d_q_offsets, max_query_len, min_match, self.cap,
+                                         d_exclude_ids)
+            local = self.backend.topk_shard(hits, n, self.k)          # [Q, k+1, 3]
         Q = local.shape[0]
         if not self.collective:
             return (local.view(1, Q, self.k + 1, 3), None, local)
@@ -100,6 +108,64 @@ class ShardedMatcher:
 
     def match_topk(self, d_queries: torch.Tensor, d_q_offsets: torch.Tensor, max_query_len: int,
                    min_match: int, d_exclude_ids: Optional[torch.Tensor] = None):
+        return self.finish(self.submit(d_queries, d_q_offsets, max_query_len, min_match, d_exclude_ids))
+
+
+def make_comm(device: int, group=None):
+    """Create the libtvz RCCL communicator of this rank.  torch.distributed (any backend) is used
+    ONLY to ship rank 0's 128-byte unique id; a non-Python host ships it by its own means."""
+    from . import corpus as tc
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    box = [tc.Comm.unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0,
+                               group=group)
+    return tc.Comm(box[0], world, rank, device)
+
+
+class RcclShardedMatcher:
+    """The sharded match with the collective BEHIND the C ABI (tvz_match_sharded): local sweep +
+    per-shard top-k -> ncclAllGather -> merge are enqueued on one HIP stream by one library call.
+    submit() alternates between two side streams with their own workspaces, so the all-gather and
+    merge of batch i overlap the sweep of batch i+1; finish() makes the current stream wait for
+    the ticket.  Same results as ShardedMatcher (which keeps the merge logic testable on gloo)."""
+
+    def __init__(self, corpus, comm, k: int = 64, cap: int = 1024, n_streams: int = 2):
+        self.corpus, self.comm = corpus, comm
+        self.k = int(k)
+        self.cap = max(int(cap), self.k)
+        self.world, self.rank = comm.n_ranks, comm.rank
+        self.collective = True
+        self.dev = torch.device("cuda", corpus.device)
+        self.streams = [torch.cuda.Stream(self.dev) for _ in range(n_streams)]
+        self.ws = [None] * n_streams
+        self._i = 0
+
+    def submit(self, d_queries: torch.Tensor, d_q_offsets: torch.Tensor, max_query_len: int,
+               min_match: int, d_exclude_ids: Optional[torch.Tensor] = None):
+        from . import corpus as tc
+        i = self._i
+        self._i = (i + 1) % len(self.streams)
+        st = self.streams[i]
+        Q = d_q_offsets.numel() - 1
+        need = tc.workspace_bytes(Q, max_query_len, self.cap, self.k, self.world)
+        if self.ws[i] is None or self.ws[i].numel() < need:
+            self.ws[i] = torch.empty(need, dtype=torch.uint8, device=self.dev)
+        st.wait_stream(torch.cuda.current_stream(self.dev))     # queries are ready; workspace is free
+        merged, totals = self.comm.match_sharded(self.corpus, d_queries, d_q_offsets, max_query_len,
+                                                 min_match, self.cap, self.k, d_exclude_ids,
+                                                 workspace=self.ws[i], stream=st)
+        merged.record_stream(st)
+        totals.record_stream(st)
+        ev = torch.cuda.Event()
+        ev.record(st)
+        return (merged, totals, ev)
+
+    def finish(self, ticket):
+        merged, totals, ev = ticket
+        torch.cuda.current_stream(self.dev).wait_event(ev)
+        return merged, totals
+
+    def match_topk(self, d_queries, d_q_offsets, max_query_len, min_match, d_exclude_ids=None):
         return self.finish(self.submit(d_queries, d_q_offsets, max_query_len, min_match, d_exclude_ids))
 
 
