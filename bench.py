@@ -166,6 +166,59 @@ def cpu_baseline_match(ids, offs, keys, queries, n_threads: int = 0):
                                                  f"{n_threads} threads, {dt_c:.2f} s = {dt_c * n_threads:.0f} core-seconds"}}
 
 
+class LocalMatcher:
+    """world size 1 without a process group: the same data path minus the all-gather
+    (tvz_match_topk -> tvz_topk_merge of the single block), two streams deep like the sharded one."""
+
+    def __init__(self, corpus, k, cap, dev):
+        self.corpus, self.k, self.cap, self.dev = corpus, k, cap, dev
+        self.streams = [torch.cuda.Stream(dev) for _ in range(2)]
+        self.ws = [None, None]
+        self.out = [None, None]
+        self._i = 0
+        self.collective = False
+        self.world = 1
+
+    def submit(self, d_q, d_off, max_len, mm, excl=None):
+        i = self._i
+        self._i ^= 1
+        st = self.streams[i]
+        Q = d_off.numel() - 1
+        need = tc.workspace_bytes(Q, max_len, self.cap, self.k)
+        if self.ws[i] is None or self.ws[i].numel() < need:
+            self.ws[i] = torch.empty(need, dtype=torch.uint8, device=self.dev)
+            self.out[i] = torch.empty((Q, self.k + 1, 3), dtype=torch.int32, device=self.dev)
+        st.wait_stream(torch.cuda.current_stream(self.dev))
+        with torch.cuda.stream(st):
+            blk = self.corpus.match_topk(d_q, d_off, max_len, mm, self.cap, self.k, d_exclude_ids=excl,
+                                         out=self.out[i], workspace=self.ws[i], stream=st)
+            merged, totals = tc.topk_merge(blk.view(1, Q, self.k + 1, 3), self.k, stream=st)
+        merged.record_stream(st)
+        totals.record_stream(st)
+        ev = torch.cuda.Event()
+        ev.record(st)
+        return merged, totals, ev
+
+    def finish(self, ticket):
+        merged, totals, ev = ticket
+        torch.cuda.current_stream(self.dev).wait_event(ev)
+        return merged, totals
+
+    def match_topk(self, *a):
+        return self.finish(self.submit(*a))
+
+
+def kernel_ms(fn, stream, reps=12, skip=2):
+    """Median duration of fn() in ms, HIP events on the stream fn launches on."""
+    ts = []
+    for _ in range(reps):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(stream); fn(); b.record(stream)
+        stream.synchronize()
+        ts.append(a.elapsed_time(b))
+    return float(np.median(ts[skip:]))
+
+
 def bench_match(args, rank, world, dev):
     C = args.corpus
     Q = args.queries
@@ -178,14 +231,20 @@ def bench_match(args, rank, world, dev):
     K_TOP = 16          # per-shard top-k travelling in the all-gather: [Q,17,3] int32 per rank
     CAP = 16384         # per-shard hit-list capacity per query (synthetic corpora: ~2,100 hits per
     #                     query at min_match=2 over 100k videos; overflows are counted below)
-    sm = sharded.ShardedMatcher(sharded.HipBackend(dc), k=K_TOP, cap=CAP,
-                                always_collective=dist.is_initialized())
+    comm = None
+    if dist.is_initialized():
+        # the collective lives behind the C ABI (tvz_match_sharded: sweep -> top-k -> ncclAllGather ->
+        # merge); torch.distributed only ships the 128-byte RCCL id
+        comm = sharded.make_comm(dev.index)
+        sm = sharded.RcclShardedMatcher(dc, comm, k=K_TOP, cap=CAP)
+    else:
+        sm = LocalMatcher(dc, K_TOP, CAP, dev)
     for _ in range(3):
         merged, totals = sm.match_topk(d_q, d_off, max_len, 2)
     barrier_sync(world)
     t0 = time.perf_counter()
-    # a stream of query batches, software-pipelined one deep: the all-gather of batch i runs on
-    # RCCL's stream while batch i+1 is matched; every batch is fully merged inside the timed region
+    # a stream of query batches over two HIP streams: the all-gather + merge of batch i overlap the
+    # sweep of batch i+1; every batch is fully merged inside the timed region
     ticket = sm.submit(d_q, d_off, max_len, 2)
     for _ in range(args.match_steps - 1):
         nxt = sm.submit(d_q, d_off, max_len, 2)
@@ -197,57 +256,95 @@ def bench_match(args, rank, world, dev):
     pairs = Q * C * args.match_steps
     mean_len = float(offs[-1]) / C
     bytes_per_pair = 8.0 * mean_len + 8.0
-    lat = [0.0]
     n_dups = int((totals != 0).sum().item())
     n_over = int((totals < 0).sum().item())            # negative total = a shard's list overflowed
     mean_hits = float(totals.abs().float().mean().item())
+    # the dominant kernel of a batch, timed on its own with HIP events on its stream (rank-local
+    # shard; prep + build + sweep launches of one tvz_match call)
+    st = torch.cuda.Stream(dev)
+    ws = torch.empty(tc.workspace_bytes(Q, max_len), dtype=torch.uint8, device=dev)
+    hits = torch.empty((Q, CAP, 3), dtype=torch.int32, device=dev)
+    n_h = torch.empty(Q, dtype=torch.int32, device=dev)
+    sweep_ms = kernel_ms(lambda: dc.match(d_q, d_off, max_len, 2, CAP, out_hits=hits, out_n=n_h, stream=st,
+                                          workspace=ws), st)
+    shard_rows, shard_keys, _ = dc.stats()
+    corpus_bytes = 16.0 * shard_rows + 8.0 * shard_keys
+    n_tiles = -(-Q // 128)
+    lat = [0.0]
+    if comm is not None:
+        comm.close()
+    out = {"value": pairs / wall, "unit": "pairs/s", "corpus_videos": C, "queries_per_batch": Q,
+           "mean_cuts_per_video": round(mean_len, 1), "min_match": 2, "steps": args.match_steps,
+           "ms_per_batch": wall * 1e3 / args.match_steps,
+           "collective": (f"tvz_match_sharded (C ABI): one ncclAllGather of [Q,{K_TOP + 1},3] int32 per batch "
+                          f"(top-{K_TOP} + hit totals), overlapped with the next batch's sweep") if sm.collective else "none",
+           "queries_with_hits": n_dups, "mean_hits_per_query": round(mean_hits, 1),
+           "hit_list_capacity": CAP, "queries_with_overflowed_shard_lists": n_over,
+           "scaling": "strong (the same corpus is sharded over the ranks)",
+           "sweep_ms_per_batch_rank0": sweep_ms,
+           "fixed_ms_per_batch": max(wall * 1e3 / args.match_steps - sweep_ms, 0.0)}
+    traffic = pmc_traffic("ts_match_join", tag=f"C{C}_Q{Q}") if world == 1 else None
+    alg = corpus_bytes * n_tiles + mean_hits * Q * 12
+    out["roofline"] = {
+        "bound": "hbm", "kernel": f"ts_match_join_kernel ({n_tiles} tiles of 128 queries; the event pair also covers "
+                                  "ts_prep + ts_join_build, < 4 % of it)",
+        "achieved": alg / (sweep_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": alg / (sweep_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
+        "algorithmic_bytes_per_launch": alg,
+        "note": "algorithmic bytes = this rank's corpus image (16 B row entry + 8 B per key) streamed once per "
+                "128-query tile + the hit triples written; `traffic` = FETCH_SIZE x2 + WRITE_SIZE of the committed "
+                "PMC pass (the image fits the 256 MB Infinity Cache, so much of the stream never reaches HBM). The "
+                "sweep is bound by LDS/L2 probe issue, not by HBM: see DESIGN.md 4.3 and profiles/r2_match_pmc.txt"}
+    out["nominal_hbm_equiv"] = {"GBps_per_gpu": pairs * bytes_per_pair / wall / 1e9 / world,
+                                "x_hbm_peak": pairs * bytes_per_pair / wall / 1e9 / world / HBM_PEAK_GBS,
+                                "note": "SURVEY 8d nominal 8*L+8 B per (query,row) pair; not a roofline: one probe of a "
+                                        "corpus key serves a whole tile of queries"}
     dc.close()
-    # configs[2]: 5k-video corpus on one GPU, batch-size sweep (SURVEY 8d asks for Q = 1, 64, 1024)
-    by_q, cpu = {}, None
+    # configs[2]: ONE query vs a 5k-video corpus on one GPU (+ the batch-size sweep SURVEY 8d asks for)
     if rank == 0 and world == 1:
-        ids5, offs5, keys5 = synth.synth_timestamp_corpus(5000, seed=synth.CORPUS_SEED)
-        q5 = synth.synth_queries(ids5, offs5, keys5, Q, seed=synth.CORPUS_SEED + 1)
+        out["config2"] = bench_match_q1(args, dev, Q)
+    return out
+
+
+def bench_match_q1(args, dev, Q):
+    res = {}
+    for C5 in (5000, 100000):
+        ids5, offs5, keys5 = synth.synth_timestamp_corpus(C5, seed=synth.CORPUS_SEED)
+        q5 = synth.synth_queries(ids5, offs5, keys5, max(Q, 64), seed=synth.CORPUS_SEED + 1)
         dc5 = tc.DeviceCorpus(dev.index)
         dc5.upload_csr(ids5, offs5, keys5)
-        for q_n in (1, 64, 1024):
-            if q_n > Q:
+        rows5, nkeys5, _ = dc5.stats()
+        image = 16.0 * rows5 + 8.0 * nkeys5
+        st = torch.cuda.Stream(dev)
+        by_q = {}
+        for q_n in (1, 8, 64, 1024):
+            if q_n > len(q5):
                 continue
             dq, do, ml = tc.pack_queries(q5[:q_n], dev)
-            hits = torch.empty((q_n, 1024, 3), dtype=torch.int32, device=dev)
+            hits = torch.empty((q_n, 4096, 3), dtype=torch.int32, device=dev)
             n_h = torch.empty(q_n, dtype=torch.int32, device=dev)
-            ts = []
-            for r in range(12):
-                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                a.record(); dc5.match(dq, do, ml, 2, 1024, out_hits=hits, out_n=n_h); b.record()
-                torch.cuda.synchronize()
-                ts.append(a.elapsed_time(b))
-            med = float(np.median(ts[2:]))
-            by_q[str(q_n)] = {"kernel_ms": round(med, 4), "pairs_per_s": q_n * 5000 / (med * 1e-3)}
+            ws = torch.empty(tc.workspace_bytes(q_n, ml), dtype=torch.uint8, device=dev)
+            med = kernel_ms(lambda: dc5.match(dq, do, ml, 2, 4096, out_hits=hits, out_n=n_h, stream=st, workspace=ws),
+                            st, reps=24, skip=4)
+            by_q[str(q_n)] = {"kernel_ms": round(med, 4), "pairs_per_s": q_n * C5 / (med * 1e-3)}
         lat = []
-        for i in range(20):
+        for i in range(60):
             t = time.perf_counter()
-            dc5.find_duplicates(q5[i % Q], 2)
+            dc5.find_duplicates(q5[i % len(q5)], 2)
             lat.append(time.perf_counter() - t)
+        q1_ms = by_q["1"]["kernel_ms"]
+        entry = {"kernel_by_batch_size": by_q,
+                 "find_duplicates_latency_us": round(float(np.median(lat[10:])) * 1e6, 1),
+                 "roofline_q1": {"bound": "hbm", "kernel": "ts_match_q1_kernel (one query, whole corpus image streamed once)",
+                                 "algorithmic_bytes_per_launch": image,
+                                 "achieved": image / (q1_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                 "frac": image / (q1_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                 "traffic": pmc_traffic("ts_match_q1", tag=f"C{C5}_Q1")}}
+        if C5 == 5000 and not args.no_cpu:
+            entry["cpu_baseline"] = cpu_baseline_match(ids5, offs5, keys5, q5)
+        res[f"c{C5}"] = entry
         dc5.close()
-        if not args.no_cpu:
-            cpu = cpu_baseline_match(ids5, offs5, keys5, q5)
-    return {"value": pairs / wall, "unit": "pairs/s", "corpus_videos": C, "queries_per_batch": Q,
-            "mean_cuts_per_video": round(mean_len, 1), "min_match": 2, "steps": args.match_steps,
-            "ms_per_batch": wall * 1e3 / args.match_steps,
-            "collective": (f"one all_gather of [Q,{K_TOP + 1},3] int32 per batch (top-{K_TOP} + hit totals), "
-                           "overlapped with the next batch's match") if sm.collective else "none",
-            "queries_with_hits": n_dups, "mean_hits_per_query": round(mean_hits, 1),
-            "hit_list_capacity": CAP, "queries_with_overflowed_shard_lists": n_over,
-            "scaling": "strong (the same corpus is sharded over the ranks)",
-            "find_duplicates_latency_ms_q1_c5000": round(float(np.median(lat)) * 1e3, 3),
-            "config2_c5000_kernel_by_batch_size": by_q, "cpu_baseline": cpu,
-            "roofline": {"bound": "hbm", "achieved": pairs * bytes_per_pair / wall / 1e9 / world,
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": pairs * bytes_per_pair / wall / 1e9 / world / HBM_PEAK_GBS,
-                         "traffic": None,
-                         "note": "nominal 8*L+8 B per pair per GPU (SURVEY 8d). A 16-query tile shares each corpus "
-                                 "byte on chip, so real HBM traffic is ~1/16 of nominal and frac can exceed 1: the "
-                                 "kernel is LDS/issue-bound, not HBM-bound"}}
+    return res
 
 
 def h2d_cost(dev, n_frames: int = 256):
@@ -266,15 +363,20 @@ def h2d_cost(dev, n_frames: int = 256):
             "note": "pinned host -> HBM copy of 256 x 1080p luma; the PCIe-inclusive ceiling of the scene path"}
 
 
-def pmc_traffic(kernel: str, T: int):
+def pmc_traffic(kernel: str, T: int = 0, tag: str = ""):
     """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/*_pmc_summary.json:
-    FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE), valid for the default T only."""
+    FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE).  Scene kernel: valid for the default T
+    only; matcher kernels: looked up under their workload tag (e.g. "C100000_Q1024")."""
     import glob
     best = None
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json"))):
         try:
             d = json.load(open(f))
-            if d.get("_frames_per_launch", 10000) == T and kernel in d:
+            if tag:
+                e = d.get(tag, {}).get(kernel)
+                if e:
+                    best = e.get("hbm_read_bytes_corrected", 0) + e.get("hbm_write_bytes", 0)
+            elif d.get("_frames_per_launch", 10000) == T and kernel in d:
                 best = d[kernel].get("hbm_read_bytes_corrected", 0) + d[kernel].get("hbm_write_bytes", 0)
         except Exception:
             pass

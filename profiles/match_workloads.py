@@ -1,0 +1,62 @@
+#!/usr/bin/env python3
+"""Matcher workloads for rocprofv3 passes (kernel trace or PMC), one process per workload so a
+counter row can be attributed by kernel name alone:
+   python3 profiles/match_workloads.py <workload> [reps]
+     join   : C=100k x Q=1024, min_match 2   -> ts_match_join_kernel (+ prep, build)   tag C100000_Q1024
+     q1_100k: C=100k x Q=1                    -> ts_match_q1_kernel                     tag C100000_Q1
+     q1_5k  : C=5k   x Q=1 + find_duplicates  -> ts_match_q1_kernel (both output modes) tag C5000_Q1
+     tile   : C=100k x Q=64, min_match 2, forced LDS tile kernel                       tag C100000_Q64
+     topk   : C=100k x Q=1024 match_topk (sweep + select top-k)                        tag C100000_Q1024
+Prints one JSON line with the event-timed median of the call."""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from tvidz_amd import _lib, corpus as tc, synth  # noqa: E402
+
+which = sys.argv[1] if len(sys.argv) > 1 else "join"
+reps = int(sys.argv[2]) if len(sys.argv) > 2 else 12
+dev = torch.device("cuda:0")
+C, Q, algo = {"join": (100000, 1024, _lib.ALGO_JOIN), "q1_100k": (100000, 1, _lib.ALGO_Q1),
+              "q1_5k": (5000, 1, _lib.ALGO_Q1), "tile": (100000, 64, _lib.ALGO_TILE),
+              "topk": (100000, 1024, _lib.ALGO_AUTO)}[which]
+ids, offs, keys = synth.synth_timestamp_corpus(C, seed=synth.CORPUS_SEED)
+queries = synth.synth_queries(ids, offs, keys, max(Q, 64), seed=synth.CORPUS_SEED + 1)
+dc = tc.DeviceCorpus(0)
+dc.upload_csr(ids, offs, keys)
+d_q, d_off, ml = tc.pack_queries(queries[:Q], dev)
+CAP = 16384 if Q > 1 else 4096
+hits = torch.empty((Q, CAP, 3), dtype=torch.int32, device=dev)
+n = torch.empty(Q, dtype=torch.int32, device=dev)
+st = torch.cuda.Stream(dev)
+ts = []
+if which == "topk":
+    ws = torch.empty(tc.workspace_bytes(Q, ml, CAP, 16), dtype=torch.uint8, device=dev)
+    out = torch.empty((Q, 17, 3), dtype=torch.int32, device=dev)
+    call = lambda: dc.match_topk(d_q, d_off, ml, 2, CAP, 16, out=out, workspace=ws, stream=st)
+else:
+    ws = torch.empty(tc.workspace_bytes(Q, ml), dtype=torch.uint8, device=dev)
+    call = lambda: dc.match(d_q, d_off, ml, 2, CAP, out_hits=hits, out_n=n, stream=st, workspace=ws, algo=algo)
+for r in range(reps):
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record(st); call(); b.record(st)
+    st.synchronize()
+    ts.append(a.elapsed_time(b))
+res = {"workload": which, "C": C, "Q": Q, "median_ms": round(float(np.median(ts[2:])), 4)}
+if which == "q1_5k":
+    lat = []
+    for i in range(200):
+        t = time.perf_counter()
+        dc.find_duplicates(queries[i % 64], 2)
+        lat.append(time.perf_counter() - t)
+    res["find_duplicates_us"] = round(float(np.median(lat[20:])) * 1e6, 1)
+    res["find_duplicates_p10_p90_us"] = [round(float(np.percentile(lat[20:], p)) * 1e6, 1) for p in (10, 90)]
+rows, nkeys, _ = dc.stats()
+res["corpus_image_bytes"] = 16 * rows + 8 * nkeys
+print(json.dumps(res))
+dc.close()

@@ -1,0 +1,84 @@
+#!/usr/bin/env python3
+"""Summarise gpurun_out/pmc_match_<tag>/ (profiles/pmc_match.sh) into profiles/<tag>_match_pmc.txt
+(per workload and kernel: launches, average duration from the kernel trace, every counter averaged
+per launch, and the derived busy / hit / conflict ratios) and profiles/<tag>_match_pmc_summary.json
+(HBM bytes per launch under the workload's tag, FETCH_SIZE x2 per MI355X_MICROARCH.md HBM)."""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "r2"
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+src = os.path.join(root, "gpurun_out", f"pmc_match_{tag}")
+TAGS = {"join": "C100000_Q1024", "q1_100k": "C100000_Q1", "q1_5k": "C5000_Q1", "tile": "C100000_Q64",
+        "topk": "C100000_Q1024"}
+OURS = ("ts_match_q1", "ts_match_tile", "ts_match_join", "ts_join_build", "ts_topk_select", "ts_topk_kernel",
+        "ts_prep", "ts_kth_fixup")
+
+
+def kname(full):
+    for o in OURS:
+        if o in full:
+            return o
+    return None
+
+
+lines, summary = [], {}
+for w in sorted(os.listdir(src)):
+    wd = os.path.join(src, w)
+    if not os.path.isdir(wd):
+        continue
+    per = collections.defaultdict(lambda: collections.defaultdict(list))
+    for f in glob.glob(os.path.join(wd, "trace", "**", "*kernel_trace.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            k = kname(r["Kernel_Name"])
+            if k:
+                per[k]["duration_ns"].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+                per[k]["_grid"] = [r.get("Grid_Size"), r.get("Workgroup_Size"), r.get("LDS_Block_Size"), r.get("VGPR_Count"), r.get("SGPR_Count")]
+    for f in glob.glob(os.path.join(wd, "p*", "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            k = kname(r["Kernel_Name"])
+            if k:
+                per[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    try:
+        lines.append(f"## workload {w} ({TAGS.get(w, '')})  " + open(os.path.join(wd, "trace.json")).read().strip())
+    except Exception:
+        lines.append(f"## workload {w}")
+    for k, d in sorted(per.items()):
+        g = d.pop("_grid", None)
+        avg = {c: sum(v) / len(v) for c, v in d.items() if v}
+        n = len(d.get("duration_ns", []))
+        lines.append(f"### {k}: {n} launches in the trace pass, grid/wg/lds/vgpr/sgpr = {g}")
+        lines.append(json.dumps({c: round(v, 1) for c, v in sorted(avg.items())}))
+        der = {}
+        wc = avg.get("SQ_WAVE_CYCLES")
+        if wc:
+            for c in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_LDS"):
+                if c in avg:
+                    der[c + "/WAVE_CYCLES"] = round(avg[c] / wc, 3)
+        if avg.get("SQ_LDS_IDX_ACTIVE"):
+            der["LDS_BANK_CONFLICT/LDS_IDX_ACTIVE"] = round(avg.get("SQ_LDS_BANK_CONFLICT", 0) / avg["SQ_LDS_IDX_ACTIVE"], 3)
+        if avg.get("TCC_HIT_sum") is not None and avg.get("TCC_MISS_sum") is not None and avg["TCC_HIT_sum"] + avg["TCC_MISS_sum"] > 0:
+            der["L2_hit_rate"] = round(avg["TCC_HIT_sum"] / (avg["TCC_HIT_sum"] + avg["TCC_MISS_sum"]), 3)
+        e = {}
+        if "FETCH_SIZE" in avg:
+            e["hbm_read_bytes_corrected"] = avg["FETCH_SIZE"] * 1024 * 2      # gfx950: FETCH_SIZE = 1/2 bytes, KiB
+            der["hbm_read_MB"] = round(e["hbm_read_bytes_corrected"] / 1e6, 2)
+        if "WRITE_SIZE" in avg:
+            e["hbm_write_bytes"] = avg["WRITE_SIZE"] * 1024
+            der["hbm_write_MB"] = round(e["hbm_write_bytes"] / 1e6, 2)
+        if "duration_ns" in avg:
+            e["avg_duration_ns"] = avg["duration_ns"]
+            if "hbm_read_bytes_corrected" in e:
+                der["hbm_GBps"] = round((e["hbm_read_bytes_corrected"] + e.get("hbm_write_bytes", 0)) / avg["duration_ns"], 1)
+        lines.append("derived: " + json.dumps(der))
+        if e and w in TAGS:
+            summary.setdefault(TAGS[w], {})
+            if k not in summary[TAGS[w]] or w != "topk":
+                summary[TAGS[w]][k] = e
+open(os.path.join(root, "profiles", f"{tag}_match_pmc.txt"), "w").write("\n".join(lines) + "\n")
+json.dump(summary, open(os.path.join(root, "profiles", f"{tag}_match_pmc_summary.json"), "w"), indent=1)
+print("\n".join(lines))
