@@ -21,6 +21,10 @@ N = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 T = int(sys.argv[2]) if len(sys.argv) > 2 else 512
 WORKERS = int(sys.argv[3]) if len(sys.argv) > 3 else 8
 BATCH = int(sys.argv[4]) if len(sys.argv) > 4 else 256
+SLOT_MB = int(sys.argv[5]) if len(sys.argv) > 5 else 64
+SWITCH = float(sys.argv[6]) if len(sys.argv) > 6 else 0.0
+if SWITCH > 0:
+    sys.setswitchinterval(SWITCH)
 H, W = 1080, 1920
 root = "/dev/shm" if os.path.isdir("/dev/shm") and shutil.disk_usage("/dev/shm").free > (N * T * H * W * 1.2) else None
 tmp = tempfile.mkdtemp(prefix="tvz_e2e_", dir=root)
@@ -39,11 +43,13 @@ try:
     def source(bucket, key, filename, unique_id):
         return feeder.Y4MReader(files[key]), None
 
-    ins = insp.Inspector(store, device="cuda:0", frame_source=source, batch=BATCH, max_workers=WORKERS)
+    ins = insp.Inspector(store, device="cuda:0", frame_source=source, batch=BATCH, max_workers=WORKERS,
+                         slot_bytes=SLOT_MB << 20, profile=True)
     # warm-up pass: a long-running service has its pinned/device slots cached by the allocators
     [f.result() for f in [ins.submit("videos", k) for k in files]]
     store.clear()
     store.corpus.upload_csr(ids + 100000, offs, keys)
+    ins.phase_seconds.clear()
     t0 = time.perf_counter()
     futs = [ins.submit("videos", k) for k in files]
     res = [f.result() for f in futs]
@@ -52,7 +58,10 @@ try:
     frames_done = sum(round(r["scene_cuts"][-1] * 30) if r["duplicates"] else T for r in res)
     print(json.dumps({"uploads": N, "frames_per_clip": T, "workers": WORKERS, "batch": BATCH, "wall_s": round(dt, 3),
                       "frames_per_s": round(N * T / dt), "GBps_luma": round(N * T * H * W / dt / 1e9, 2),
-                      "cuts": [r["total_cuts"] for r in res], "dups": [len(r["duplicates"]) for r in res],
+                      "slot_MiB": SLOT_MB, "switch_interval": sys.getswitchinterval(),
+                      "cuts_total": sum(r["total_cuts"] for r in res), "dups_total": sum(len(r["duplicates"]) for r in res),
+                      "phase_thread_seconds": {k: (round(v, 3) if isinstance(v, float) else v)
+                                               for k, v in sorted(ins.phase_seconds.items()) if not k.startswith("n_")},
                       "tmp": "shm" if root else "disk"}))
     store.close()
 finally:

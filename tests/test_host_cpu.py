@@ -217,3 +217,38 @@ def test_y4m_high_bit_depth_round_trip(tmp_path):
         buf = np.zeros((5, 10, 14), dtype=np.int16)
         assert r.read_into(buf) == 5 and (buf.view(np.uint16) == luma).all()
         r.close()
+
+
+def test_write_behind_coalesces_and_flushes(store):
+    """add_timestamps_async: the device row is upserted at once, the SQL row is written behind by
+    one thread that keeps only the latest prefix of a video; flush() makes the table identical to
+    what per-cut commits (db.py:58-62) would have left."""
+    a, b = store.add_video("a.mp4"), store.add_video("b.mp4")
+    for k in range(1, 40):
+        store.add_timestamps_async(a.id, [float(i) for i in range(k)])
+        assert store.corpus.rows[0] == (a.id, [float(i) for i in range(k)])     # visible to the next match at once
+        if k % 3 == 0:
+            store.add_timestamps_async(b.id, [100.0 + i for i in range(k)])
+    store.flush(a.id)
+    store.flush()
+    s = store.SessionLocal()
+    try:
+        rows = {r.video_id: r.timestamps for r in s.query(tdb.VideoTimestamps).all()}
+    finally:
+        s.close()
+    assert rows == {a.id: [float(i) for i in range(39)], b.id: [100.0 + i for i in range(39)]}
+    assert store.sync_if_stale() is False            # our own rows are not "someone else's"
+    # a row added behind the store's back (another worker / plain SQL) is picked up
+    s = store.SessionLocal()
+    try:
+        v = tdb.Video(filename="ext.mp4")
+        s.add(v); s.commit()
+        s.add(tdb.VideoTimestamps(video_id=v.id, timestamps=[7.5, 8.5])); s.commit()
+        ext_id = v.id
+    finally:
+        s.close()
+    assert store.find_duplicates([7.5, 8.5], 2) == []
+    assert store.sync_if_stale() is True
+    assert store.find_duplicates([7.5, 8.5], 2) == [(ext_id, 2)]
+    store.clear()
+    assert store.sync_if_stale() is False and store.find_duplicates([7.5], 1) == []

@@ -914,9 +914,35 @@ __global__ __launch_bounds__(kQ1Block) void ts_match_q1_kernel(
     const int g = threadIdx.x / kGroup;
     const int32_t excl = exclude_ids ? exclude_ids[q] : exclude_one;
     const int64_t stride = (int64_t)gridDim.x * kQ1Groups;
-    for (int64_t r = (int64_t)blockIdx.x * kQ1Groups + g; r < n_rows; r += stride) {
-        const Row row = load_row(rows + r);
-        const int64_t *rk = keys + row.off;
+    // Software pipeline over (row, step): a step = four 16-byte loads per lane = 128 keys per
+    // group.  While the 8 keys of one step are probed, the loads of the NEXT step - of this row,
+    // or the first of the group's next row, whose entry was fetched one row ahead - are already in
+    // flight, so a group never sits idle on a dependent row-entry -> keys round trip (the first
+    // version did, at every row: 78 % of its wave-cycles were waits, profiles/r2a_match_pmc.txt).
+    constexpr int kLd = 4;                                  // 16-byte loads per lane and step
+    constexpr int kStepKeys = kLd * 2 * kGroup;             // 128
+    longlong2 buf[kLd];
+    // UNCONDITIONAL loads (lanes past the row's end read the arena's first 16 bytes instead and
+    // are masked at compare time): a branch around a load makes the compiler wait with vmcnt(0)
+    // right after issuing the prefetch, which is how the first pipelined version bought nothing
+    auto issue = [&](int64_t off, int len, int base) {
+#pragma unroll
+        for (int j = 0; j < kLd; ++j) {
+            const int i = base + gl * 2 + j * 2 * kGroup;
+            const int64_t *p = (i < len) ? keys + off + i : keys;
+            buf[j] = *reinterpret_cast<const longlong2 *>(p);
+        }
+    };
+    int64_t r = (int64_t)blockIdx.x * kQ1Groups + g;
+    const int64_t last_row = n_rows - 1;
+    Row row = load_row(rows + (r < n_rows ? r : last_row));       // past the end: a valid row, never used
+    issue(row.off, row.len, 0);
+    while (r < n_rows) {
+        const int64_t rn = r + stride;
+        // lands while this row is probed; past the end it is the last row again (valid memory, and
+        // the loop ends before anything of it is used) - masking its length here would make the
+        // compiler wait for the entry at once
+        const Row nrow = load_row(rows + (rn < n_rows ? rn : last_row));
         uint32_t cnt = 0, m1 = 0xffffffffu, m2 = 0xffffffffu;
         unsigned long long top = kTopNone;
         auto acc = [&](uint32_t pos) {
@@ -929,38 +955,44 @@ __global__ __launch_bounds__(kQ1Block) void ts_match_q1_kernel(
                 top = top5_insert(top, pos);
             }
         };
-        for (int i0 = gl * 2; i0 < row.len; i0 += 4 * kGroup) {
-            const bool second = i0 + 2 * kGroup < row.len;
-            const longlong2 a = *reinterpret_cast<const longlong2 *>(rk + i0);
-            longlong2 b = make_longlong2(kEmpty, kEmpty);
-            if (second) b = *reinterpret_cast<const longlong2 *>(rk + i0 + 2 * kGroup);
-            const int64_t kk[4] = {a.x, a.y, b.x, b.y};
-            const bool valid[4] = {true, i0 + 1 < row.len, second, i0 + 2 * kGroup + 1 < row.len};
-            uint32_t hp[4];
-            longlong2 w[4];
+        for (int base = 0;; base += kStepKeys) {
+            longlong2 cur[kLd];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                hp[j] = home(kk[j]);
-                w[j] = *reinterpret_cast<const longlong2 *>(skey + hp[j]);
-            }
+            for (int j = 0; j < kLd; ++j) cur[j] = buf[j];
+            const bool more = base + kStepKeys < row.len;
+            issue(more ? row.off : nrow.off, more ? row.len : nrow.len, more ? base + kStepKeys : 0);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                // in the table, or its home pair is full (the probe sequence goes on)
-                const bool slow = valid[j] & ((w[j].x == kk[j]) | ((w[j].x != kEmpty) & (w[j].y != kEmpty)) |
-                                              (w[j].y == kk[j]));
-                if (slow) {
-                    uint32_t h = hp[j];
-                    longlong2 ww = w[j];
-                    while (true) {
-                        if (ww.x == kEmpty) break;
-                        if (ww.x == kk[j]) acc(spos[h]);
-                        if (ww.y == kEmpty) break;
-                        if (ww.y == kk[j]) acc(spos[h + 1]);
-                        h = (h + 2) & smask;
-                        ww = *reinterpret_cast<const longlong2 *>(skey + h);
+            for (int j = 0; j < kLd; ++j) {
+                const int i = base + gl * 2 + j * 2 * kGroup;
+                const int64_t kk[2] = {cur[j].x, cur[j].y};
+                const bool valid[2] = {i < row.len, i + 1 < row.len};
+                uint32_t hp[2];
+                longlong2 w[2];
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    hp[e] = home(kk[e]);
+                    w[e] = *reinterpret_cast<const longlong2 *>(skey + hp[e]);
+                }
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    // in the table, or its home pair is full (the probe sequence goes on)
+                    const bool slow = valid[e] & ((w[e].x == kk[e]) | (w[e].y == kk[e]) |
+                                                  ((w[e].x != kEmpty) & (w[e].y != kEmpty)));
+                    if (slow) {
+                        uint32_t h = hp[e];
+                        longlong2 ww = w[e];
+                        while (true) {
+                            if (ww.x == kEmpty) break;
+                            if (ww.x == kk[e]) acc(spos[h]);
+                            if (ww.y == kEmpty) break;
+                            if (ww.y == kk[e]) acc(spos[h + 1]);
+                            h = (h + 2) & smask;
+                            ww = *reinterpret_cast<const longlong2 *>(skey + h);
+                        }
                     }
                 }
             }
+            if (!more) break;
         }
         // the group's totals (every lane ends up with them)
 #define TVZ_SUM_STEP(C) cnt += dpp16<C>(cnt);
@@ -968,11 +1000,13 @@ __global__ __launch_bounds__(kQ1Block) void ts_match_q1_kernel(
 #undef TVZ_SUM_STEP
         const bool hit = (int64_t)cnt >= (int64_t)min_match && row.vid != excl;
         if constexpr (MODE == kQ1ModeM2) {
+            if (__ballot(hit) != 0ull) {
 #define TVZ_M2_STEP(C) { const uint32_t p1 = dpp16<C>(m1), p2 = dpp16<C>(m2); \
-            const uint32_t lo = m1 < p1 ? m1 : p1, hi = m1 < p1 ? p1 : m1, r2 = m2 < p2 ? m2 : p2; \
-            m1 = lo; m2 = hi < r2 ? hi : r2; }
-            TVZ_ROW16_BUTTERFLY(TVZ_M2_STEP)
+                const uint32_t lo = m1 < p1 ? m1 : p1, hi = m1 < p1 ? p1 : m1, r2 = m2 < p2 ? m2 : p2; \
+                m1 = lo; m2 = hi < r2 ? hi : r2; }
+                TVZ_ROW16_BUTTERFLY(TVZ_M2_STEP)
 #undef TVZ_M2_STEP
+            }
         } else if constexpr (MODE == kQ1ModeTop5) {
             if (__ballot(hit) != 0ull) {                // rare: most rows never reach min_match
 #define TVZ_T5_STEP(C) { const unsigned long long p = dpp16_64<C>(top); \
@@ -1003,6 +1037,8 @@ __global__ __launch_bounds__(kQ1Block) void ts_match_q1_kernel(
                 }
             }
         }
+        row = nrow;
+        r = rn;
     }
     if constexpr (HOSTOUT) {
         __syncthreads();

@@ -71,6 +71,19 @@ class Store:
         elif self.url.startswith("sqlite"):
             kw = dict(connect_args={"timeout": 30})
         self.engine = create_engine(self.url, **kw)
+        if self.url.startswith("sqlite") and not kw.get("poolclass"):
+            # the SQLite file backend (tests, probes; production is Postgres as in the reference):
+            # WAL keeps readers from blocking the writer, and every write below goes through
+            # _write_lock, so 64 upload threads never spin in SQLite's busy handler (its back-off
+            # sleeps of up to 100 ms showed up as a bimodal +1 s in the concurrent-upload probe)
+            from sqlalchemy import event
+
+            @event.listens_for(self.engine, "connect")
+            def _sqlite_pragmas(dbapi_conn, _rec):
+                cur = dbapi_conn.cursor()
+                cur.execute("PRAGMA journal_mode=WAL")
+                cur.execute("PRAGMA synchronous=NORMAL")
+                cur.close()
         self.SessionLocal = sessionmaker(bind=self.engine)
         Base.metadata.create_all(self.engine)                   # db.py:30
         if corpus is None:
@@ -78,8 +91,19 @@ class Store:
             corpus = DeviceCorpus(device)
         self.corpus = corpus
         self._write_lock = threading.Lock()
+        # SQLite allows one writer: serialise writes in-process instead of in its busy handler;
+        # Postgres (MVCC) needs no such lock
+        import contextlib
+        self._sql_write = self._write_lock if self.url.startswith("sqlite") else contextlib.nullcontext()
         self._census = (0, 0)            # (row count, max id) of video_timestamps as this process knows it
         self._dirty = False
+        # write-behind of the growing cut prefixes (add_timestamps_async): latest list per video
+        self._pending = {}
+        self._inflight = set()
+        self._wb_cv = threading.Condition()
+        self._wb_error = None
+        self._wb_stop = False
+        self._wb_thread = None
         self.reload_corpus()
 
     # -- device mirror -------------------------------------------------------
@@ -98,33 +122,43 @@ class Store:
         self._dirty = False
         return len(data)
 
-    def sync_if_stale(self) -> bool:
+    def sync_if_stale(self, min_interval: float = 0.0) -> bool:
         """Reload the mirror if `video_timestamps` gained or lost rows that this process did not
-        write (another worker, plain SQL), or if a device upsert failed after its SQL commit."""
+        write (another worker, plain SQL), or if a device upsert failed after its SQL commit.
+        `min_interval` > 0 skips the census when one ran less than that many seconds ago (the
+        driver asks once per upload; a burst of uploads shares one census)."""
         from sqlalchemy import func
+        import time as _time
+        now = _time.monotonic()
+        if min_interval > 0 and not self._dirty and now - getattr(self, "_census_at", -1e9) < min_interval:
+            return False
+        self._census_at = now
         with self._write_lock:
             session = self.SessionLocal()
             try:
                 cnt, mx = session.query(func.count(VideoTimestamps.id), func.max(VideoTimestamps.id)).one()
             finally:
                 session.close()
-            if self._dirty or (int(cnt or 0), int(mx or 0)) != self._census:
+            stale = self._dirty or (int(cnt or 0), int(mx or 0)) != self._census
+        if stale:
+            self.flush()                    # our own write-behind first: its rows must be in SQL
+            with self._write_lock:
                 self.reload_corpus()
-                return True
-        return False
+        return stale
 
     # -- reference API -------------------------------------------------------
     def add_video(self, filename, thumbnail_path=None):         # db.py:32-41
-        session = self.SessionLocal()
-        try:
-            video = Video(filename=filename, thumbnail_path=thumbnail_path)
-            session.add(video)
-            session.commit()
-            session.refresh(video)
-            session.expunge(video)
-            return video
-        finally:
-            session.close()
+        with self._sql_write:
+            session = self.SessionLocal()
+            try:
+                video = Video(filename=filename, thumbnail_path=thumbnail_path)
+                session.add(video)
+                session.commit()
+                session.refresh(video)
+                session.expunge(video)
+                return video
+            finally:
+                session.close()
 
     def add_timestamps(self, video_id, timestamps):             # db.py:43-64
         ts = [float(x) for x in timestamps]
@@ -149,15 +183,85 @@ class Store:
                 self._dirty = True          # SQL has the row, the mirror may not: reload on next use
                 raise
 
+    def _write_timestamps_sql(self, session, video_id, ts) -> None:
+        """The SQL half of add_timestamps (db.py:52-62) inside the caller's session."""
+        ts_row = (session.query(VideoTimestamps).filter_by(video_id=video_id)
+                  .order_by(VideoTimestamps.id).first())
+        if ts_row:
+            ts_row.timestamps = ts
+            session.flush()
+        else:
+            ts_row = VideoTimestamps(video_id=video_id, timestamps=ts)
+            session.add(ts_row)
+            session.flush()
+            self._census = (self._census[0] + 1, max(self._census[1], int(ts_row.id)))
+
+    def add_timestamps_async(self, video_id, timestamps) -> None:
+        """add_timestamps for the streaming driver: the HBM row - what the NEXT find_duplicates of
+        any upload matches against - is upserted before this returns (stream-ordered, no wait);
+        the SQL row is written behind by one writer thread that coalesces the growing prefixes of
+        a video (only the latest list matters: db.py:58 overwrites the row) and commits many
+        videos per transaction.  flush(video_id) before reporting the upload `done` makes the
+        final table state identical to the reference's per-cut commits."""
+        ts = [float(x) for x in timestamps]
+        self.corpus.upsert(int(video_id), ts)
+        with self._wb_cv:
+            if self._wb_error is not None:
+                raise self._wb_error
+            self._pending[int(video_id)] = ts
+            if self._wb_thread is None:
+                self._wb_thread = threading.Thread(target=self._write_behind, name="tvz-sql-writer", daemon=True)
+                self._wb_thread.start()
+            self._wb_cv.notify_all()
+
+    def flush(self, video_id=None) -> None:
+        """Block until the write-behind has committed `video_id` (or everything)."""
+        with self._wb_cv:
+            while True:
+                if self._wb_error is not None:
+                    raise self._wb_error
+                busy = (self._pending or self._inflight) if video_id is None else \
+                    (int(video_id) in self._pending or int(video_id) in self._inflight)
+                if not busy:
+                    return
+                self._wb_cv.wait(timeout=0.5)
+
+    def _write_behind(self) -> None:
+        while True:
+            with self._wb_cv:
+                while not self._pending and not self._wb_stop:
+                    self._wb_cv.wait(timeout=0.5)
+                if self._wb_stop and not self._pending:
+                    return
+                batch, self._pending = self._pending, {}
+                self._inflight = set(batch)
+            try:
+                with self._write_lock:
+                    session = self.SessionLocal()
+                    try:
+                        for vid, ts in batch.items():
+                            self._write_timestamps_sql(session, vid, ts)
+                        session.commit()
+                    finally:
+                        session.close()
+            except Exception as e:          # surfaced by the next add_timestamps_async / flush
+                self._dirty = True
+                with self._wb_cv:
+                    self._wb_error = e
+            with self._wb_cv:
+                self._inflight = set()
+                self._wb_cv.notify_all()
+
     def update_duplicates(self, video_id, duplicate_ids):       # db.py:66-74
-        session = self.SessionLocal()
-        try:
-            video = session.query(Video).filter_by(id=video_id).first()
-            if video:
-                video.duplicates = [int(d) for d in duplicate_ids]
-                session.commit()
-        finally:
-            session.close()
+        with self._sql_write:
+            session = self.SessionLocal()
+            try:
+                video = session.query(Video).filter_by(id=video_id).first()
+                if video:
+                    video.duplicates = [int(d) for d in duplicate_ids]
+                    session.commit()
+            finally:
+                session.close()
 
     def find_duplicates(self, new_timestamps, min_match=5) -> List[Tuple[int, int]]:   # db.py:76-94
         return self.corpus.find_duplicates(new_timestamps, min_match)
@@ -189,6 +293,10 @@ class Store:
             session.close()
 
     def clear(self):                                            # app.py:325-333
+        try:
+            self.flush()
+        except Exception:
+            pass
         with self._write_lock:
             session = self.SessionLocal()
             try:
@@ -216,6 +324,15 @@ class Store:
             session.close()
 
     def close(self):
+        try:
+            self.flush()
+        except Exception:
+            pass
+        with self._wb_cv:
+            self._wb_stop = True
+            self._wb_cv.notify_all()
+        if self._wb_thread is not None:
+            self._wb_thread.join(timeout=5)
         self.corpus.close()
         self.engine.dispose()
 

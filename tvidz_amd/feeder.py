@@ -418,11 +418,16 @@ class FrameFeeder:
                 if n < self.batch:
                     break
         except BaseException as e:  # surfaced to the consumer
-            self._err = e
-            try:
-                self._full.put((None, -1), timeout=1.0)
-            except queue.Full:
-                pass
+            # (a reader closed under us by close() - the early stop at the first duplicate - ends
+            # here too: nobody is listening then, and waiting on the full queue cost a second)
+            if not self._stop.is_set():
+                self._err = e
+                while not self._stop.is_set():
+                    try:
+                        self._full.put((None, -1), timeout=0.05)
+                        break
+                    except queue.Full:
+                        continue
         finally:
             if slot is not None:
                 self.pool.release(slot)

@@ -81,7 +81,8 @@ class Inspector:
                  threshold: float = scene.DEFAULT_THRESHOLD, min_match: int = 2,
                  pts_policy: str = scene.PTS_POLICY_G6, batch: int = 256, max_workers: int = 16,
                  near_duplicates: bool = False, near_eps: float = 1.0 / 30, near_max_offset: float = 30.0,
-                 near_jaccard: float = 0.8, slot_bytes: int = 64 << 20, n_slots: Optional[int] = None):
+                 near_jaccard: float = 0.8, slot_bytes: int = 64 << 20, n_slots: Optional[int] = None,
+                 profile: bool = False):
         self.store = store
         self.device = torch.device(device)
         self.frame_source = frame_source or s3_frame_source
@@ -103,6 +104,18 @@ class Inspector:
         self._scorers: Dict[tuple, list] = {}           # idle SceneScorers by (H, W, bitdepth, frames)
         self._scorers_lock = threading.Lock()
         self._tls = threading.local()
+        # optional per-phase wall-clock accounting of the driver loop (profiles/e2e_service.py)
+        self.phase_seconds: Optional[Dict[str, float]] = {} if profile else None
+        self._phase_lock = threading.Lock()
+
+    def _phase(self, name: str, t0: float) -> float:
+        t1 = time.perf_counter()
+        if self.phase_seconds is not None:
+            with self._phase_lock:
+                self.phase_seconds[name] = self.phase_seconds.get(name, 0.0) + (t1 - t0)
+                self.phase_seconds["n_" + name] = self.phase_seconds.get("n_" + name, 0) + 1
+                self.phase_seconds["max_" + name] = max(self.phase_seconds.get("max_" + name, 0.0), t1 - t0)
+        return t1
 
     def close(self) -> None:
         self.pool.shutdown(wait=True)
@@ -138,9 +151,12 @@ class Inspector:
         analysis_key = f"{unique_id}_{filename}"                           # app.py:136
         with self.analysis_lock:
             self.analysis_results.pop(analysis_key, None)
+        t = time.perf_counter()
         if hasattr(self.store, "sync_if_stale"):
-            self.store.sync_if_stale()      # rows written by another process since our last look
+            self.store.sync_if_stale(min_interval=1.0)   # rows written by another process since our last look
+        t = self._phase("sync_census", t)
         video = self.store.add_video(original_filename)                    # app.py:150
+        t = self._phase("add_video", t)
         video_id = video.id
         self._set(analysis_key, {"status": "analyzing", "scene_cuts": [], "progress": 0.0,
                                  "total_cuts": 0, "duplicates": [], "original_filename": filename,
@@ -149,7 +165,9 @@ class Inspector:
         reader = None
         try:
             reader, local_path = self.frame_source(bucket, key, filename, unique_id)
+            t = self._phase("open_source", t)
             scene_timestamps, dups_to_report = self._run(analysis_key, video_id, reader)
+            t = self._phase("run_total", t)
             result = {"status": "done", "scene_cuts": scene_timestamps, "progress": 1.0,
                       "total_cuts": len(scene_timestamps),
                       "duplicates": list(set(dups_to_report)) if dups_to_report else [],
@@ -195,8 +213,10 @@ class Inspector:
         if stream is None:
             stream = self._tls.stream = torch.cuda.Stream(self.device)
         with torch.cuda.stream(stream):
+            t = time.perf_counter()
             scorer, skey = self._scorer_get(reader.H, reader.W, bitdepth, frames_per_batch)
             feeder = FrameFeeder(reader, frames_per_batch, self.device, pool=self.slots)
+            self._phase("setup", t)
             scene_timestamps, dups_to_report = self._loop(analysis_key, video_id, feeder, scorer, skey,
                                                           pts_of, time_base, total_frames)
         return scene_timestamps, dups_to_report
@@ -206,9 +226,19 @@ class Inspector:
         dups_to_report: List[str] = []
         frames_done = 0
         try:
-            for base, d_frames in feeder:
+            t = time.perf_counter()
+            batches = iter(feeder)
+            while True:
+                try:
+                    base, d_frames = next(batches)
+                except StopIteration:
+                    t = self._phase("wait_eof", t)
+                    break
+                t = self._phase("wait_frames", t)
                 scorer.score_batch(d_frames)               # state (prev frame, prev mafd) stays in HBM
+                t = self._phase("enqueue_score", t)
                 idx = scorer.fetch_cuts()                  # the batch's ONE device-to-host sync
+                t = self._phase("fetch_cuts", t)
                 frames_done = base + d_frames.shape[0]
                 grew = False
                 for i in idx:
@@ -223,12 +253,13 @@ class Inspector:
                     # reference's per-cut loop (app.py:234-238) would have stopped
                     hits = self.store.find_duplicates_kth(scene_timestamps, self.min_match,
                                                           exclude_id=video_id)            # :235-237
+                    t = self._phase("match", t)
                     hits = [h for h in hits if h[2] < KTH_NEVER]
                     if hits:
                         kstar = min(h[2] for h in hits)
                         dup_ids = [h[0] for h in hits if h[2] == kstar]
                         scene_timestamps = scene_timestamps[:max(kstar, 0) + 1]
-                        self.store.add_timestamps(video_id, scene_timestamps)             # :234
+                        self._persist(video_id, scene_timestamps)                         # :234
                         self.store.update_duplicates(video_id, dup_ids)                   # :239
                         for dup_id in dup_ids:                                            # :241-245
                             dup_video = self.store.get_video_by_id(dup_id)
@@ -237,12 +268,27 @@ class Inspector:
                         self._progress(analysis_key, scene_timestamps, frames_done, total_frames,
                                        dups_to_report)
                         break                                                             # :249-255
-                    self.store.add_timestamps(video_id, scene_timestamps)                 # :234
+                    self._persist(video_id, scene_timestamps)                             # :234
+                    t = self._phase("persist", t)
                 self._progress(analysis_key, scene_timestamps, frames_done, total_frames, dups_to_report)
+                t = self._phase("progress", t)
         finally:
+            t = time.perf_counter()
             feeder.close()                                 # stops the decoder (app.py:249-252)
             self._scorer_put(skey, scorer)
+            t = self._phase("close_feeder", t)
+            if hasattr(self.store, "flush"):
+                self.store.flush(video_id)                 # the SQL row is committed before `done`
+            self._phase("flush_sql", t)
         return scene_timestamps, dups_to_report
+
+    def _persist(self, video_id: int, scene_timestamps) -> None:
+        """app.py:234: the growing prefix goes to the device corpus at once (the next match of any
+        upload sees it) and to SQL through the store's coalescing write-behind."""
+        if hasattr(self.store, "add_timestamps_async"):
+            self.store.add_timestamps_async(video_id, scene_timestamps)
+        else:
+            self.store.add_timestamps(video_id, scene_timestamps)
 
     def _near(self, video_id: int, scene_timestamps):
         """Rows whose cut pattern aligns with this video's under a constant shift (tolerant Jaccard
