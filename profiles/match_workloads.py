@@ -21,6 +21,7 @@ from tvidz_amd import _lib, corpus as tc, synth  # noqa: E402
 
 which = sys.argv[1] if len(sys.argv) > 1 else "join"
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 12
+MM = int(sys.argv[3]) if len(sys.argv) > 3 else 2
 dev = torch.device("cuda:0")
 C, Q, algo = {"join": (100000, 1024, _lib.ALGO_JOIN), "q1_100k": (100000, 1, _lib.ALGO_Q1),
               "q1_5k": (5000, 1, _lib.ALGO_Q1), "tile": (100000, 64, _lib.ALGO_TILE),
@@ -38,16 +39,17 @@ ts = []
 if which == "topk":
     ws = torch.empty(tc.workspace_bytes(Q, ml, CAP, 16), dtype=torch.uint8, device=dev)
     out = torch.empty((Q, 17, 3), dtype=torch.int32, device=dev)
-    call = lambda: dc.match_topk(d_q, d_off, ml, 2, CAP, 16, out=out, workspace=ws, stream=st)
+    call = lambda: dc.match_topk(d_q, d_off, ml, MM, CAP, 16, out=out, workspace=ws, stream=st)
 else:
     ws = torch.empty(tc.workspace_bytes(Q, ml), dtype=torch.uint8, device=dev)
-    call = lambda: dc.match(d_q, d_off, ml, 2, CAP, out_hits=hits, out_n=n, stream=st, workspace=ws, algo=algo)
+    call = lambda: dc.match(d_q, d_off, ml, MM, CAP, out_hits=hits, out_n=n, stream=st, workspace=ws, algo=algo)
 for r in range(reps):
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record(st); call(); b.record(st)
     st.synchronize()
     ts.append(a.elapsed_time(b))
-res = {"workload": which, "C": C, "Q": Q, "median_ms": round(float(np.median(ts[2:])), 4)}
+res = {"workload": which, "C": C, "Q": Q, "min_match": MM, "median_ms": round(float(np.median(ts[2:])), 4),
+       "hits": int(n.sum().item()) if which != "topk" else None}
 if which == "q1_5k":
     lat = []
     for i in range(200):

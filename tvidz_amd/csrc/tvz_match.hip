@@ -18,8 +18,10 @@
 // Kernels: tvz_match_kernels.h.  No process-global mutable state: the sweep algorithm is a
 // per-call argument and scratch is the caller's workspace.
 #include <algorithm>
+#include <atomic>
 #include <mutex>
 #include <shared_mutex>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
@@ -51,7 +53,9 @@ struct Staging {
     int64_t *d_sq = nullptr;         // long queries: sorted distinct keys + multiplicities
     int32_t *d_smult = nullptr;
     int64_t sq_cap = 0;
+    std::atomic<int> busy{0};        // a sweep of this staging is in flight (drain() waits for it)
 };
+
 
 constexpr int kQ1MaxBlocks = 2048;
 constexpr int64_t kQueryStageKeys = kMaxQueryLen + 1;
@@ -89,6 +93,7 @@ struct tvz_corpus {
     RingSlot ring[kRingSlots];
     int ring_next = 0;
     std::vector<Staging *> free_staging;
+    std::vector<Staging *> all_staging;   // every staging ever made (checked out or free)
     int64_t stage_rows = 0;          // rows the stagings are sized for
 };
 
@@ -153,6 +158,12 @@ int drain(tvz_corpus *c) {
     }
     TVZ_HIP(hipStreamSynchronize(c->mstream));
     for (RingSlot &s : c->ring) s.pending = false;
+    // single-query sweeps are not event-tracked (their caller waits for them itself): a few us each
+    {
+        std::lock_guard<std::mutex> lk(c->stage_mu);
+        for (Staging *s : c->all_staging)
+            while (s->busy.load(std::memory_order_acquire)) std::this_thread::yield();
+    }
     return TVZ_OK;
 }
 
@@ -237,6 +248,10 @@ int staging_new(tvz_corpus *c, Staging **out) {
     TVZ_HIP(hipMalloc(&s->d_hits_n, sizeof(int32_t)));
     if (int rc = staging_size(s, c->stage_rows)) return rc;
     g.s = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(c->stage_mu);
+        c->all_staging.push_back(s);
+    }
     *out = s;
     return TVZ_OK;
 }
@@ -399,7 +414,9 @@ template <bool HOSTOUT>
 int launch_q1(tvz_corpus *c, const double *d_queries, const int64_t *d_q_offsets, int32_t Q,
               int32_t max_query_len, int32_t min_match, const int32_t *d_exclude_ids,
               int32_t exclude_one, int32_t cap, int32_t *d_hits, int32_t *d_hits_n, int blocks_x,
-              HostOut ho, hipStream_t st) {
+              HostOut ho, hipStream_t st, const QByVal *byval = nullptr) {
+    static const QByVal kNoQuery = {};
+    const QByVal &qv = byval ? *byval : kNoQuery;
     const int64_t n_rows = (int64_t)c->h_rows.size();
     const int s_log2 = q1_slots_log2(max_query_len);
     const size_t lds = q1_lds_bytes(s_log2);
@@ -407,7 +424,7 @@ int launch_q1(tvz_corpus *c, const double *d_queries, const int64_t *d_q_offsets
 #define TVZ_Q1(MODE)                                                                              \
     hipLaunchKernelGGL((ts_match_q1_kernel<MODE, HOSTOUT>), grid, dim3(kQ1Block), lds, st, c->rows.p, \
                        n_rows, c->keys.p, d_queries, d_q_offsets, min_match, d_exclude_ids,          \
-                       exclude_one, cap, d_hits, d_hits_n, s_log2, ho)
+                       exclude_one, cap, d_hits, d_hits_n, s_log2, ho, qv)
     if (min_match <= 0 || min_match > kTop) TVZ_Q1(kQ1ModeCount);
     else if (min_match <= 2) TVZ_Q1(kQ1ModeM2);
     else TVZ_Q1(kQ1ModeTop5);
@@ -417,6 +434,7 @@ int launch_q1(tvz_corpus *c, const double *d_queries, const int64_t *d_q_offsets
 }
 
 int q1_blocks(int64_t n_rows, int32_t Q) {
+
     // every row group gets >= 1 row; about 8 blocks per CU in total over the Q block columns
     int64_t b = tvz::ceil_div(n_rows, kQ1Groups);
     const int64_t per_q = std::max<int64_t>(256, kQ1MaxBlocks / std::max(1, Q));
@@ -585,7 +603,8 @@ static int tvz_corpus_destroy_impl(tvz_corpus *c) {
     {
         std::unique_lock<std::shared_mutex> lk(c->mu);
         if (c->mstream) (void)drain(c);
-        for (Staging *s : c->free_staging) staging_free(s);
+        for (Staging *s : c->all_staging) staging_free(s);
+        c->all_staging.clear();
         c->free_staging.clear();
         for (RingSlot &s : c->ring) {
             if (s.h) (void)hipHostFree(s.h);
@@ -814,11 +833,20 @@ static int tvz_find_duplicates_impl(tvz_corpus *c, const double *h_query, int64_
     const int32_t excl = exclude_id >= 0 ? exclude_id : -1;
     const bool one_launch = n <= kMaxQueryLen && min_match <= kTop;
     if (one_launch) {
-        // ---- ONE launch + ONE synchronisation: the kernel writes its hits to pinned host memory
-        s->h_query[0] = 0;
-        s->h_query[1] = n;
-        if (n) memcpy(s->h_query + 2, h_query, (size_t)n * 8);
-        TVZ_HIP(hipMemcpyAsync(s->d_query, s->h_query, (size_t)(n + 2) * 8, hipMemcpyHostToDevice, s->stream));
+        // ---- ONE launch + ONE synchronisation: the kernel writes its hits to pinned host memory;
+        // a query of up to 440 timestamps travels in the kernel arguments (no copy at all)
+        const bool by_value = n <= kQ1ByValKeys;
+        QByVal qv;
+        if (by_value) {
+            qv.n = (int32_t)n;
+            qv.pad = 0;
+            if (n) memcpy(qv.k, h_query, (size_t)n * 8);
+        } else {
+            s->h_query[0] = 0;
+            s->h_query[1] = n;
+            memcpy(s->h_query + 2, h_query, (size_t)n * 8);
+            TVZ_HIP(hipMemcpyAsync(s->d_query, s->h_query, (size_t)(n + 2) * 8, hipMemcpyHostToDevice, s->stream));
+        }
         int blocks = 0, region = 0;
         {
             std::shared_lock<std::shared_mutex> lk(c->mu);
@@ -832,14 +860,26 @@ static int tvz_find_duplicates_impl(tvz_corpus *c, const double *h_query, int64_
                 blocks = q1_blocks(n_rows, 1);
                 region = (int)(tvz::ceil_div(n_rows, (int64_t)blocks * kQ1Groups) * kQ1Groups);
                 const HostOut ho{s->dh_hits, s->dh_counts, region};
-                if (int rc = launch_q1<true>(c, reinterpret_cast<const double *>(s->d_query + 2), s->d_query,
-                                             1, (int32_t)n, min_match, nullptr, excl, 0, nullptr, nullptr,
-                                             blocks, ho, s->stream))
+                s->busy.store(1, std::memory_order_release);         // drain() waits for this sweep
+                if (int rc = launch_q1<true>(c, by_value ? nullptr : reinterpret_cast<const double *>(s->d_query + 2),
+                                             by_value ? nullptr : s->d_query, 1, (int32_t)n, min_match, nullptr,
+                                             excl, 0, nullptr, nullptr, blocks, ho, s->stream,
+                                             by_value ? &qv : nullptr)) {
+                    s->busy.store(0, std::memory_order_release);
                     return rc;
-                if (int rc = record(c, s->stream)) return rc;
+                }
             }
         }
-        TVZ_HIP(hipStreamSynchronize(s->stream));
+        // (polling the per-block counts from the host instead was tried: it needs a system-scope
+        // release per block, which saved 1.5 us at 5k rows and cost 60 us at 100k)
+        {
+            const hipError_t e = hipStreamSynchronize(s->stream);
+            if (e != hipSuccess) {
+                s->busy.store(0, std::memory_order_release);
+                return tvz::fail(TVZ_ERR_HIP, "single-query sweep failed: %s", hipGetErrorString(e));
+            }
+        }
+        s->busy.store(0, std::memory_order_release);
         // compact the per-block regions in place (block order; sorted below anyway)
         Hit *hh = reinterpret_cast<Hit *>(s->h_hits);
         int64_t w = 0;

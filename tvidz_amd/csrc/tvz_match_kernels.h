@@ -819,18 +819,27 @@ __global__ __launch_bounds__(kBlock) void ts_align_kernel(
 
 
 // ---- single-query sweep: the streaming driver's per-micro-batch call and small batches -------
-// One query per block column (blockIdx.y).  Every block rebuilds the query's keys as a small
-// multimap in LDS (8-byte keys, load factor <= 0.5, usually 0.2; every query element takes its own
-// slot, so multiplicity is exact and a lookup walks slot PAIRS - one aligned ds_read_b128 - up to
-// the first free slot).  A 16-lane group owns one corpus row at a time and streams its keys with
-// 16-byte loads; hits are accounted in PER-LANE registers (count + the smallest matching query
-// positions), reduced over the 16 lanes once per row with DPP.  No per-row LDS state, no clears,
-// no atomics on the hot path; rows are spread over up to 2048 blocks, so the sweep is bounded by
-// how fast the corpus streams out of HBM / Infinity Cache: algorithmic bytes = 16 B row entry +
-// 8 B per key, each read once per query.
+// One query per block column (blockIdx.y).  Every block rebuilds the query in LDS as
+//   (a) a blocked Bloom filter: one 64-bit word per key, one bit in each half, chosen by hash bits
+//       (words >= 4 x keys: ~0.02 % false positives per probe, never a false negative), and
+//   (b) an exact multimap (8-byte keys, load <= 0.5; every query element takes its own slot, so
+//       multiplicity is exact; a lookup walks slot PAIRS up to the first free slot).
+// A 16-lane group owns one corpus row at a time and streams its keys with 16-byte loads.
+// FAST PASS, branch-free: per key one hash, one ds_read_b64 of its Bloom word, two bit tests, one
+// add - about 16 wave-instructions per 64 keys - which only COUNTS the row's keys that may be in
+// the query.  A row can reach min_match only if that count does (query with repeated keys: if it
+// is >= 1), so the EXACT PASS - full-key probe of the multimap, hit count and the smallest
+// matching query positions in per-lane registers, DPP reduction over the 16 lanes - runs for the
+// ~2 % of rows that are real candidates instead of for every wave-instruction that has one
+// matching lane out of 64 (which is all of them: the first version did that and was bound by
+// instruction issue at 78 instructions per 64 keys, profiles/r2a_match_pmc.txt).
+// No per-row LDS state, no atomics on the hot path; rows are spread over up to 2048 blocks, so the
+// sweep is bounded by how fast the corpus streams out of HBM / Infinity Cache: algorithmic bytes =
+// 16 B row entry + 8 B per key, each read once per query.
 constexpr int kQ1Block = 256;
 constexpr int kQ1Groups = kQ1Block / kGroup;          // rows in flight per block
 constexpr int kQ1MinLog2 = 8, kQ1MaxLog2 = 13;        // 256 .. 8192 slots (2 KiB .. 64 KiB of keys)
+constexpr int kQ1BloomMaxLog2 = 12;                   // <= 4096 words (32 KiB)
 constexpr int kQ1ModeM2 = 0;                          // min_match 1..2: two smallest positions
 constexpr int kQ1ModeTop5 = 1;                        // min_match 3..5: five smallest positions
 constexpr int kQ1ModeCount = 2;                       // min_match <= 0 (kth = -1) or > 5 (fix-up)
@@ -841,12 +850,24 @@ struct HostOut {           // tvz_find_duplicates: hits go straight to pinned ho
     int32_t region;        // hit slots per block = rows one block can sweep
 };
 
-inline size_t q1_lds_bytes(int s_log2) { return ((size_t)8 + 2) << s_log2; }
+// A short single query travels BY VALUE in the kernel-argument segment (q_offsets == nullptr):
+// tvz_find_duplicates then needs no host-to-device copy at all - one launch, one synchronisation.
+constexpr int kQ1ByValKeys = 440;                     // 3520 B of the 4 KiB kernarg segment
+struct QByVal {
+    int32_t n;
+    int32_t pad;
+    double k[kQ1ByValKeys];
+};
 
 inline int q1_slots_log2(int64_t n) {
     int s = kQ1MinLog2;
     while (s < kQ1MaxLog2 && ((int64_t)1 << s) < 4 * n) ++s;
     return s;
+}
+inline int q1_bloom_log2(int s_log2) { return s_log2 < kQ1BloomMaxLog2 ? s_log2 : kQ1BloomMaxLog2; }
+// exact table: 8 B key + 2 B position per slot; Bloom: 8 B per word
+inline size_t q1_lds_bytes(int s_log2) {
+    return (((size_t)8 + 2) << s_log2) + ((size_t)8 << q1_bloom_log2(s_log2));
 }
 
 template <int CTRL>
@@ -866,174 +887,191 @@ __device__ __forceinline__ unsigned long long dpp16_64(unsigned long long v) {
     STEP(0x141) /* row_half_mirror     */ \
     STEP(0x140) /* row_mirror          */
 
+// the 32-bit mix every Q1 hash is cut from (bits 0-4 / 5-9: the two Bloom bits; x * C: the slots)
+__device__ __forceinline__ uint32_t q1_mix(int64_t k) {
+    const uint32_t lo = (uint32_t)k, hi = (uint32_t)((uint64_t)k >> 32);
+    uint32_t x = lo ^ (hi + (hi << 3)) ^ (hi >> 9);
+    x ^= x >> 20;
+    return x;
+}
+
 template <int MODE, bool HOSTOUT>
 __global__ __launch_bounds__(kQ1Block) void ts_match_q1_kernel(
     const Row *__restrict__ rows, int64_t n_rows, const int64_t *__restrict__ keys,
     const double *__restrict__ queries, const int64_t *__restrict__ q_offsets, int32_t min_match,
     const int32_t *__restrict__ exclude_ids, int32_t exclude_one, int32_t cap,
-    int32_t *__restrict__ hits, int32_t *__restrict__ hits_n, int32_t s_log2, HostOut ho) {
+    int32_t *__restrict__ hits, int32_t *__restrict__ hits_n, int32_t s_log2, HostOut ho,
+    const QByVal qv) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int S = 1 << s_log2;
+    const int b_log2 = s_log2 < kQ1BloomMaxLog2 ? s_log2 : kQ1BloomMaxLog2;
     int64_t *skey = reinterpret_cast<int64_t *>(smem);
-    uint16_t *spos = reinterpret_cast<uint16_t *>(skey + S);
-    __shared__ int32_t s_nhits;
+    uint2 *bloom = reinterpret_cast<uint2 *>(skey + S);
+    uint16_t *spos = reinterpret_cast<uint16_t *>(bloom + ((size_t)1 << b_log2));
+    __shared__ int32_t s_nhits, s_dups;
     const int q = blockIdx.y;
-    const int64_t qo = q_offsets[q];
-    const int64_t n = q_offsets[q + 1] - qo;
-    if (threadIdx.x == 0) s_nhits = 0;
+    const bool byval = q_offsets == nullptr;          // the query is in the kernel arguments
+    const int64_t qo = byval ? 0 : q_offsets[q];
+    const int64_t n = byval ? qv.n : q_offsets[q + 1] - qo;
+    if (threadIdx.x == 0) { s_nhits = 0; s_dups = 0; }
     if (2 * n > S) {
-        // the caller's max_query_len was not an upper bound (the table is sized from it)
+        // the caller's max_query_len was not an upper bound (the tables are sized from it)
         if (!HOSTOUT && threadIdx.x == 0) hits_n[q] = INT32_MIN;
         if (HOSTOUT && threadIdx.x == 0) ho.counts[blockIdx.x] = INT32_MIN;
         return;
     }
     for (int i = threadIdx.x * 2; i < S; i += kQ1Block * 2)
         *reinterpret_cast<longlong2 *>(skey + i) = make_longlong2(kEmpty, kEmpty);
+    for (int i = threadIdx.x; i < (1 << b_log2); i += kQ1Block) bloom[i] = make_uint2(0u, 0u);
     __syncthreads();
     const int pair_shift = 33 - s_log2;               // home PAIR from the top hash bits
+    const int word_shift = 32 - b_log2;
     const uint32_t smask = (uint32_t)S - 1u;
-    auto home = [&](int64_t k) -> uint32_t {
-        const uint32_t lo = (uint32_t)k, hi = (uint32_t)((uint64_t)k >> 32);
-        uint32_t x = lo ^ (hi + (hi << 3)) ^ (hi >> 9);
-        x ^= x >> 20;
-        const uint32_t y = __umul24(x, 0x9E3779u);      // __umul24 returns int: shift the UNSIGNED copy
-        return (y >> pair_shift) << 1;
-    };
     for (int e = threadIdx.x; e < (int)n; e += kQ1Block) {
         int64_t k;
-        if (!canon_key(queries[qo + e], k)) continue;           // NaN never matches
-        uint32_t h = home(k);
-        while (atomicCAS(reinterpret_cast<unsigned long long *>(&skey[h]), (unsigned long long)kEmpty,
-                         (unsigned long long)k) != (unsigned long long)kEmpty)
+        const double qk = byval ? qv.k[e] : queries[qo + e];
+        if (!canon_key(qk, k)) continue;                         // NaN never matches
+        const uint32_t x = q1_mix(k);
+        const uint32_t y = __umul24(x, 0x9E3779u);              // __umul24 returns int: keep it unsigned
+        uint32_t *bw = reinterpret_cast<uint32_t *>(bloom + (y >> word_shift));
+        atomicOr(bw, 1u << (x & 31u));
+        atomicOr(bw + 1, 1u << ((x >> 5) & 31u));
+        uint32_t h = (y >> pair_shift) << 1;
+        while (true) {
+            const unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long *>(&skey[h]),
+                                                     (unsigned long long)kEmpty, (unsigned long long)k);
+            if (old == (unsigned long long)kEmpty) break;
+            if (old == (unsigned long long)k) s_dups = 1;       // the query repeats a key
             h = (h + 1) & smask;
+        }
         spos[h] = (uint16_t)e;
     }
     __syncthreads();
+    // a row reaches min_match only if >= thr of its keys pass the filter
+    const int32_t thr = min_match <= 0 ? 0 : (s_dups ? 1 : min_match);
 
     const int gl = threadIdx.x & (kGroup - 1);
     const int g = threadIdx.x / kGroup;
     const int32_t excl = exclude_ids ? exclude_ids[q] : exclude_one;
     const int64_t stride = (int64_t)gridDim.x * kQ1Groups;
-    // Software pipeline over (row, step): a step = four 16-byte loads per lane = 128 keys per
-    // group.  While the 8 keys of one step are probed, the loads of the NEXT step - of this row,
-    // or the first of the group's next row, whose entry was fetched one row ahead - are already in
-    // flight, so a group never sits idle on a dependent row-entry -> keys round trip (the first
-    // version did, at every row: 78 % of its wave-cycles were waits, profiles/r2a_match_pmc.txt).
-    constexpr int kLd = 4;                                  // 16-byte loads per lane and step
-    constexpr int kStepKeys = kLd * 2 * kGroup;             // 128
-    longlong2 buf[kLd];
-    // UNCONDITIONAL loads (lanes past the row's end read the arena's first 16 bytes instead and
-    // are masked at compare time): a branch around a load makes the compiler wait with vmcnt(0)
-    // right after issuing the prefetch, which is how the first pipelined version bought nothing
-    auto issue = [&](int64_t off, int len, int base) {
-#pragma unroll
-        for (int j = 0; j < kLd; ++j) {
-            const int i = base + gl * 2 + j * 2 * kGroup;
-            const int64_t *p = (i < len) ? keys + off + i : keys;
-            buf[j] = *reinterpret_cast<const longlong2 *>(p);
-        }
+    // A step = EIGHT 16-byte loads per lane = 256 keys per group: a typical row (~200 cuts) is one
+    // step, i.e. 8 KiB per wave in flight while it waits - with 16-32 waves per CU that is the
+    // 100+ KiB per CU an HBM stream needs (Little's law; the first versions kept 2-4 KiB per wave
+    // in flight and levelled off at 2.5 TB/s whatever their instruction count).  The group's
+    // next row entry is fetched one row ahead, so a row costs ONE dependent round trip.
+    // UNCONDITIONAL loads (lanes past the row's end read the arena's first 16 bytes instead and are
+    // masked at compare time): a branch around a load makes the compiler wait with vmcnt(0).
+    constexpr int kLd = 8;                                  // 16-byte loads per lane and step
+    constexpr int kStepKeys = kLd * 2 * kGroup;             // 256
+    auto maybe = [&](int64_t k) -> uint32_t {               // 1 if k may be in the query
+        const uint32_t x = q1_mix(k);
+        const uint32_t y = __umul24(x, 0x9E3779u);
+        const uint2 w = bloom[y >> word_shift];
+        return (w.x >> (x & 31u)) & (w.y >> ((x >> 5) & 31u)) & 1u;
     };
     int64_t r = (int64_t)blockIdx.x * kQ1Groups + g;
     const int64_t last_row = n_rows - 1;
     Row row = load_row(rows + (r < n_rows ? r : last_row));       // past the end: a valid row, never used
-    issue(row.off, row.len, 0);
     while (r < n_rows) {
         const int64_t rn = r + stride;
-        // lands while this row is probed; past the end it is the last row again (valid memory, and
-        // the loop ends before anything of it is used) - masking its length here would make the
-        // compiler wait for the entry at once
+        // lands while this row is tested; past the end it is the last row again (valid memory, and
+        // the loop ends before anything of it is used)
         const Row nrow = load_row(rows + (rn < n_rows ? rn : last_row));
-        uint32_t cnt = 0, m1 = 0xffffffffu, m2 = 0xffffffffu;
-        unsigned long long top = kTopNone;
-        auto acc = [&](uint32_t pos) {
-            ++cnt;
-            if constexpr (MODE == kQ1ModeM2) {
-                const uint32_t lo = m1 < pos ? m1 : pos, hi = m1 < pos ? pos : m1;
-                m1 = lo;
-                m2 = m2 < hi ? m2 : hi;
-            } else if constexpr (MODE == kQ1ModeTop5) {
-                top = top5_insert(top, pos);
-            }
-        };
-        for (int base = 0;; base += kStepKeys) {
+        uint32_t may = 0;
+        for (int base = 0; base < row.len; base += kStepKeys) {
             longlong2 cur[kLd];
-#pragma unroll
-            for (int j = 0; j < kLd; ++j) cur[j] = buf[j];
-            const bool more = base + kStepKeys < row.len;
-            issue(more ? row.off : nrow.off, more ? row.len : nrow.len, more ? base + kStepKeys : 0);
 #pragma unroll
             for (int j = 0; j < kLd; ++j) {
                 const int i = base + gl * 2 + j * 2 * kGroup;
-                const int64_t kk[2] = {cur[j].x, cur[j].y};
-                const bool valid[2] = {i < row.len, i + 1 < row.len};
-                uint32_t hp[2];
-                longlong2 w[2];
+                const int64_t *p = (i < row.len) ? keys + row.off + i : keys;
+                cur[j] = *reinterpret_cast<const longlong2 *>(p);
+            }
 #pragma unroll
-                for (int e = 0; e < 2; ++e) {
-                    hp[e] = home(kk[e]);
-                    w[e] = *reinterpret_cast<const longlong2 *>(skey + hp[e]);
+            for (int j = 0; j < kLd; ++j) {
+                const int i = base + gl * 2 + j * 2 * kGroup;
+                // unconditional probes, masked afterwards: no branch per key
+                may += (maybe(cur[j].x) & (uint32_t)(i < row.len)) + (maybe(cur[j].y) & (uint32_t)(i + 1 < row.len));
+            }
+        }
+#define TVZ_SUM_STEP(C) may += dpp16<C>(may);
+        TVZ_ROW16_BUTTERFLY(TVZ_SUM_STEP)
+#undef TVZ_SUM_STEP
+        const bool cand = (int32_t)may >= thr;
+        if (__ballot(cand) != 0ull) {
+            // ---- exact pass over the candidate rows of this wave (their keys are L2-hot) ----
+            uint32_t cnt = 0, m1 = 0xffffffffu, m2 = 0xffffffffu;
+            unsigned long long top = kTopNone;
+            auto acc = [&](uint32_t pos) {
+                ++cnt;
+                if constexpr (MODE == kQ1ModeM2) {
+                    const uint32_t lo = m1 < pos ? m1 : pos, hi = m1 < pos ? pos : m1;
+                    m1 = lo;
+                    m2 = m2 < hi ? m2 : hi;
+                } else if constexpr (MODE == kQ1ModeTop5) {
+                    top = top5_insert(top, pos);
                 }
+            };
+            if (cand) {
+                const int64_t *rk = keys + row.off;
+                for (int i0 = gl * 2; i0 < row.len; i0 += 2 * kGroup) {
+                    const longlong2 a = *reinterpret_cast<const longlong2 *>(rk + i0);
+                    const int64_t kk[2] = {a.x, a.y};
+                    const bool valid[2] = {true, i0 + 1 < row.len};
 #pragma unroll
-                for (int e = 0; e < 2; ++e) {
-                    // in the table, or its home pair is full (the probe sequence goes on)
-                    const bool slow = valid[e] & ((w[e].x == kk[e]) | (w[e].y == kk[e]) |
-                                                  ((w[e].x != kEmpty) & (w[e].y != kEmpty)));
-                    if (slow) {
-                        uint32_t h = hp[e];
-                        longlong2 ww = w[e];
+                    for (int e = 0; e < 2; ++e) {
+                        if (!valid[e]) continue;
+                        const uint32_t y = __umul24(q1_mix(kk[e]), 0x9E3779u);
+                        uint32_t h = (y >> pair_shift) << 1;
                         while (true) {
+                            const longlong2 ww = *reinterpret_cast<const longlong2 *>(skey + h);
                             if (ww.x == kEmpty) break;
                             if (ww.x == kk[e]) acc(spos[h]);
                             if (ww.y == kEmpty) break;
                             if (ww.y == kk[e]) acc(spos[h + 1]);
                             h = (h + 2) & smask;
-                            ww = *reinterpret_cast<const longlong2 *>(skey + h);
                         }
                     }
                 }
             }
-            if (!more) break;
-        }
-        // the group's totals (every lane ends up with them)
+            // the group's totals (every lane ends up with them; non-candidate groups carry zeros)
 #define TVZ_SUM_STEP(C) cnt += dpp16<C>(cnt);
-        TVZ_ROW16_BUTTERFLY(TVZ_SUM_STEP)
+            TVZ_ROW16_BUTTERFLY(TVZ_SUM_STEP)
 #undef TVZ_SUM_STEP
-        const bool hit = (int64_t)cnt >= (int64_t)min_match && row.vid != excl;
-        if constexpr (MODE == kQ1ModeM2) {
+            const bool hit = cand && (int64_t)cnt >= (int64_t)min_match && row.vid != excl;
             if (__ballot(hit) != 0ull) {
+                if constexpr (MODE == kQ1ModeM2) {
 #define TVZ_M2_STEP(C) { const uint32_t p1 = dpp16<C>(m1), p2 = dpp16<C>(m2); \
-                const uint32_t lo = m1 < p1 ? m1 : p1, hi = m1 < p1 ? p1 : m1, r2 = m2 < p2 ? m2 : p2; \
-                m1 = lo; m2 = hi < r2 ? hi : r2; }
-                TVZ_ROW16_BUTTERFLY(TVZ_M2_STEP)
+                    const uint32_t lo = m1 < p1 ? m1 : p1, hi = m1 < p1 ? p1 : m1, r2 = m2 < p2 ? m2 : p2; \
+                    m1 = lo; m2 = hi < r2 ? hi : r2; }
+                    TVZ_ROW16_BUTTERFLY(TVZ_M2_STEP)
 #undef TVZ_M2_STEP
-            }
-        } else if constexpr (MODE == kQ1ModeTop5) {
-            if (__ballot(hit) != 0ull) {                // rare: most rows never reach min_match
+                } else if constexpr (MODE == kQ1ModeTop5) {
 #define TVZ_T5_STEP(C) { const unsigned long long p = dpp16_64<C>(top); \
-                _Pragma("unroll") for (int i = 0; i < kTop; ++i) top = top5_insert(top, (uint32_t)(p >> (12 * i)) & 0xfffu); }
-                TVZ_ROW16_BUTTERFLY(TVZ_T5_STEP)
+                    _Pragma("unroll") for (int i = 0; i < kTop; ++i) top = top5_insert(top, (uint32_t)(p >> (12 * i)) & 0xfffu); }
+                    TVZ_ROW16_BUTTERFLY(TVZ_T5_STEP)
 #undef TVZ_T5_STEP
+                }
             }
-        }
-        if (hit && gl == 0) {
-            int32_t kth;
-            if (min_match <= 0) kth = -1;
-            else if constexpr (MODE == kQ1ModeM2) kth = (int32_t)(min_match == 1 ? m1 : m2);
-            else if constexpr (MODE == kQ1ModeTop5) kth = (int32_t)((top >> (12 * (min_match - 1))) & 0xfffu);
-            else kth = -2 - (int32_t)r;                 // resolved by ts_kth_fixup_kernel
-            if constexpr (HOSTOUT) {
-                const int slot = atomicAdd(&s_nhits, 1);
-                int32_t *h = ho.hits + ((int64_t)blockIdx.x * ho.region + slot) * 3;
-                h[0] = row.vid;
-                h[1] = (int32_t)cnt;
-                h[2] = kth;
-            } else {
-                const int slot = atomicAdd(&hits_n[q], 1);
-                if (slot < cap) {
-                    int32_t *h = hits + ((int64_t)q * cap + slot) * 3;
+            if (hit && gl == 0) {
+                int32_t kth;
+                if (min_match <= 0) kth = -1;
+                else if constexpr (MODE == kQ1ModeM2) kth = (int32_t)(min_match == 1 ? m1 : m2);
+                else if constexpr (MODE == kQ1ModeTop5) kth = (int32_t)((top >> (12 * (min_match - 1))) & 0xfffu);
+                else kth = -2 - (int32_t)r;                 // resolved by ts_kth_fixup_kernel
+                if constexpr (HOSTOUT) {
+                    const int slot = atomicAdd(&s_nhits, 1);
+                    int32_t *h = ho.hits + ((int64_t)blockIdx.x * ho.region + slot) * 3;
                     h[0] = row.vid;
                     h[1] = (int32_t)cnt;
                     h[2] = kth;
+                } else {
+                    const int slot = atomicAdd(&hits_n[q], 1);
+                    if (slot < cap) {
+                        int32_t *h = hits + ((int64_t)q * cap + slot) * 3;
+                        h[0] = row.vid;
+                        h[1] = (int32_t)cnt;
+                        h[2] = kth;
+                    }
                 }
             }
         }
