@@ -292,29 +292,29 @@ int reserve_locked(tvz_corpus *c, int64_t n_rows, int64_t n_keys) {
 // ---- workspace layout of the batched calls -------------------------------------------------
 struct JoinShape {
     int n_tiles = 0;
+    int q_per_tile = 0;
     int s_log2 = 0;
-    size_t b_keys = 0, b_pack = 0, b_bloom = 0;
-    size_t bytes() const { return b_keys + b_pack + b_bloom; }
+    size_t bytes() const { return (size_t)n_tiles * ((size_t)4 << s_log2); }
 };
 
+// Tiles of up to 1024 queries whose elements fit a table of at most 2^19 four-byte slots (2 MiB:
+// L2 resident) at load factor <= 0.55: one corpus sweep per tile.
 JoinShape join_shape(int32_t Q, int32_t max_query_len) {
     JoinShape j;
     if (Q <= 0 || max_query_len <= 0) return j;
-    j.n_tiles = (int)tvz::ceil_div(Q, kJoinQ);
-    // slots per tile: load factor <= 0.5 (typically ~0.25) AND small enough to live in one XCD's
-    // 4 MiB L2 next to the streamed corpus (2 MiB at max_query_len <= 512); a table of 4 MiB was
-    // measured at the Infinity-Cache random-line rate instead of the L2's
-    j.s_log2 = 10;
-    while (((int64_t)1 << j.s_log2) < (int64_t)2 * kJoinQ * max_query_len) ++j.s_log2;
-    const size_t S = (size_t)1 << j.s_log2;
-    j.b_keys = (size_t)j.n_tiles * S * 8;
-    j.b_pack = (size_t)j.n_tiles * S * 4;
-    j.b_bloom = (size_t)j.n_tiles * (kJoinBloomBits / 8);
+    int64_t qpt = (int64_t)(0.55 * (double)((int64_t)1 << kJoinMaxSlotsLog2)) / max_query_len;
+    qpt = std::max<int64_t>(1, std::min<int64_t>(qpt, kJoinQ));
+    qpt = std::min<int64_t>(qpt, Q);
+    j.q_per_tile = (int)qpt;
+    j.n_tiles = (int)tvz::ceil_div(Q, qpt);
+    j.s_log2 = 12;
+    while (j.s_log2 < kJoinMaxSlotsLog2 && (double)((int64_t)1 << j.s_log2) * 0.55 < (double)qpt * max_query_len) ++j.s_log2;
     return j;
 }
 
 struct WsLayout {
     unsigned char *join = nullptr;  size_t join_bytes = 0;
+    int32_t *counters = nullptr;    // [Q] one per 128-byte line
     int32_t *hits = nullptr;        // [Q][cap][3]
     int32_t *hits_n = nullptr;      // [Q]
     int32_t *local = nullptr;       // [Q][k+1][3]
@@ -332,6 +332,8 @@ WsLayout ws_layout(void *base, int32_t Q, int32_t max_query_len, int32_t cap, in
     w.join_bytes = join_shape(Q, max_query_len).bytes();
     w.join = reinterpret_cast<unsigned char *>(p);
     p += al256(w.join_bytes);
+    w.counters = reinterpret_cast<int32_t *>(p);
+    p += al256((size_t)Q * kCountStride * 4);
     if (k > 0) {
         w.hits = reinterpret_cast<int32_t *>(p);
         p += al256((size_t)Q * (size_t)cap * 12);
@@ -354,7 +356,7 @@ constexpr int kJoinMinQ = 64;
 constexpr int64_t kJoinMinPairs = 5000000;
 
 int pick_algo(int32_t algo, int32_t Q, int64_t n_rows, int32_t max_query_len, int32_t min_match) {
-    const bool join_legal = min_match <= 2 && max_query_len > 0;
+    const bool join_legal = min_match >= 1 && min_match <= 2 && max_query_len > 0;
     if (algo == TVZ_ALGO_AUTO) {
         if (Q <= kQ1MaxQ) return TVZ_ALGO_Q1;
         if (join_legal && Q >= kJoinMinQ && (int64_t)Q * n_rows >= kJoinMinPairs) return TVZ_ALGO_JOIN;
@@ -364,11 +366,11 @@ int pick_algo(int32_t algo, int32_t Q, int64_t n_rows, int32_t max_query_len, in
     return algo;
 }
 
-int launch_prep(int32_t *d_hits_n, int32_t Q, void *ones, size_t ones_bytes, void *zeros,
+int launch_prep(int32_t *d_hits_n, int32_t ns, int32_t Q, void *ones, size_t ones_bytes, void *zeros,
                 size_t zero_bytes, hipStream_t st) {
     const size_t work = std::max<size_t>((size_t)Q, std::max(ones_bytes, zero_bytes) / 16);
     const int blocks = (int)std::min<size_t>(std::max<size_t>(1, tvz::ceil_div((int64_t)work, kBlock * 4)), 1024);
-    hipLaunchKernelGGL(ts_prep_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, st, d_hits_n, Q,
+    hipLaunchKernelGGL(ts_prep_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, st, d_hits_n, ns, Q,
                        reinterpret_cast<uint4 *>(ones), ones_bytes / 16,
                        reinterpret_cast<uint4 *>(zeros), zero_bytes / 16);
     TVZ_HIP(hipGetLastError());
@@ -377,35 +379,26 @@ int launch_prep(int32_t *d_hits_n, int32_t Q, void *ones, size_t ones_bytes, voi
 
 int launch_join(tvz_corpus *c, const double *d_queries, const int64_t *d_q_offsets, int32_t Q,
                 int32_t max_query_len, int32_t min_match, const int32_t *d_exclude_ids,
-                int32_t cap, int32_t *d_hits, int32_t *d_hits_n, unsigned char *ws, size_t ws_bytes,
-                hipStream_t st) {
+                int32_t cap, int32_t *d_hits, int32_t *d_hits_n, int32_t ns, unsigned char *ws,
+                size_t ws_bytes, hipStream_t st) {
     const int64_t n_rows = (int64_t)c->h_rows.size();
     const JoinShape j = join_shape(Q, max_query_len);
     if (ws == nullptr || ws_bytes < j.bytes())
         return tvz::fail(TVZ_ERR_WORKSPACE, "hash join needs a workspace of %zu bytes (got %zu): size it "
                                             "with tvz_match_workspace_bytes", j.bytes(), ws_bytes);
-    unsigned long long *tkeys = reinterpret_cast<unsigned long long *>(ws);
-    uint32_t *tpack = reinterpret_cast<uint32_t *>(ws + j.b_keys);
-    uint32_t *tbloom = reinterpret_cast<uint32_t *>(ws + j.b_keys + j.b_pack);
-    // one launch: hit counters = 0, every table key = kJEmpty, presence bitmaps = 0
-    if (int rc = launch_prep(d_hits_n, Q, tkeys, j.b_keys, tbloom, j.b_bloom, st)) return rc;
+    uint32_t *table = reinterpret_cast<uint32_t *>(ws);
+    // one launch: hit counters = 0, every table slot = free
+    if (int rc = launch_prep(d_hits_n, ns, Q, table, j.bytes(), nullptr, 0, st)) return rc;
     hipLaunchKernelGGL(ts_join_build_kernel, dim3((unsigned)tvz::ceil_div(max_query_len, kBlock), (unsigned)Q),
-                       dim3(kBlock), 0, st, d_queries, d_q_offsets, Q, max_query_len, j.s_log2, tkeys, tpack,
-                       tbloom, d_hits_n);
+                       dim3(kBlock), 0, st, d_queries, d_q_offsets, Q, max_query_len, j.q_per_tile, j.s_log2,
+                       table, d_hits_n, ns);
     TVZ_HIP(hipGetLastError());
-    // two 1024-thread blocks per CU: about two rounds of 512 blocks, >= 8 rows per 16-lane group
-    const int n_tiles = j.n_tiles;
-    const int64_t g = (8 % n_tiles == 0) ? 8 / n_tiles : 1;
-    int64_t chunks = std::max<int64_t>(1, 1024 / n_tiles);
-    chunks = std::min(chunks, std::max<int64_t>(1, n_rows / (2 * kJoinGroups)));
-    chunks = tvz::round_up(chunks, g);
-    const int64_t rpb = tvz::round_up(tvz::ceil_div(n_rows, chunks), kJoinGroups);
-    int64_t blocks = (int64_t)n_tiles * chunks;
-    if (8 % n_tiles == 0) blocks = tvz::round_up(blocks, 8);
-    hipLaunchKernelGGL(ts_match_join_kernel, dim3((unsigned)blocks), dim3(kJoinBlock), kJoinLds, st,
-                       c->rows.p, n_rows, c->keys.p, reinterpret_cast<const int64_t *>(tkeys), tpack, tbloom,
-                       j.s_log2, Q, n_tiles, (int32_t)chunks, min_match, d_exclude_ids, cap, d_hits,
-                       d_hits_n, (int32_t)rpb);
+    // two 16-wave blocks per CU (8192 waves in all over the tiles), >= 4 rows per wave
+    int64_t chunks = std::max<int64_t>(1, 512 / j.n_tiles);
+    chunks = std::min(chunks, std::max<int64_t>(1, n_rows / (4 * kJoinWaves)));
+    hipLaunchKernelGGL(ts_match_join_kernel, dim3((unsigned)chunks, (unsigned)j.n_tiles), dim3(kJoinBlock),
+                       kJoinLds, st, c->rows.p, n_rows, c->keys.p, d_queries, d_q_offsets, table, j.s_log2, Q,
+                       j.q_per_tile, min_match, d_exclude_ids, cap, d_hits, d_hits_n, ns);
     TVZ_HIP(hipGetLastError());
     return TVZ_OK;
 }
@@ -413,8 +406,8 @@ int launch_join(tvz_corpus *c, const double *d_queries, const int64_t *d_q_offse
 template <bool HOSTOUT>
 int launch_q1(tvz_corpus *c, const double *d_queries, const int64_t *d_q_offsets, int32_t Q,
               int32_t max_query_len, int32_t min_match, const int32_t *d_exclude_ids,
-              int32_t exclude_one, int32_t cap, int32_t *d_hits, int32_t *d_hits_n, int blocks_x,
-              HostOut ho, hipStream_t st, const QByVal *byval = nullptr) {
+              int32_t exclude_one, int32_t cap, int32_t *d_hits, int32_t *d_hits_n, int32_t ns,
+              int blocks_x, HostOut ho, hipStream_t st, const QByVal *byval = nullptr) {
     static const QByVal kNoQuery = {};
     const QByVal &qv = byval ? *byval : kNoQuery;
     const int64_t n_rows = (int64_t)c->h_rows.size();
@@ -424,7 +417,7 @@ int launch_q1(tvz_corpus *c, const double *d_queries, const int64_t *d_q_offsets
 #define TVZ_Q1(MODE)                                                                              \
     hipLaunchKernelGGL((ts_match_q1_kernel<MODE, HOSTOUT>), grid, dim3(kQ1Block), lds, st, c->rows.p, \
                        n_rows, c->keys.p, d_queries, d_q_offsets, min_match, d_exclude_ids,          \
-                       exclude_one, cap, d_hits, d_hits_n, s_log2, ho, qv)
+                       exclude_one, cap, d_hits, d_hits_n, ns, s_log2, ho, qv)
     if (min_match <= 0 || min_match > kTop) TVZ_Q1(kQ1ModeCount);
     else if (min_match <= 2) TVZ_Q1(kQ1ModeM2);
     else TVZ_Q1(kQ1ModeTop5);
@@ -444,8 +437,8 @@ int q1_blocks(int64_t n_rows, int32_t Q) {
 
 int launch_match(tvz_corpus *c, const double *d_queries, const int64_t *d_q_offsets, int32_t Q,
                  int32_t max_query_len, int32_t min_match, const int32_t *d_exclude_ids,
-                 int32_t cap, int32_t *d_hits, int32_t *d_hits_n, unsigned char *ws, size_t ws_bytes,
-                 int32_t algo, hipStream_t st) {
+                 int32_t cap, int32_t *d_hits, int32_t *d_hits_n, int32_t ns, unsigned char *ws,
+                 size_t ws_bytes, int32_t algo, hipStream_t st) {
     if (max_query_len > kMaxQueryLen)
         return tvz::fail(TVZ_ERR_UNSUPPORTED, "query of %d timestamps exceeds the supported %d",
                          max_query_len, kMaxQueryLen);
@@ -457,14 +450,14 @@ int launch_match(tvz_corpus *c, const double *d_queries, const int64_t *d_q_offs
     if (a == TVZ_ALGO_JOIN && algo == TVZ_ALGO_AUTO && (ws == nullptr || ws_bytes < join_shape(Q, max_query_len).bytes()))
         a = TVZ_ALGO_TILE;
     if (n_rows == 0 || a != TVZ_ALGO_JOIN)
-        if (int rc = launch_prep(d_hits_n, Q, nullptr, 0, nullptr, 0, st)) return rc;
+        if (int rc = launch_prep(d_hits_n, ns, Q, nullptr, 0, nullptr, 0, st)) return rc;
     if (n_rows == 0 || Q == 0) return TVZ_OK;
     if (a == TVZ_ALGO_JOIN)
         return launch_join(c, d_queries, d_q_offsets, Q, max_query_len, min_match, d_exclude_ids, cap,
-                           d_hits, d_hits_n, ws, ws_bytes, st);
+                           d_hits, d_hits_n, ns, ws, ws_bytes, st);
     if (a == TVZ_ALGO_Q1) {
         if (int rc = launch_q1<false>(c, d_queries, d_q_offsets, Q, max_query_len, min_match,
-                                      d_exclude_ids, -1, cap, d_hits, d_hits_n, q1_blocks(n_rows, Q),
+                                      d_exclude_ids, -1, cap, d_hits, d_hits_n, ns, q1_blocks(n_rows, Q),
                                       HostOut{nullptr, nullptr, 0}, st))
             return rc;
     } else {
@@ -484,27 +477,27 @@ int launch_match(tvz_corpus *c, const double *d_queries, const int64_t *d_q_offs
         if (min_match <= 2)
             hipLaunchKernelGGL(ts_match_tile_kernel<false>, dim3((unsigned)chunks, (unsigned)tiles),
                                dim3(kTileBlock), kTileLds, st, c->rows.p, n_rows, c->keys.p, d_queries,
-                               d_q_offsets, Q, nq, min_match, d_exclude_ids, cap, d_hits, d_hits_n,
+                               d_q_offsets, Q, nq, min_match, d_exclude_ids, cap, d_hits, d_hits_n, ns,
                                (int32_t)rpb);
         else
             hipLaunchKernelGGL(ts_match_tile_kernel<true>, dim3((unsigned)chunks, (unsigned)tiles),
                                dim3(kTileBlock), kTileLds, st, c->rows.p, n_rows, c->keys.p, d_queries,
-                               d_q_offsets, Q, nq, min_match, d_exclude_ids, cap, d_hits, d_hits_n,
+                               d_q_offsets, Q, nq, min_match, d_exclude_ids, cap, d_hits, d_hits_n, ns,
                                (int32_t)rpb);
         TVZ_HIP(hipGetLastError());
     }
     if (min_match > kTop) {
         hipLaunchKernelGGL(ts_kth_fixup_kernel, dim3((unsigned)Q), dim3(kBlock), 0, st, c->rows.p,
-                           c->keys.p, d_queries, d_q_offsets, min_match, cap, d_hits, d_hits_n);
+                           c->keys.p, d_queries, d_q_offsets, min_match, cap, d_hits, d_hits_n, ns);
         TVZ_HIP(hipGetLastError());
     }
     return TVZ_OK;
 }
 
-int launch_topk_local(const int32_t *d_hits, const int32_t *d_hits_n, int32_t Q, int32_t cap,
+int launch_topk_local(const int32_t *d_hits, const int32_t *d_hits_n, int32_t ns, int32_t Q, int32_t cap,
                       int32_t k, int32_t *d_out, int mode, hipStream_t st) {
     hipLaunchKernelGGL(ts_topk_select_kernel, dim3((unsigned)Q), dim3(kBlock), 0, st, d_hits, d_hits_n,
-                       Q, cap, k, d_out, mode);
+                       ns, Q, cap, k, d_out, mode);
     TVZ_HIP(hipGetLastError());
     return TVZ_OK;
 }
@@ -539,10 +532,11 @@ int tvz_match_topk_local(tvz_corpus *c, const double *d_queries, const int64_t *
     DeviceGuard dg(c->device);
     hipStream_t st = reinterpret_cast<hipStream_t>(hip_stream);
     std::shared_lock<std::shared_mutex> lk(c->mu);
+    // the sweeps count into one-counter-per-line scratch; the select kernel reads it as it is
     if (int rc = launch_match(c, d_queries, d_q_offsets, Q, max_query_len, min_match, d_exclude_ids,
-                              cap, w.hits, w.hits_n, w.join, w.join_bytes, algo, st))
+                              cap, w.hits, w.counters, kCountStride, w.join, w.join_bytes, algo, st))
         return rc;
-    if (int rc = launch_topk_local(w.hits, w.hits_n, Q, cap, k, d_out, 1, st)) return rc;
+    if (int rc = launch_topk_local(w.hits, w.counters, kCountStride, Q, cap, k, d_out, 1, st)) return rc;
     return record(c, st);
 }
 
@@ -788,17 +782,34 @@ static int tvz_match_impl(tvz_corpus *c, const double *d_queries, const int64_t 
     TVZ_REQUIRE(d_hits_n && (cap == 0 || d_hits), "NULL output");
     DeviceGuard dg(c->device);
     hipStream_t st = reinterpret_cast<hipStream_t>(hip_stream);
+    // with a workspace (tvz_match_workspace_bytes(Q, max_query_len, 0, 0, 1)) the sweeps count into
+    // one-counter-per-cache-line scratch and may use the hash join; without one they fall back to
+    // the caller's dense counters and the LDS kernels
     unsigned char *ws = nullptr;
     size_t ws_bytes = 0;
+    int32_t *cnt = d_hits_n;
+    int32_t ns = 1;
     if (d_workspace) {
-        const uintptr_t p = (reinterpret_cast<uintptr_t>(d_workspace) + 255) & ~(uintptr_t)255;
-        const size_t lost = p - reinterpret_cast<uintptr_t>(d_workspace);
-        if (workspace_bytes > lost) { ws = reinterpret_cast<unsigned char *>(p); ws_bytes = workspace_bytes - lost; }
+        const WsLayout w = ws_layout(d_workspace, Q, max_query_len, cap, 0, 1);
+        if (workspace_bytes >= w.total) {
+            ws = w.join;
+            ws_bytes = w.join_bytes;
+            cnt = w.counters;
+            ns = kCountStride;
+        } else if (algo == TVZ_ALGO_JOIN) {
+            return tvz::fail(TVZ_ERR_WORKSPACE, "workspace of %zu bytes, the hash join needs %zu: size it with "
+                                                "tvz_match_workspace_bytes", workspace_bytes, w.total);
+        }
     }
     std::shared_lock<std::shared_mutex> lk(c->mu);
     if (int rc = launch_match(c, d_queries, d_q_offsets, Q, max_query_len, min_match,
-                              d_exclude_ids, cap, d_hits, d_hits_n, ws, ws_bytes, algo, st))
+                              d_exclude_ids, cap, d_hits, cnt, ns, ws, ws_bytes, algo, st))
         return rc;
+    if (ns != 1) {
+        hipLaunchKernelGGL(ts_counts_gather_kernel, dim3((unsigned)tvz::ceil_div(Q, kBlock)), dim3(kBlock), 0, st,
+                           cnt, ns, d_hits_n, Q);
+        TVZ_HIP(hipGetLastError());
+    }
     return record(c, st);
 }
 
@@ -863,7 +874,7 @@ static int tvz_find_duplicates_impl(tvz_corpus *c, const double *h_query, int64_
                 s->busy.store(1, std::memory_order_release);         // drain() waits for this sweep
                 if (int rc = launch_q1<true>(c, by_value ? nullptr : reinterpret_cast<const double *>(s->d_query + 2),
                                              by_value ? nullptr : s->d_query, 1, (int32_t)n, min_match, nullptr,
-                                             excl, 0, nullptr, nullptr, blocks, ho, s->stream,
+                                             excl, 0, nullptr, nullptr, 1, blocks, ho, s->stream,
                                              by_value ? &qv : nullptr)) {
                     s->busy.store(0, std::memory_order_release);
                     return rc;
@@ -948,7 +959,7 @@ static int tvz_find_duplicates_impl(tvz_corpus *c, const double *h_query, int64_
             std::shared_lock<std::shared_mutex> lk(c->mu);
             const int64_t n_rows = (int64_t)c->h_rows.size();
             if (int rc = wait_mutations(c, s->stream)) return rc;
-            if (int rc = launch_prep(s->d_hits_n, 1, nullptr, 0, nullptr, 0, s->stream)) return rc;
+            if (int rc = launch_prep(s->d_hits_n, 1, 1, nullptr, 0, nullptr, 0, s->stream)) return rc;
             if (n_rows) {
                 if (longq) {
                     hipLaunchKernelGGL(ts_match_longq_kernel, dim3((unsigned)tvz::ceil_div(n_rows, kGroupsPerBlock)),
@@ -958,14 +969,14 @@ static int tvz_find_duplicates_impl(tvz_corpus *c, const double *h_query, int64_
                     TVZ_HIP(hipGetLastError());
                 } else {
                     if (int rc = launch_q1<false>(c, reinterpret_cast<const double *>(d_q + 2), d_q, 1, (int32_t)n,
-                                                  min_match, nullptr, -1, (int32_t)want, s->d_hits, s->d_hits_n,
+                                                  min_match, nullptr, -1, (int32_t)want, s->d_hits, s->d_hits_n, 1,
                                                   q1_blocks(n_rows, 1), HostOut{nullptr, nullptr, 0}, s->stream))
                         return rc;
                 }
                 if (min_match > 0) {
                     hipLaunchKernelGGL(ts_kth_fixup_kernel, dim3(1), dim3(kBlock), 0, s->stream, c->rows.p,
                                        c->keys.p, reinterpret_cast<const double *>(d_q + 2), d_q, min_match,
-                                       (int32_t)want, s->d_hits, s->d_hits_n);
+                                       (int32_t)want, s->d_hits, s->d_hits_n, 1);
                     TVZ_HIP(hipGetLastError());
                 }
             }
@@ -1015,7 +1026,7 @@ static int tvz_topk_impl(const int32_t *d_lists, const int32_t *d_lists_n, int32
     if (Q == 0) return TVZ_OK;
     TVZ_REQUIRE((d_lists || cap == 0) && d_topk, "NULL argument");
     hipStream_t st = reinterpret_cast<hipStream_t>(hip_stream);
-    if (n_lists == 1) return launch_topk_local(d_lists, d_lists_n, Q, cap, k, d_topk, 0, st);
+    if (n_lists == 1) return launch_topk_local(d_lists, d_lists_n, 1, Q, cap, k, d_topk, 0, st);
     hipLaunchKernelGGL(ts_topk_kernel, dim3((unsigned)Q), dim3(kBlock), 0, st, d_lists, d_lists_n,
                        n_lists, Q, cap, k, d_topk, 0, nullptr);
     TVZ_HIP(hipGetLastError());
@@ -1028,7 +1039,7 @@ static int tvz_topk_shard_impl(const int32_t *d_hits, const int32_t *d_hits_n, i
     TVZ_REQUIRE(k >= 1 && k <= kSortCap / 2, "k=%d out of range [1, %d]", k, kSortCap / 2);
     if (Q == 0) return TVZ_OK;
     TVZ_REQUIRE((d_hits || cap == 0) && d_hits_n && d_out, "NULL argument");
-    return launch_topk_local(d_hits, d_hits_n, Q, cap, k, d_out, 1, reinterpret_cast<hipStream_t>(hip_stream));
+    return launch_topk_local(d_hits, d_hits_n, 1, Q, cap, k, d_out, 1, reinterpret_cast<hipStream_t>(hip_stream));
 }
 
 static int tvz_topk_merge_impl(const int32_t *d_gathered, int32_t n_ranks, int32_t Q, int32_t k,

@@ -6,7 +6,8 @@
 //                        a 16-lane group per row, per-lane counters, no per-row LDS state.
 //                        HBM/MALL-stream-bound: the single-query and small-batch path.
 // ts_match_tile_kernel   one LDS hash table per tile of <= 16 queries, ring/drain slow path.
-// ts_join_build_kernel + ts_match_join_kernel   device-memory hash join per 128-query tile.
+// ts_join_build_kernel + ts_match_join_kernel   device-memory hash join per tile of <= 1024 queries,
+//                        a wave per corpus row, per-wave LDS accounting (min_match 1..2).
 // ts_match_longq_kernel  single queries longer than a tile (> 4095 timestamps).
 // ts_kth_fixup_kernel    kth for min_match > 5.
 // ts_topk_select_kernel  per-query k best of a long hit list: kth histogram in LDS picks the
@@ -157,7 +158,7 @@ __global__ __launch_bounds__(kTileBlock) void ts_match_tile_kernel(
     const Row *__restrict__ rows, int64_t n_rows, const int64_t *__restrict__ keys,
     const double *__restrict__ queries, const int64_t *__restrict__ q_offsets, int32_t Q,
     int32_t nq_tile, int32_t min_match, const int32_t *__restrict__ exclude_ids, int32_t cap,
-    int32_t *__restrict__ hits, int32_t *__restrict__ hits_n, int32_t rows_per_block) {
+    int32_t *__restrict__ hits, int32_t *__restrict__ hits_n, int32_t ns, int32_t rows_per_block) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t *slots = reinterpret_cast<uint32_t *>(smem);
     int64_t *ekey = reinterpret_cast<int64_t *>(smem + (size_t)kTileSlots * 4);
@@ -179,7 +180,7 @@ __global__ __launch_bounds__(kTileBlock) void ts_match_tile_kernel(
     if (s_qoff[nq] - qbase > kTileMaxEntries) {
         // the caller's max_query_len was not an upper bound: poison the affected counters instead
         // of returning silently truncated matches (every row chunk of this tile takes this exit)
-        if (threadIdx.x < nq) hits_n[q0 + threadIdx.x] = INT32_MIN;
+        if (threadIdx.x < nq) hits_n[(size_t)(q0 + threadIdx.x) * ns] = INT32_MIN;
         return;
     }
     const int total = (int)(s_qoff[nq] - qbase);
@@ -343,7 +344,7 @@ __global__ __launch_bounds__(kTileBlock) void ts_match_tile_kernel(
                 else if (!TOP5) kth = (int32_t)(uint32_t)(min_match == 1 ? t5 : t5 >> 32);
                 else if (min_match <= kTop) kth = (int32_t)((t5 >> (12 * (min_match - 1))) & 0xfffu);
                 else kth = -2 - (int32_t)r;          // resolved by ts_kth_fixup_kernel
-                const int slot = atomicAdd(&hits_n[q0 + gl], 1);
+                const int slot = atomicAdd(&hits_n[(size_t)(q0 + gl) * ns], 1);
                 if (slot < cap) {
                     int32_t *h = hits + ((int64_t)(q0 + gl) * cap + slot) * 3;
                     h[0] = row.vid;
@@ -355,47 +356,61 @@ __global__ __launch_bounds__(kTileBlock) void ts_match_tile_kernel(
     }
 }
 
-// ---- hash join for large query batches (Q >= 32, min_match <= 2) ----------------------------
-// The LDS tile kernel probes every corpus key once per 16 queries.  For big batches against big
-// corpora a database hash JOIN does less work: build one multimap per tile of 128 queries in device
-// memory (sized to stay in one XCD's 4 MiB L2), then sweep the corpus once per tile - one probe of a
-// corpus key serves 128 queries, 8x fewer probes than the LDS tile.  Blocks of one tile are mapped
-// to one XCD (blockIdx % 8) so its table is served from that XCD's L2.  What it buys is bounded by
-// the L2: a random 16-byte probe moves a whole cache line, and the measured probe rate (~180 G/s)
-// is the L2's random-line rate - LDS has no line granularity, which is why the LDS tile stays
-// competitive with 8x the probes (1.18 vs 2.30 ms at C=100k, Q=1024).  An LDS presence bitmap of
-// the tile's keys (64 KiB) keeps ~70 % of the corpus keys from touching the L2 at all.  Per (row group, query) state lives in LDS: a u16 hit
-// counter and the two smallest matching positions (u16 + u16 in one CAS word); after a row each
-// lane scans 8 of the tile's 128 queries and emits the hits.
-constexpr int kJoinQ = 128;
+// ---- hash join for large query batches (min_match 1..2) -------------------------------------
+// The LDS tile kernel probes every corpus key once per 16 queries.  For big batches a database
+// hash JOIN does less work: build ONE multimap per tile of up to 1024 queries in device memory,
+// then sweep the corpus ONCE per tile - one probe of a corpus key serves 1024 queries.
+//
+// What bounds such a probe is where the table lives: a random 16-byte probe moves a whole cache
+// line, and beyond an XCD's 4 MiB L2 the lines come at the Infinity Cache's random-line rate
+// (a 12 MiB table of 8-byte keys + packs: 47 % L2 hits, 3.6 GB fetched per sweep, no faster than
+// eight sweeps over 128-query tables that fit - profiles/r2c_match_pmc.txt).  So the table is made
+// SMALL instead: one 32-bit slot per query element,
+//      [ fingerprint : 10 | query-in-tile : 10 | position : 12 ]       (0xffffffff = free)
+// in 16-byte buckets of four; 2^19 slots = 2 MiB hold the 205 k elements of 1024 queries at load
+// 0.4 and stay in L2.  A probe loads the key's home bucket (one 16-byte load), compares four
+// fingerprints, and only on a fingerprint match (a real match, or 1 probe in ~700 by chance)
+// verifies the FULL key against the query element itself (queries[...], 1.6 MB, also cache
+// resident), so results stay exact.  A bucket with no free slot sends the probe on to the next.
+//
+// Sweep: a whole WAVE owns one corpus row at a time (64 lanes x 16 B = 128 keys per load
+// instruction).  Matches are accounted in a per-wave LDS table of 256 slots keyed by the query's
+// index in the tile - (tag | count) claimed with one CAS, the two smallest matching positions kept
+// with two atomicMin - 3 KiB per wave, so two 16-wave blocks fit a CU at full occupancy.  After a
+// row each lane scans 4 slots, emits the (query, row) pairs that reached min_match and resets
+// them.  A row that touches more than 256 distinct queries of the tile sets an overflow flag and is
+// re-done in 4 passes of 256 queries each, which always fit.
+// SIMT shapes the inner loop as it did the tile kernel's: ~40 % of the lanes have a fingerprint
+// match per key, so handling matches where they are found runs the verify + account path at
+// every one of the 16 (key, slot) positions of a step with a fraction of the lanes (first
+// version: 1,400 wave-instructions per 64 keys, profiles/r2d_match_pmc.txt).  Instead the
+// fingerprint stage only PUSHES (slot, key index) candidates into a per-wave LDS ring by
+// ballot/mbcnt compaction, and whenever 64 are pending the whole wave drains them with every lane
+// busy on the exact compare and the accounting.
+constexpr int kJoinQ = 1024;                          // queries per tile (10 bits of a slot)
 constexpr int kJoinBlock = 1024;
-constexpr int kJoinGroups = kJoinBlock / kGroup;
-constexpr int kJoinBloomBits = 1 << 19;                           // 64 KiB presence bitmap per tile
-constexpr size_t kJoinLds = (size_t)kJoinGroups * kJoinQ * 10 + kJoinBloomBits / 8;   // 80 + 64 KiB
-constexpr int64_t kJEmpty = -1;                                    // 0xff..ff: a NaN pattern
+constexpr int kJoinWaves = kJoinBlock / 64;
+constexpr int kJoinSlots = 256;                       // per-wave accounting slots
+constexpr int kJoinMaxSlotsLog2 = 19;                 // 2^19 x 4 B = 2 MiB per tile
+constexpr int kJoinRing = 128;                        // per-wave candidate ring (entries of 8 B)
+constexpr size_t kJoinLds = (size_t)kJoinWaves * kJoinSlots * 12 + (size_t)kJoinWaves * kJoinRing * 8 +
+                            kJoinWaves * 4 + (kJoinQ + 1) * 8;
+constexpr uint32_t kJFree = 0xffffffffu;
 
-__device__ __forceinline__ uint32_t hash32(int64_t k) {
+// bucket index (high bits) and 10-bit fingerprint (low bits) of a canonical key
+__device__ __forceinline__ void join_hash(int64_t k, int s_log2, uint32_t &bucket, uint32_t &fp) {
     const uint32_t lo = (uint32_t)k, hi = (uint32_t)((uint64_t)k >> 32);
     uint32_t x = lo ^ (hi + (hi << 3)) ^ (hi >> 9);
     x ^= x >> 20;
     const uint32_t y = __umul24(x, 0x9E3779u);
-    return y ^ (y >> 15);
+    bucket = y >> (34 - s_log2);                      // s_log2 - 2 bits: buckets of 4 slots
+    fp = (x ^ (x >> 11)) & 0x3ffu;
 }
 
-// Table layout: keys int64[S] and packs u32[S] apart, so ONE 16-byte load fetches the two keys of a
-// slot pair; the (position | query-in-tile << 12) pack is only loaded on a match.  Random global
-// accesses cost the CU's address pipeline ~1 lane-address per cycle, so loads per probe are what
-// bounds this kernel (an array-of-structs slot needed two loads per probe: 1.6x slower).
-
-// The table is a MULTIMAP: every query element takes its own slot (the first free one of its key's
-// probe sequence), so a lookup needs no dependent chain loads - it walks the probe sequence up to
-// the first free slot and accounts every slot that carries the key.  (A chained layout was tried:
-// on a 64-lane wave some lane almost always has a chain to follow, and each hop is a dependent
-// ~1 us L2 access.)
 __global__ __launch_bounds__(kBlock) void ts_join_build_kernel(
     const double *__restrict__ queries, const int64_t *__restrict__ q_offsets, int32_t Q,
-    int32_t max_len, int32_t s_log2, unsigned long long *__restrict__ tkeys,
-    uint32_t *__restrict__ tpack, uint32_t *__restrict__ tbloom, int32_t *__restrict__ hits_n) {
+    int32_t max_len, int32_t q_per_tile, int32_t s_log2, uint32_t *__restrict__ table,
+    int32_t *__restrict__ hits_n, int32_t ns) {
     const int q = blockIdx.y;
     const int64_t o = q_offsets[q];
     const int i = blockIdx.x * kBlock + threadIdx.x;
@@ -403,165 +418,175 @@ __global__ __launch_bounds__(kBlock) void ts_join_build_kernel(
     if (len > max_len) {
         // max_query_len was not an upper bound (the table is sized from it): nothing of this
         // query is inserted and its counter is poisoned instead (stays negative)
-        if (i == 0) hits_n[q] = INT32_MIN;
+        if (i == 0) hits_n[(size_t)q * ns] = INT32_MIN;
         return;
     }
     if (i >= (int)len) return;
     int64_t k;
     if (!canon_key(queries[o + i], k)) return;                     // NaN never matches
-    const uint32_t smask = (1u << s_log2) - 1u;
-    const size_t tb = (size_t)(q / kJoinQ) << s_log2;
-    const uint32_t hv = hash32(k);
-    const uint32_t bit = hv & (uint32_t)(kJoinBloomBits - 1);      // presence bit (low hash bits)
-    atomicOr(&tbloom[(size_t)(q / kJoinQ) * (kJoinBloomBits / 32) + (bit >> 5)], 1u << (bit & 31));
-    uint32_t h = (hv >> (32 - s_log2)) & ~1u;                      // home pair (high hash bits)
-    while (true) {
-        const unsigned long long old = atomicCAS(&tkeys[tb + h], (unsigned long long)kJEmpty,
-                                                 (unsigned long long)k);
-        if (old == (unsigned long long)kJEmpty) break;             // claimed a free slot
-        h = (h + 1) & smask;
+    const int tile = q / q_per_tile;
+    uint32_t *tb = table + ((size_t)tile << s_log2);
+    const uint32_t bmask = (1u << (s_log2 - 2)) - 1u;
+    uint32_t b, fp;
+    join_hash(k, s_log2, b, fp);
+    const uint32_t entry = (fp << 22) | ((uint32_t)(q - tile * q_per_tile) << 12) | (uint32_t)i;
+    while (true) {                                                 // first free slot from the home bucket on
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (atomicCAS(&tb[b * 4 + j], kJFree, entry) == kJFree) return;
+        b = (b + 1) & bmask;
     }
-    tpack[tb + h] = (uint32_t)i | ((uint32_t)(q % kJoinQ) << 12);
 }
 
 __global__ __launch_bounds__(kJoinBlock) void ts_match_join_kernel(
     const Row *__restrict__ rows, int64_t n_rows, const int64_t *__restrict__ keys,
-    const int64_t *__restrict__ tkeys, const uint32_t *__restrict__ tpack,
-    const uint32_t *__restrict__ tbloom, int32_t s_log2, int32_t Q, int32_t n_tiles, int32_t n_chunks,
+    const double *__restrict__ queries, const int64_t *__restrict__ q_offsets,
+    const uint32_t *__restrict__ table, int32_t s_log2, int32_t Q, int32_t q_per_tile,
     int32_t min_match, const int32_t *__restrict__ exclude_ids, int32_t cap,
-    int32_t *__restrict__ hits, int32_t *__restrict__ hits_n, int32_t rows_per_block) {
+    int32_t *__restrict__ hits, int32_t *__restrict__ hits_n, int32_t ns) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    uint32_t *m1_all = reinterpret_cast<uint32_t *>(smem);                     // [groups][128] smallest pos
-    uint32_t *m2_all = m1_all + kJoinGroups * kJoinQ;                          // [groups][128] 2nd smallest
-    uint32_t *cnt_all = m2_all + kJoinGroups * kJoinQ;                         // [groups][64] 2 x u16
-    uint32_t *bloom = cnt_all + kJoinGroups * (kJoinQ / 2);                    // [2^19 bits]
-    // block -> (tile, chunk): blocks of one tile share blockIdx % 8, i.e. (observed) one XCD and its L2
-    const int b = blockIdx.x;
-    int tile, chunk;
-    if (8 % n_tiles == 0) {
-        const int g = 8 / n_tiles;                                             // XCDs per tile
-        tile = (b % 8) / g;
-        chunk = (b / 8) * g + (b % 8) % g;
-    } else if (n_tiles % 8 == 0) {
-        tile = (b % 8) + 8 * ((b / 8) % (n_tiles / 8));
-        chunk = (b / 8) / (n_tiles / 8);
-    } else {
-        tile = b / n_chunks;
-        chunk = b % n_chunks;
-    }
-    if (tile >= n_tiles || chunk >= n_chunks) return;
-    const int gl = threadIdx.x & (kGroup - 1);
-    const int g = threadIdx.x / kGroup;
-    uint32_t *m1 = m1_all + g * kJoinQ;
-    uint32_t *m2 = m2_all + g * kJoinQ;
-    uint32_t *cntw = cnt_all + g * (kJoinQ / 2);
-    for (int i = gl; i < kJoinQ; i += kGroup) { m1[i] = 0xffffffffu; m2[i] = 0xffffffffu; }
-    {   // the tile's presence bitmap: 64 KiB copied from device memory into LDS once per block
-        const uint4 *src = reinterpret_cast<const uint4 *>(tbloom + (size_t)tile * (kJoinBloomBits / 32));
-        uint4 *dst = reinterpret_cast<uint4 *>(bloom);
-        for (int i = threadIdx.x; i < kJoinBloomBits / 128; i += kJoinBlock) dst[i] = src[i];
-    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t *w0 = reinterpret_cast<uint32_t *>(smem) + wave * kJoinSlots;                     // (q+1) << 20 | count
+    uint32_t *m1 = reinterpret_cast<uint32_t *>(smem) + (kJoinWaves + wave) * kJoinSlots;      // smallest position
+    uint32_t *m2 = reinterpret_cast<uint32_t *>(smem) + (2 * kJoinWaves + wave) * kJoinSlots;  // second smallest
+    uint32_t *rslot = reinterpret_cast<uint32_t *>(smem + (size_t)kJoinWaves * kJoinSlots * 12) + wave * kJoinRing;
+    uint32_t *rkidx = reinterpret_cast<uint32_t *>(smem + (size_t)kJoinWaves * kJoinSlots * 12) +
+                      (kJoinWaves + wave) * kJoinRing;
+    uint32_t *ovf = reinterpret_cast<uint32_t *>(smem + (size_t)kJoinWaves * kJoinSlots * 12 +
+                                                 (size_t)kJoinWaves * kJoinRing * 8) + wave;
+    int64_t *s_qoff = reinterpret_cast<int64_t *>(smem + (size_t)kJoinWaves * kJoinSlots * 12 +
+                                                  (size_t)kJoinWaves * kJoinRing * 8 + kJoinWaves * 4);
+    const int tile = blockIdx.y;
+    const int q0 = tile * q_per_tile;
+    const int nq = (Q - q0 < q_per_tile) ? Q - q0 : q_per_tile;
+    for (int i = threadIdx.x; i <= nq; i += kJoinBlock) s_qoff[i] = q_offsets[q0 + i];
+    for (int i = lane; i < kJoinSlots; i += 64) { w0[i] = 0; m1[i] = 0xffffffffu; m2[i] = 0xffffffffu; }
+    if (lane == 0) *ovf = 0;
     __syncthreads();
-    for (int i = gl; i < kJoinQ / 2; i += kGroup) cntw[i] = 0;
-    const int q0 = tile * kJoinQ;
-    const uint32_t smask = (1u << s_log2) - 1u;
-    const int64_t *tk = tkeys + ((size_t)tile << s_log2);
-    const uint32_t *tp = tpack + ((size_t)tile << s_log2);
-    const int64_t r0 = (int64_t)chunk * rows_per_block;
-    int64_t r1 = r0 + rows_per_block;
-    if (r1 > n_rows) r1 = n_rows;
+    const uint32_t bmask = (1u << (s_log2 - 2)) - 1u;
+    const uint4 *tb = reinterpret_cast<const uint4 *>(table + ((size_t)tile << s_log2));
+    const int64_t n_waves = (int64_t)gridDim.x * kJoinWaves;
+    uint32_t qhead = 0, qtail = 0;                                    // wave-uniform ring cursors
 
-    auto account = [&](uint32_t pk) {                    // one matching (query, position) entry
-        const uint32_t ql = pk >> 12, pos = pk & 0xfffu;
-        atomicAdd(&cntw[ql >> 1], 1u << (16 * (ql & 1)));
-        const uint32_t old = atomicMin(&m1[ql], pos);    // two plain LDS atomics, no CAS loop
-        atomicMin(&m2[ql], old > pos ? old : pos);       // larger of two distinct hits >= 2nd smallest
-    };
-
-    constexpr int kK = 4;                                // keys per lane and step: 8 table loads in flight
-    for (int64_t r = r0 + g; r < r1; r += kJoinGroups) {
+    for (int64_t r = (int64_t)blockIdx.x * kJoinWaves + wave; r < n_rows; r += n_waves) {
         const Row row = load_row(rows + r);
         const int64_t *rk = keys + row.off;
-        for (int i0 = gl * 2; i0 < row.len; i0 += kGroup * kK) {
-            int64_t kk[kK];
-            bool valid[kK];
-#pragma unroll
-            for (int j = 0; j < kK / 2; ++j) {
-                const int i = i0 + j * kGroup * 2;
-                longlong2 v = make_longlong2(0, 0);
-                if (i < row.len) v = *reinterpret_cast<const longlong2 *>(rk + i);
-                kk[2 * j] = v.x;
-                kk[2 * j + 1] = v.y;
-                valid[2 * j] = i < row.len;
-                valid[2 * j + 1] = i + 1 < row.len;
+        int part = -1;                                                // -1: every query of the tile
+        // one verified (query, position) match; part >= 0 restricts to queries with (q & 3) == part
+        auto account = [&](uint32_t ql, uint32_t pos) {
+            if (part >= 0 && (int)(ql & 3u) != part) return;
+            const uint32_t tag = (ql + 1u) << 20;
+            uint32_t s = (ql * 157u) & (uint32_t)(kJoinSlots - 1);
+            for (int tries = 0;; ++tries) {
+                const uint32_t old = atomicCAS(&w0[s], 0u, tag);
+                if (old == 0u || (old >> 20) == ql + 1u) break;       // claimed, or this query's slot
+                if (tries == kJoinSlots) { *ovf = 1u; return; }        // > 256 distinct queries: redo the row
+                s = (s + 1) & (uint32_t)(kJoinSlots - 1);
             }
-            uint32_t h[kK];
-            longlong2 sk[kK];
-#pragma unroll
-            for (int j = 0; j < kK; ++j) {               // independent L2 reads, all in flight
-                // LDS presence filter first: a random probe of the table costs a whole L2 line,
-                // and ~70 % of the corpus keys are in no query of the tile
-                const uint32_t hv = hash32(kk[j]);
-                const uint32_t bit = hv & (uint32_t)(kJoinBloomBits - 1);
-                h[j] = (hv >> (32 - s_log2)) & ~1u;
-                sk[j] = make_longlong2(kJEmpty, kJEmpty);
-                if (valid[j] && ((bloom[bit >> 5] >> (bit & 31)) & 1u))
-                    sk[j] = *reinterpret_cast<const longlong2 *>(tk + h[j]);
+            atomicAdd(&w0[s], 1u);
+            const uint32_t o = atomicMin(&m1[s], pos);                // two plain LDS atomics, no CAS loop
+            atomicMin(&m2[s], o > pos ? o : pos);                     // larger of two distinct hits >= 2nd smallest
+        };
+        // n <= 64 pending candidates: every lane takes one - exact compare against the query
+        // element itself, then the accounting
+        auto drain = [&](uint32_t n) {
+            wave_lds_fence();
+            if ((uint32_t)lane < n) {
+                const uint32_t idx = (qhead + lane) & (uint32_t)(kJoinRing - 1);
+                const uint32_t slot = rslot[idx];
+                const int64_t k = rk[rkidx[idx]];
+                const uint32_t ql = (slot >> 12) & 0x3ffu, pos = slot & 0xfffu;
+                int64_t qk;
+                if (canon_key(queries[s_qoff[ql] + pos], qk) && qk == k) account(ql, pos);
             }
-#pragma unroll
-            for (int j = 0; j < kK; ++j) {
-                if (!valid[j]) continue;
-                if (sk[j].x == kk[j]) account(tp[h[j]]);
-                if (sk[j].x == kJEmpty) continue;
-                if (sk[j].y == kk[j]) account(tp[h[j] + 1]);
-                if (sk[j].y == kJEmpty) continue;
-                uint32_t hh = h[j];                      // home pair full: keep walking (rare)
-                while (true) {
-                    hh = (hh + 2) & smask;
-                    const longlong2 a = *reinterpret_cast<const longlong2 *>(tk + hh);
-                    if (a.x == kk[j]) account(tp[hh]);
-                    if (a.x == kJEmpty) break;
-                    if (a.y == kk[j]) account(tp[hh + 1]);
-                    if (a.y == kJEmpty) break;
+            qhead += n;
+        };
+        auto push = [&](bool cand, uint32_t slot, uint32_t ki) {
+            const unsigned long long bal = __ballot(cand);
+            if (bal) {                                                // wave-uniform
+                const uint32_t ofs = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32),
+                                     __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+                if (cand) {
+                    const uint32_t idx = (qtail + ofs) & (uint32_t)(kJoinRing - 1);
+                    rslot[idx] = slot;
+                    rkidx[idx] = ki;
+                }
+                qtail += (uint32_t)__popcll(bal);
+                if (qtail - qhead >= 64u) drain(64u);
+            }
+        };
+        // fingerprint stage of one key: candidates of its home bucket (and of the following ones
+        // while they are full) go to the ring
+        auto probe = [&](bool valid, uint32_t ki, uint32_t b, uint32_t fp, uint4 bk) {
+            bool more = valid;
+            while (true) {
+                push(more && (bk.x >> 22) == fp && bk.x != kJFree, bk.x, ki);
+                push(more && (bk.y >> 22) == fp && bk.y != kJFree, bk.y, ki);
+                push(more && (bk.z >> 22) == fp && bk.z != kJFree, bk.z, ki);
+                push(more && (bk.w >> 22) == fp && bk.w != kJFree, bk.w, ki);
+                more = more && bk.x != kJFree && bk.y != kJFree && bk.z != kJFree && bk.w != kJFree;
+                if (__ballot(more) == 0ull) break;                     // wave-uniform; a full bucket is rare
+                if (more) {
+                    b = (b + 1) & bmask;
+                    bk = tb[b];
                 }
             }
-        }
-        // lane gl owns queries gl*8 .. gl*8+7 of the tile (4 counter words of 2 x u16)
-        wave_lds_fence();
-        const uint4 cw = *reinterpret_cast<const uint4 *>(cntw + gl * 4);
-        if ((cw.x | cw.y | cw.z | cw.w) == 0 && min_match > 0) continue;      // nothing matched
-        const uint32_t w[4] = {cw.x, cw.y, cw.z, cw.w};
-        uint32_t todo = 0;                               // bit j: query gl*8+j reaches min_match
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int c = (int)((w[j >> 1] >> (16 * (j & 1))) & 0xffffu);
-            todo |= (uint32_t)(c >= min_match && q0 + gl * 8 + j < Q) << j;
-        }
-        while (todo) {                                   // usually 0 or 1 iterations
-            const int j = __ffs(todo) - 1;
-            todo &= todo - 1;
-            const int ql = gl * 8 + j;
-            const int q = q0 + ql;
-            const uint32_t c = (w[j >> 1] >> (16 * (j & 1))) & 0xffffu;
-            if (!(exclude_ids && exclude_ids[q] == row.vid)) {
-                const int32_t kth = min_match <= 0 ? -1 : (int32_t)(min_match == 1 ? m1[ql] : m2[ql]);
-                const int slot = atomicAdd(&hits_n[q], 1);
-                if (slot < cap) {
-                    int32_t *hp = hits + ((int64_t)q * cap + slot) * 3;
-                    hp[0] = row.vid;
-                    hp[1] = (int32_t)c;
-                    hp[2] = kth;
-                }
+        };
+        while (true) {
+            for (int base = 0; base < row.len; base += 256) {
+                // 2 x 16-byte loads per lane = 4 keys; unconditional (clamped) loads keep them all in flight
+                const int i0 = base + lane * 2, i1 = i0 + 128;
+                const longlong2 v0 = *reinterpret_cast<const longlong2 *>((i0 < row.len) ? rk + i0 : keys);
+                const longlong2 v1 = *reinterpret_cast<const longlong2 *>((i1 < row.len) ? rk + i1 : keys);
+                uint32_t b0, b1, b2, b3, f0, f1, f2, f3;
+                join_hash(v0.x, s_log2, b0, f0);
+                join_hash(v0.y, s_log2, b1, f1);
+                join_hash(v1.x, s_log2, b2, f2);
+                join_hash(v1.y, s_log2, b3, f3);
+                const uint4 k0 = tb[b0], k1 = tb[b1], k2 = tb[b2], k3 = tb[b3];   // independent, all in flight
+                probe(i0 < row.len, (uint32_t)i0, b0, f0, k0);
+                probe(i0 + 1 < row.len, (uint32_t)i0 + 1u, b1, f1, k1);
+                probe(i1 < row.len, (uint32_t)i1, b2, f2, k2);
+                probe(i1 + 1 < row.len, (uint32_t)i1 + 1u, b3, f3, k3);
             }
+            while (qtail != qhead) drain(qtail - qhead < 64u ? qtail - qhead : 64u);   // row boundary: settle
+            wave_lds_fence();
+            const bool overflow = *ovf != 0u;
+            // every lane owns 4 slots: emit the (query, row) pairs that reached min_match, reset all
+            const uint4 cw = *reinterpret_cast<const uint4 *>(w0 + lane * 4);
+            if (!overflow && (cw.x | cw.y | cw.z | cw.w)) {
+                const uint4 a1 = *reinterpret_cast<const uint4 *>(m1 + lane * 4);
+                const uint4 a2 = *reinterpret_cast<const uint4 *>(m2 + lane * 4);
+                auto emit = [&](uint32_t wv, uint32_t p1, uint32_t p2) {
+                    if (!wv) return;
+                    const int c = (int)(wv & 0xfffffu);
+                    const int q = q0 + (int)(wv >> 20) - 1;
+                    if (c < min_match || q >= Q) return;
+                    if (exclude_ids && exclude_ids[q] == row.vid) return;
+                    const int32_t kth = (int32_t)(min_match == 1 ? p1 : p2);
+                    const int slot = atomicAdd(&hits_n[(size_t)q * ns], 1);
+                    if (slot < cap) {
+                        int32_t *hp = hits + ((int64_t)q * cap + slot) * 3;
+                        hp[0] = row.vid;
+                        hp[1] = c;
+                        hp[2] = kth;
+                    }
+                };
+                emit(cw.x, a1.x, a2.x);
+                emit(cw.y, a1.y, a2.y);
+                emit(cw.z, a1.z, a2.z);
+                emit(cw.w, a1.w, a2.w);
+            }
+            const uint4 ones = make_uint4(0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu);
+            *reinterpret_cast<uint4 *>(w0 + lane * 4) = make_uint4(0, 0, 0, 0);
+            *reinterpret_cast<uint4 *>(m1 + lane * 4) = ones;
+            *reinterpret_cast<uint4 *>(m2 + lane * 4) = ones;
+            if (lane == 0) *ovf = 0;
+            wave_lds_fence();
+            if (overflow && part < 0) { part = 0; continue; }          // redo in 4 passes of <= 256 queries
+            if (part >= 0 && part < 3) { ++part; continue; }
+            break;
         }
-        // unconditional reset of this lane's 8 queries: 5 wide LDS stores, no per-query branches
-        const uint4 ones = make_uint4(0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu);
-        *reinterpret_cast<uint4 *>(cntw + gl * 4) = make_uint4(0, 0, 0, 0);
-        *reinterpret_cast<uint4 *>(m1 + gl * 8) = ones;
-        *reinterpret_cast<uint4 *>(m1 + gl * 8 + 4) = ones;
-        *reinterpret_cast<uint4 *>(m2 + gl * 8) = ones;
-        *reinterpret_cast<uint4 *>(m2 + gl * 8 + 4) = ones;
-        wave_lds_fence();
     }
 }
 
@@ -611,12 +636,12 @@ __global__ __launch_bounds__(kBlock) void ts_match_longq_kernel(
 __global__ __launch_bounds__(kBlock) void ts_kth_fixup_kernel(
     const Row *__restrict__ rows, const int64_t *__restrict__ keys,
     const double *__restrict__ queries, const int64_t *__restrict__ q_offsets, int32_t min_match,
-    int32_t cap, int32_t *__restrict__ hits, const int32_t *__restrict__ hits_n) {
+    int32_t cap, int32_t *__restrict__ hits, const int32_t *__restrict__ hits_n, int32_t ns) {
     const int q = blockIdx.x;
     const int gl = threadIdx.x & (kGroup - 1);
     const int g = threadIdx.x / kGroup;
     const int gshift = (threadIdx.x & 63) & ~(kGroup - 1);
-    int n = hits_n[q];
+    int n = hits_n[(size_t)q * ns];
     if (n > cap) n = cap;
     const int64_t qo = q_offsets[q];
     const int32_t qlen = (int32_t)(q_offsets[q + 1] - qo);
@@ -900,7 +925,7 @@ __global__ __launch_bounds__(kQ1Block) void ts_match_q1_kernel(
     const Row *__restrict__ rows, int64_t n_rows, const int64_t *__restrict__ keys,
     const double *__restrict__ queries, const int64_t *__restrict__ q_offsets, int32_t min_match,
     const int32_t *__restrict__ exclude_ids, int32_t exclude_one, int32_t cap,
-    int32_t *__restrict__ hits, int32_t *__restrict__ hits_n, int32_t s_log2, HostOut ho,
+    int32_t *__restrict__ hits, int32_t *__restrict__ hits_n, int32_t ns, int32_t s_log2, HostOut ho,
     const QByVal qv) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int S = 1 << s_log2;
@@ -916,7 +941,7 @@ __global__ __launch_bounds__(kQ1Block) void ts_match_q1_kernel(
     if (threadIdx.x == 0) { s_nhits = 0; s_dups = 0; }
     if (2 * n > S) {
         // the caller's max_query_len was not an upper bound (the tables are sized from it)
-        if (!HOSTOUT && threadIdx.x == 0) hits_n[q] = INT32_MIN;
+        if (!HOSTOUT && threadIdx.x == 0) hits_n[(size_t)q * ns] = INT32_MIN;
         if (HOSTOUT && threadIdx.x == 0) ho.counts[blockIdx.x] = INT32_MIN;
         return;
     }
@@ -1065,7 +1090,7 @@ __global__ __launch_bounds__(kQ1Block) void ts_match_q1_kernel(
                     h[1] = (int32_t)cnt;
                     h[2] = kth;
                 } else {
-                    const int slot = atomicAdd(&hits_n[q], 1);
+                    const int slot = atomicAdd(&hits_n[(size_t)q * ns], 1);
                     if (slot < cap) {
                         int32_t *h = hits + ((int64_t)q * cap + slot) * 3;
                         h[0] = row.vid;
@@ -1102,15 +1127,15 @@ __device__ __forceinline__ int sel_bin(int32_t kth) {
 }
 
 __global__ __launch_bounds__(kBlock) void ts_topk_select_kernel(
-    const int32_t *__restrict__ lists, const int32_t *__restrict__ lists_n, int32_t Q, int32_t cap,
-    int32_t k, int32_t *__restrict__ topk, int32_t mode) {
+    const int32_t *__restrict__ lists, const int32_t *__restrict__ lists_n, int32_t ns, int32_t Q,
+    int32_t cap, int32_t k, int32_t *__restrict__ topk, int32_t mode) {
     __shared__ uint64_t key[kSortCap];
     __shared__ int32_t cnt[kSortCap];
     __shared__ uint32_t hist[kSelBins];
     __shared__ uint32_t part[kBlock];
     __shared__ int32_t s_pos, s_bin;
     const int q = blockIdx.x;
-    const int32_t total = lists_n ? lists_n[q] : cap;
+    const int32_t total = lists_n ? lists_n[(size_t)q * ns] : cap;
     const bool overflow = total > cap;
     const int n = total > cap ? cap : (total < 0 ? 0 : total);
     const int32_t *src = lists + (int64_t)q * cap * 3;
@@ -1194,13 +1219,24 @@ __global__ __launch_bounds__(kBlock) void ts_topk_select_kernel(
 
 // ---- small helpers launched around the sweeps ------------------------------------------------
 // hit counters = 0, hash-join key tables = 0xff.. (kJEmpty), presence bitmaps = 0: one launch
-__global__ __launch_bounds__(kBlock) void ts_prep_kernel(int32_t *__restrict__ hits_n, int32_t Q,
+__global__ __launch_bounds__(kBlock) void ts_prep_kernel(int32_t *__restrict__ hits_n, int32_t ns, int32_t Q,
                                                          uint4 *__restrict__ ones16, size_t n_ones16,
                                                          uint4 *__restrict__ zero16, size_t n_zero16) {
     const size_t i0 = (size_t)blockIdx.x * kBlock + threadIdx.x, step = (size_t)gridDim.x * kBlock;
-    for (size_t i = i0; i < (size_t)Q; i += step) hits_n[i] = 0;
+    for (size_t i = i0; i < (size_t)Q; i += step) hits_n[i * ns] = 0;
     for (size_t i = i0; i < n_ones16; i += step) ones16[i] = make_uint4(~0u, ~0u, ~0u, ~0u);
     for (size_t i = i0; i < n_zero16; i += step) zero16[i] = make_uint4(0, 0, 0, 0);
+}
+
+// Hit counters live one per 128-byte line while the sweeps append (kCountStride int32 apart): a
+// returning atomic is serialised per cache LINE at the memory side, and 1024 adjacent int32
+// counters are 32 lines - with 2 M hits per batch that alone was ~1 ms, whatever the sweep did
+// (profiles/r2c_match_pmc.txt).  This copies them to the caller's dense array afterwards.
+constexpr int kCountStride = 32;
+__global__ __launch_bounds__(kBlock) void ts_counts_gather_kernel(const int32_t *__restrict__ padded, int32_t ns,
+                                                                  int32_t *__restrict__ dense, int32_t Q) {
+    const int q = blockIdx.x * kBlock + threadIdx.x;
+    if (q < Q) dense[q] = padded[(size_t)q * ns];
 }
 
 // upsert: the row entry is swapped by ONE 16-byte store, ordered on the mutation stream behind
