@@ -179,10 +179,11 @@ int tvz_corpus_stats(tvz_corpus *c, int64_t *n_rows, int64_t *n_keys, int64_t *a
  * ------------------------------------------------------------------------ */
 
 /* Which kernel sweeps the corpus, PER CALL (there is no global knob); results never depend on it.
- *   AUTO : Q <= 8 -> Q1; large batches with min_match <= 2 -> JOIN; else TILE
+ *   AUTO : one query (or <= 4 against a small corpus) -> Q1; >= 64 queries x >= 3 M pairs with
+ *          min_match 1..2 -> JOIN; else TILE
  *   Q1   : one corpus sweep per query, the query's keys in a small LDS table, per-lane counters
  *   TILE : one LDS hash table per tile of <= 16 queries
- *   JOIN : device-memory hash join per tile of 128 queries (min_match <= 2 only) */
+ *   JOIN : device-memory hash join per tile of <= 1024 queries (min_match 1..2; other values take TILE) */
 #define TVZ_ALGO_AUTO 0
 #define TVZ_ALGO_Q1 1
 #define TVZ_ALGO_TILE 2

@@ -348,17 +348,21 @@ WsLayout ws_layout(void *base, int32_t Q, int32_t max_query_len, int32_t cap, in
     return w;
 }
 
-// Dispatch (A/B grids under profiles/): the per-query sweep wins for a handful of queries (each
-// streams the corpus once, no shared table to build); the hash join wins once its fixed cost
-// (table clear + build) is amortised; the LDS tile in between and for min_match > 2.
-constexpr int kQ1MaxQ = 8;
+// Dispatch, from the A/B grid profiles/r2_match_ab.txt (C in 5k..100k x Q in 16..1024): the
+// per-query sweep only for a lone query (each query streams the corpus once; from a handful of
+// queries on, sharing one LDS table per 16 wins); the hash join once its fixed cost (2 MiB table
+// clear + build, ~40 us) is amortised - from about 3 M (query, row) pairs at 64+ queries it is
+// 1.1x (C=50k x Q=64) to 4.6x (C=100k x Q=1024) faster than the LDS tile; the tile in between and
+// for min_match outside 1..2.
+constexpr int kQ1MaxQ = 1;
+constexpr int kQ1SmallRows = 20000;       // up to 4 queries also sweep one by one below this
 constexpr int kJoinMinQ = 64;
-constexpr int64_t kJoinMinPairs = 5000000;
+constexpr int64_t kJoinMinPairs = 3000000;
 
 int pick_algo(int32_t algo, int32_t Q, int64_t n_rows, int32_t max_query_len, int32_t min_match) {
     const bool join_legal = min_match >= 1 && min_match <= 2 && max_query_len > 0;
     if (algo == TVZ_ALGO_AUTO) {
-        if (Q <= kQ1MaxQ) return TVZ_ALGO_Q1;
+        if (Q <= kQ1MaxQ || (Q <= 4 && n_rows <= kQ1SmallRows)) return TVZ_ALGO_Q1;
         if (join_legal && Q >= kJoinMinQ && (int64_t)Q * n_rows >= kJoinMinPairs) return TVZ_ALGO_JOIN;
         return TVZ_ALGO_TILE;
     }

@@ -430,15 +430,24 @@ __global__ __launch_bounds__(kBlock) void ts_join_build_kernel(
     uint32_t b, fp;
     join_hash(k, s_log2, b, fp);
     const uint32_t entry = (fp << 22) | ((uint32_t)(q - tile * q_per_tile) << 12) | (uint32_t)i;
-    while (true) {                                                 // first free slot from the home bucket on
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-            if (atomicCAS(&tb[b * 4 + j], kJFree, entry) == kJFree) return;
-        b = (b + 1) & bmask;
+    // first free slot from the home bucket on: look, then claim it.  The look may be stale (this
+    // CU's L1), but slots only ever go from free to taken, so a stale view can only offer a slot
+    // that is gone - the failed CAS returns what is there and corrects the view.
+    uint4 bk = *reinterpret_cast<const uint4 *>(tb + b * 4);
+    while (true) {
+        const int j = bk.x == kJFree ? 0 : bk.y == kJFree ? 1 : bk.z == kJFree ? 2 : bk.w == kJFree ? 3 : 4;
+        if (j == 4) {                                              // bucket full: next one
+            b = (b + 1) & bmask;
+            bk = *reinterpret_cast<const uint4 *>(tb + b * 4);
+            continue;
+        }
+        const uint32_t old = atomicCAS(&tb[b * 4 + j], kJFree, entry);
+        if (old == kJFree) return;
+        if (j == 0) bk.x = old; else if (j == 1) bk.y = old; else if (j == 2) bk.z = old; else bk.w = old;
     }
 }
 
-__global__ __launch_bounds__(kJoinBlock) void ts_match_join_kernel(
+__global__ __launch_bounds__(kJoinBlock, 8) void ts_match_join_kernel(
     const Row *__restrict__ rows, int64_t n_rows, const int64_t *__restrict__ keys,
     const double *__restrict__ queries, const int64_t *__restrict__ q_offsets,
     const uint32_t *__restrict__ table, int32_t s_log2, int32_t Q, int32_t q_per_tile,
