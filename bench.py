@@ -51,7 +51,9 @@ def parse():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--frames", type=int, default=10000, help="1080p frames per GPU per step")
     ap.add_argument("--corpus", type=int, default=100000, help="corpus videos, sharded over the ranks (configs[3])")
-    ap.add_argument("--queries", type=int, default=1024, help="query videos per match batch")
+    ap.add_argument("--queries", type=int, default=4096,
+                    help="query videos per match batch (sized so that a 1/8 shard is still well above the fixed "
+                         "per-batch cost: DESIGN.md 5, profiles/r2_predicted_scaling.json)")
     ap.add_argument("--match-steps", type=int, default=20)
     ap.add_argument("--no-match", action="store_true")
     ap.add_argument("--no-cpu", action="store_true")
@@ -269,8 +271,9 @@ def bench_match(args, rank, world, dev):
                                           workspace=ws), st)
     shard_rows, shard_keys, _ = dc.stats()
     corpus_bytes = 16.0 * shard_rows + 8.0 * shard_keys
-    n_tiles = -(-Q // 128)
-    lat = [0.0]
+    # tvz_match.hip join_shape(): tiles of <= 1024 queries whose elements fit a 2 MiB table at load 0.55
+    q_per_tile = max(1, min(1024, int(0.55 * (1 << 19)) // max(max_len, 1), Q))
+    n_tiles = -(-Q // q_per_tile)
     if comm is not None:
         comm.close()
     out = {"value": pairs / wall, "unit": "pairs/s", "corpus_videos": C, "queries_per_batch": Q,
@@ -282,23 +285,26 @@ def bench_match(args, rank, world, dev):
            "hit_list_capacity": CAP, "queries_with_overflowed_shard_lists": n_over,
            "scaling": "strong (the same corpus is sharded over the ranks)",
            "sweep_ms_per_batch_rank0": sweep_ms,
-           "fixed_ms_per_batch": max(wall * 1e3 / args.match_steps - sweep_ms, 0.0)}
-    traffic = pmc_traffic("ts_match_join", tag=f"C{C}_Q{Q}") if world == 1 else None
+           "predicted_scaling": "profiles/r2_predicted_scaling.json (single-GPU shard timings)"}
+    tag = f"C{C}_Q{Q}"
+    traffic = pmc_traffic("ts_match_join", tag=tag) if world == 1 else None
     alg = corpus_bytes * n_tiles + mean_hits * Q * 12
     out["roofline"] = {
-        "bound": "hbm", "kernel": f"ts_match_join_kernel ({n_tiles} tiles of 128 queries; the event pair also covers "
-                                  "ts_prep + ts_join_build, < 4 % of it)",
+        "bound": "hbm",
+        "kernel": f"ts_match_join_kernel: {n_tiles} corpus sweep(s), one per tile of <= {q_per_tile} queries (the event "
+                  "pair also covers ts_prep + ts_join_build + the counter gather, < 10 % of it)",
         "achieved": alg / (sweep_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": alg / (sweep_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
-        "algorithmic_bytes_per_launch": alg,
-        "note": "algorithmic bytes = this rank's corpus image (16 B row entry + 8 B per key) streamed once per "
-                "128-query tile + the hit triples written; `traffic` = FETCH_SIZE x2 + WRITE_SIZE of the committed "
-                "PMC pass (the image fits the 256 MB Infinity Cache, so much of the stream never reaches HBM). The "
-                "sweep is bound by LDS/L2 probe issue, not by HBM: see DESIGN.md 4.3 and profiles/r2_match_pmc.txt"}
+        "algorithmic_bytes_per_launch": alg, "avg_launch_ms": sweep_ms,
+        "limiter": "not HBM: the sweep streams this rank's corpus image once per tile (16 B row entry + 8 B per key) and "
+                   "is bound by wave-instruction issue and L2-hit probe latency of the 2 MiB fingerprint table "
+                   "(profiles/r2_match_pmc.txt: ~240 M wave-instructions per 1024-query sweep of 100k rows, L2 hit "
+                   "78 %, 66 % of wave-cycles waiting); `traffic` is FETCH_SIZE x2 + WRITE_SIZE of the committed PMC "
+                   "pass for this workload tag (" + tag + ") and includes Infinity-Cache hits"}
     out["nominal_hbm_equiv"] = {"GBps_per_gpu": pairs * bytes_per_pair / wall / 1e9 / world,
                                 "x_hbm_peak": pairs * bytes_per_pair / wall / 1e9 / world / HBM_PEAK_GBS,
                                 "note": "SURVEY 8d nominal 8*L+8 B per (query,row) pair; not a roofline: one probe of a "
-                                        "corpus key serves a whole tile of queries"}
+                                        "corpus key serves a whole tile of up to 1024 queries"}
     dc.close()
     # configs[2]: ONE query vs a 5k-video corpus on one GPU (+ the batch-size sweep SURVEY 8d asks for)
     if rank == 0 and world == 1:
@@ -333,12 +339,22 @@ def bench_match_q1(args, dev, Q):
             dc5.find_duplicates(q5[i % len(q5)], 2)
             lat.append(time.perf_counter() - t)
         q1_ms = by_q["1"]["kernel_ms"]
-        entry = {"kernel_by_batch_size": by_q,
+        # the same sweep with min_match 5 (the reference's default: a handful of hits instead of the
+        # thousands of accidental min_match=2 collisions, each a serialised append to one hit list)
+        dq, do, ml = tc.pack_queries(q5[:1], dev)
+        hits = torch.empty((1, 4096, 3), dtype=torch.int32, device=dev)
+        n_h = torch.empty(1, dtype=torch.int32, device=dev)
+        ws = torch.empty(tc.workspace_bytes(1, ml), dtype=torch.uint8, device=dev)
+        q1_mm5 = kernel_ms(lambda: dc5.match(dq, do, ml, 5, 4096, out_hits=hits, out_n=n_h, stream=st, workspace=ws),
+                           st, reps=24, skip=4)
+        entry = {"kernel_by_batch_size": by_q, "q1_kernel_ms_min_match5": round(q1_mm5, 4),
                  "find_duplicates_latency_us": round(float(np.median(lat[10:])) * 1e6, 1),
-                 "roofline_q1": {"bound": "hbm", "kernel": "ts_match_q1_kernel (one query, whole corpus image streamed once)",
+                 "roofline_q1": {"bound": "hbm", "kernel": "ts_match_q1_kernel (one query, whole corpus image streamed "
+                                                           "once; event pair also covers ts_prep + the counter gather)",
                                  "algorithmic_bytes_per_launch": image,
                                  "achieved": image / (q1_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                  "frac": image / (q1_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                 "frac_min_match5": image / (q1_mm5 * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                  "traffic": pmc_traffic("ts_match_q1", tag=f"C{C5}_Q1")}}
         if C5 == 5000 and not args.no_cpu:
             entry["cpu_baseline"] = cpu_baseline_match(ids5, offs5, keys5, q5)

@@ -2,11 +2,12 @@
 """Matcher workloads for rocprofv3 passes (kernel trace or PMC), one process per workload so a
 counter row can be attributed by kernel name alone:
    python3 profiles/match_workloads.py <workload> [reps]
-     join   : C=100k x Q=1024, min_match 2   -> ts_match_join_kernel (+ prep, build)   tag C100000_Q1024
+     join   : C=100k x Q=4096, min_match 2   -> ts_match_join_kernel (+ prep, build)   tag C100000_Q4096
      q1_100k: C=100k x Q=1                    -> ts_match_q1_kernel                     tag C100000_Q1
      q1_5k  : C=5k   x Q=1 + find_duplicates  -> ts_match_q1_kernel (both output modes) tag C5000_Q1
      tile   : C=100k x Q=64, min_match 2, forced LDS tile kernel                       tag C100000_Q64
-     topk   : C=100k x Q=1024 match_topk (sweep + select top-k)                        tag C100000_Q1024
+     topk   : C=100k x Q=4096 match_topk (sweep + select top-k) + merge                tag C100000_Q4096
+     shard8 : rank 0's 1/8 shard (12.5k rows) x Q=4096, match_topk + merge              tag C12500_Q4096
 Prints one JSON line with the event-timed median of the call."""
 import json
 import os
@@ -23,23 +24,29 @@ which = sys.argv[1] if len(sys.argv) > 1 else "join"
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 12
 MM = int(sys.argv[3]) if len(sys.argv) > 3 else 2
 dev = torch.device("cuda:0")
-C, Q, algo = {"join": (100000, 1024, _lib.ALGO_JOIN), "q1_100k": (100000, 1, _lib.ALGO_Q1),
+C, Q, algo = {"join": (100000, 4096, _lib.ALGO_JOIN), "q1_100k": (100000, 1, _lib.ALGO_Q1),
               "q1_5k": (5000, 1, _lib.ALGO_Q1), "tile": (100000, 64, _lib.ALGO_TILE),
-              "topk": (100000, 1024, _lib.ALGO_AUTO)}[which]
+              "topk": (100000, 4096, _lib.ALGO_AUTO), "shard8": (100000, 4096, _lib.ALGO_AUTO)}[which]
 ids, offs, keys = synth.synth_timestamp_corpus(C, seed=synth.CORPUS_SEED)
 queries = synth.synth_queries(ids, offs, keys, max(Q, 64), seed=synth.CORPUS_SEED + 1)
 dc = tc.DeviceCorpus(0)
-dc.upload_csr(ids, offs, keys)
+if which == "shard8":          # rank 0's shard of an 8-way sharded corpus, the whole batch of queries
+    from tvidz_amd import sharded
+    dc.upload_csr(*sharded.shard_csr(ids, offs, keys, 0, 8))
+else:
+    dc.upload_csr(ids, offs, keys)
 d_q, d_off, ml = tc.pack_queries(queries[:Q], dev)
 CAP = 16384 if Q > 1 else 4096
 hits = torch.empty((Q, CAP, 3), dtype=torch.int32, device=dev)
 n = torch.empty(Q, dtype=torch.int32, device=dev)
 st = torch.cuda.Stream(dev)
 ts = []
-if which == "topk":
+if which in ("topk", "shard8"):
     ws = torch.empty(tc.workspace_bytes(Q, ml, CAP, 16), dtype=torch.uint8, device=dev)
     out = torch.empty((Q, 17, 3), dtype=torch.int32, device=dev)
-    call = lambda: dc.match_topk(d_q, d_off, ml, MM, CAP, 16, out=out, workspace=ws, stream=st)
+    def call():
+        blk = dc.match_topk(d_q, d_off, ml, MM, CAP, 16, out=out, workspace=ws, stream=st)
+        tc.topk_merge(blk.view(1, Q, 17, 3), 16, stream=st)
 else:
     ws = torch.empty(tc.workspace_bytes(Q, ml), dtype=torch.uint8, device=dev)
     call = lambda: dc.match(d_q, d_off, ml, MM, CAP, out_hits=hits, out_n=n, stream=st, workspace=ws, algo=algo)
@@ -49,7 +56,7 @@ for r in range(reps):
     st.synchronize()
     ts.append(a.elapsed_time(b))
 res = {"workload": which, "C": C, "Q": Q, "min_match": MM, "median_ms": round(float(np.median(ts[2:])), 4),
-       "hits": int(n.sum().item()) if which != "topk" else None}
+       "hits": int(n.sum().item()) if which not in ("topk", "shard8") else None}
 if which == "q1_5k":
     lat = []
     for i in range(200):

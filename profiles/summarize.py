@@ -18,7 +18,8 @@ shutil.copy(os.path.join(src, "trace", "trace_kernel_stats.csv"), os.path.join(d
 for f in ("bench_under_trace.json",):
     if os.path.exists(os.path.join(src, f)):
         shutil.copy(os.path.join(src, f), os.path.join(dst, f"{tag}_{f}"))
-OURS = ("luma_sad", "scene_finalize", "scene_select", "ts_match_tile", "ts_match_join", "ts_join_build", "ts_topk")
+OURS = ("luma_sad", "scene_finalize", "scene_tail", "scene_select", "ts_match_tile", "ts_match_join", "ts_join_build",
+        "ts_match_q1", "ts_topk_select", "ts_topk", "ts_prep")
 summary = {}
 for counter, sub, fn in (("FETCH_SIZE", "pmc_fetch", "fetch"), ("WRITE_SIZE", "pmc_write", "write")):
     path = os.path.join(src, sub, f"{fn}_counter_collection.csv")

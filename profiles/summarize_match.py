@@ -13,10 +13,10 @@ import sys
 tag = sys.argv[1] if len(sys.argv) > 1 else "r2"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "gpurun_out", f"pmc_match_{tag}")
-TAGS = {"join": "C100000_Q1024", "q1_100k": "C100000_Q1", "q1_5k": "C5000_Q1", "tile": "C100000_Q64",
-        "topk": "C100000_Q1024"}
+TAGS = {"join": "C100000_Q4096", "q1_100k": "C100000_Q1", "q1_5k": "C5000_Q1", "tile": "C100000_Q64",
+        "topk": "C100000_Q4096", "shard8": "C12500_Q4096"}
 OURS = ("ts_match_q1", "ts_match_tile", "ts_match_join", "ts_join_build", "ts_topk_select", "ts_topk_kernel",
-        "ts_prep", "ts_kth_fixup")
+        "ts_prep", "ts_kth_fixup", "ts_counts_gather")
 
 
 def kname(full):

@@ -1127,7 +1127,8 @@ __global__ __launch_bounds__(kQ1Block) void ts_match_q1_kernel(
 //   true number of hits as (-1, n, NEVER) so one all-gather moves lists and totals together; n is
 //   NEGATED when the shard's hit list overflowed its capacity (its top-k may then be inexact).
 constexpr int kSelBins = 4098;                // kth -1 .. 4095 exactly, everything above shares the last
-constexpr int kSelMin = 1024;                 // lists up to this long are sorted directly
+constexpr int kSelMin = 64;                   // lists up to this long are sorted directly (a 512-entry bitonic
+                                              // sort per query was 24 us per 1024 queries on a 1/8 shard)
 constexpr int kSelChunk = 1024;
 
 __device__ __forceinline__ int sel_bin(int32_t kth) {

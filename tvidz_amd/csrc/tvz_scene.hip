@@ -415,31 +415,38 @@ __global__ __launch_bounds__(kTailBlock) void scene_tail_kernel(
     const uint8_t *__restrict__ sel, int64_t T, int32_t *__restrict__ cuts, int32_t cuts_cap,
     StateHdr *__restrict__ st, const WsHdr *__restrict__ wh) {
     __shared__ int32_t wsum[kTailBlock / 64];
-    __shared__ int32_t s_base;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (threadIdx.x == 0) s_base = 0;
-    __syncthreads();
     if (cuts) {
-        for (int64_t b = 0; b < T; b += kTailBlock) {
-            const int64_t t = b + threadIdx.x;
-            const bool f = t < T && sel[t] != 0;
-            const unsigned long long bal = __ballot(f);
-            const int before = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32),
-                                                         __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
-            if (lane == 0) wsum[wave] = __popcll(bal);
-            __syncthreads();
-            int ofs = s_base;
-            for (int w = 0; w < wave; ++w) ofs += wsum[w];
-            if (f && ofs + before < cuts_cap) cuts[1 + ofs + before] = (int32_t)t;
-            __syncthreads();
-            if (threadIdx.x == 0) {
-                int tot = 0;
-                for (int w = 0; w < kTailBlock / 64; ++w) tot += wsum[w];
-                s_base += tot;
-            }
-            __syncthreads();
+        // ONE pass: thread i owns the frames [i*c, (i+1)*c); count, block-wide exclusive scan of the
+        // 1024 counts (DPP-free: ballot-less integer scan over LDS per wave, then over the 16 waves),
+        // then every thread writes its own frames' indices - ascending by construction
+        const int64_t c = (T + kTailBlock - 1) / kTailBlock;
+        const int64_t t0 = (int64_t)threadIdx.x * c;
+        const int64_t t1 = t0 + c < T ? t0 + c : T;
+        int mine = 0;
+        for (int64_t t = t0; t < t1; ++t) mine += sel[t] != 0;
+        // inclusive scan within the wave
+        int incl = mine;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int v = __shfl_up(incl, off);
+            if (lane >= off) incl += v;
         }
-        if (threadIdx.x == 0) cuts[0] = s_base;
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        int base = 0, total = 0;
+        for (int w = 0; w < kTailBlock / 64; ++w) {
+            const int v = wsum[w];
+            if (w < wave) base += v;
+            total += v;
+        }
+        int pos = base + incl - mine;
+        for (int64_t t = t0; t < t1; ++t)
+            if (sel[t] != 0) {
+                if (pos < cuts_cap) cuts[1 + pos] = (int32_t)t;
+                ++pos;
+            }
+        if (threadIdx.x == 0) cuts[0] = total;
     }
     if (st && threadIdx.x == 0) {
         st->prev_mafd = wh->last_mafd;
