@@ -165,3 +165,47 @@ def test_opt_in_near_duplicates_flags_the_cut_shifted_copy(tmp_path):
         assert nd["filename"] == "a.y4m" and nd["jaccard"] == 1.0 and abs(nd["shift_seconds"] + 7 / 30) < 1e-9
     finally:
         store.close()
+
+
+def test_container_time_base_and_real_pts_reach_the_fingerprint(tmp_path):
+    """an mp4's stream time base is 1/15360 (or 1/90000) and its pts are not the
+    frame index; showinfo prints pts x time_base (app.py:230).  A reader that reports such a time
+    base and per-frame pts must give the SAME scene_cuts as the same frames in a Y4M at 30 fps -
+    and therefore be flagged as its duplicate."""
+    store = tdb.Store(f"sqlite:///{tmp_path}/t.db", device=0)
+    luma = _clip(7, [33, 90, 171, 240])
+    files = {"1700000060-orig.y4m": str(tmp_path / "orig.y4m")}
+    feeder.write_y4m(files["1700000060-orig.y4m"], luma)
+
+    class ContainerReader:                      # what FFmpegReader presents for a 30 fps mp4
+        H, W, bitdepth, total_frames = H, W, 8, T
+        time_base = (1, 15360)
+
+        def __init__(self):
+            self.t = 0
+
+        def read_into(self, out):
+            n = min(out.shape[0], T - self.t)
+            out[:n] = luma[self.t:self.t + n]
+            self.t += n
+            return n
+
+        def pts_of(self, n):
+            return 512 * n                     # 15360 / 30
+
+        def close(self):
+            pass
+
+    def source(bucket, key, filename, uid):
+        return (ContainerReader(), None) if key.endswith(".mp4") else (feeder.Y4MReader(files[key]), None)
+    ins = insp.Inspector(store, device=DEV, frame_source=source, batch=64)
+    try:
+        r1 = ins.analyze_file("videos", "1700000060-orig.y4m")
+        exp = _oracle_cuts(luma)
+        assert r1["status"] == "done" and r1["scene_cuts"] == exp and [round(x * 30) for x in exp] == [33, 90, 171, 240]
+        r2 = ins.analyze_file("videos", "1700000061-remux.mp4")
+        assert r2["status"] == "done", r2
+        assert r2["scene_cuts"] == exp[:2] and r2["duplicates"] == ["orig.y4m"]   # same fingerprint: a duplicate
+    finally:
+        ins.close()
+        store.close()

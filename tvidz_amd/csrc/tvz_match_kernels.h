@@ -450,7 +450,7 @@ __global__ __launch_bounds__(kBlock) void ts_join_build_kernel(
 __global__ __launch_bounds__(kJoinBlock, 8) void ts_match_join_kernel(
     const Row *__restrict__ rows, int64_t n_rows, const int64_t *__restrict__ keys,
     const double *__restrict__ queries, const int64_t *__restrict__ q_offsets,
-    const uint32_t *__restrict__ table, int32_t s_log2, int32_t Q, int32_t q_per_tile,
+    const uint32_t *__restrict__ table, int32_t s_log2, int32_t Q, int32_t q_per_tile, int32_t tile,
     int32_t min_match, const int32_t *__restrict__ exclude_ids, int32_t cap,
     int32_t *__restrict__ hits, int32_t *__restrict__ hits_n, int32_t ns) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -465,7 +465,6 @@ __global__ __launch_bounds__(kJoinBlock, 8) void ts_match_join_kernel(
                                                  (size_t)kJoinWaves * kJoinRing * 8) + wave;
     int64_t *s_qoff = reinterpret_cast<int64_t *>(smem + (size_t)kJoinWaves * kJoinSlots * 12 +
                                                   (size_t)kJoinWaves * kJoinRing * 8 + kJoinWaves * 4);
-    const int tile = blockIdx.y;
     const int q0 = tile * q_per_tile;
     const int nq = (Q - q0 < q_per_tile) ? Q - q0 : q_per_tile;
     for (int i = threadIdx.x; i <= nq; i += kJoinBlock) s_qoff[i] = q_offsets[q0 + i];

@@ -229,7 +229,7 @@ def detect_scene_cuts(frames: Union[torch.Tensor, Iterable], time_base: Tuple[in
         from .feeder import FrameFeeder, open_reader
         reader = open_reader(frames)
         time_base = reader.time_base
-        pts = _ReaderPts(reader)
+        pts = ReaderPts(reader)
         frames = (d for _, d in FrameFeeder(reader, batch, dev))
     chunks = [frames] if isinstance(frames, torch.Tensor) else frames
     base = 0
@@ -253,7 +253,7 @@ def detect_scene_cuts(frames: Union[torch.Tensor, Iterable], time_base: Tuple[in
         base += chunk.shape[0]
 
 
-class _ReaderPts:
+class ReaderPts:
     """pts[n] of a reader: its own per-frame pts if it has them, else the frame index."""
 
     def __init__(self, reader):
