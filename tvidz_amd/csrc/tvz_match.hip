@@ -393,8 +393,7 @@ int launch_join(tvz_corpus *c, const double *d_queries, const int64_t *d_q_offse
     uint32_t *table = reinterpret_cast<uint32_t *>(ws);
     // one launch: hit counters = 0, every table slot = free
     if (int rc = launch_prep(d_hits_n, ns, Q, table, j.bytes(), nullptr, 0, st)) return rc;
-    hipLaunchKernelGGL(ts_join_build_kernel, dim3((unsigned)tvz::ceil_div(max_query_len, kBlock), (unsigned)Q),
-                       dim3(kBlock), 0, st, d_queries, d_q_offsets, Q, max_query_len, j.q_per_tile, j.s_log2,
+    hipLaunchKernelGGL(ts_join_build_kernel, dim3((unsigned)tvz::ceil_div(Q, kBlock / 64)), dim3(kBlock), 0, st, d_queries, d_q_offsets, Q, max_query_len, j.q_per_tile, j.s_log2,
                        table, d_hits_n, ns);
     TVZ_HIP(hipGetLastError());
     // ONE launch per tile, each filling the chip (two 16-wave blocks per CU): tiles that ran side by
@@ -505,8 +504,12 @@ int launch_match(tvz_corpus *c, const double *d_queries, const int64_t *d_q_offs
 
 int launch_topk_local(const int32_t *d_hits, const int32_t *d_hits_n, int32_t ns, int32_t Q, int32_t cap,
                       int32_t k, int32_t *d_out, int mode, hipStream_t st) {
-    hipLaunchKernelGGL(ts_topk_select_kernel, dim3((unsigned)Q), dim3(kBlock), 0, st, d_hits, d_hits_n,
-                       ns, Q, cap, k, d_out, mode);
+    if (k <= kSelSmallK)
+        hipLaunchKernelGGL(ts_topk_select_kernel<4 * kSelSmallK>, dim3((unsigned)Q), dim3(kBlock), 0, st, d_hits,
+                           d_hits_n, ns, Q, cap, k, d_out, mode);
+    else
+        hipLaunchKernelGGL(ts_topk_select_kernel<kSortCap>, dim3((unsigned)Q), dim3(kBlock), 0, st, d_hits,
+                           d_hits_n, ns, Q, cap, k, d_out, mode);
     TVZ_HIP(hipGetLastError());
     return TVZ_OK;
 }

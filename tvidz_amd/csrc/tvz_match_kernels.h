@@ -391,7 +391,10 @@ constexpr int kJoinQ = 1024;                          // queries per tile (10 bi
 constexpr int kJoinBlock = 1024;
 constexpr int kJoinWaves = kJoinBlock / 64;
 constexpr int kJoinSlots = 256;                       // per-wave accounting slots
-constexpr int kJoinMaxSlotsLog2 = 19;                 // 2^19 x 4 B = 2 MiB per tile
+#ifndef TVZ_JOIN_MAX_LOG2
+#define TVZ_JOIN_MAX_LOG2 19                          // 2^19 x 4 B = 2 MiB per tile
+#endif
+constexpr int kJoinMaxSlotsLog2 = TVZ_JOIN_MAX_LOG2;
 constexpr int kJoinRing = 128;                        // per-wave candidate ring (entries of 8 B)
 constexpr size_t kJoinLds = (size_t)kJoinWaves * kJoinSlots * 12 + (size_t)kJoinWaves * kJoinRing * 8 +
                             kJoinWaves * 4 + (kJoinQ + 1) * 8;
@@ -407,43 +410,49 @@ __device__ __forceinline__ void join_hash(int64_t k, int s_log2, uint32_t &bucke
     fp = (x ^ (x >> 11)) & 0x3ffu;
 }
 
+// One WAVE per query (4 per block), lanes striding over its elements: a block per query with 47 of
+// 256 threads busy was 4096 nearly empty blocks and 110 us per 4096 queries - more than a sweep of
+// a 1/8 shard.
 __global__ __launch_bounds__(kBlock) void ts_join_build_kernel(
     const double *__restrict__ queries, const int64_t *__restrict__ q_offsets, int32_t Q,
     int32_t max_len, int32_t q_per_tile, int32_t s_log2, uint32_t *__restrict__ table,
     int32_t *__restrict__ hits_n, int32_t ns) {
-    const int q = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    const int q = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    if (q >= Q) return;
     const int64_t o = q_offsets[q];
-    const int i = blockIdx.x * kBlock + threadIdx.x;
     const int64_t len = q_offsets[q + 1] - o;
     if (len > max_len) {
         // max_query_len was not an upper bound (the table is sized from it): nothing of this
         // query is inserted and its counter is poisoned instead (stays negative)
-        if (i == 0) hits_n[(size_t)q * ns] = INT32_MIN;
+        if (lane == 0) hits_n[(size_t)q * ns] = INT32_MIN;
         return;
     }
-    if (i >= (int)len) return;
-    int64_t k;
-    if (!canon_key(queries[o + i], k)) return;                     // NaN never matches
     const int tile = q / q_per_tile;
     uint32_t *tb = table + ((size_t)tile << s_log2);
     const uint32_t bmask = (1u << (s_log2 - 2)) - 1u;
-    uint32_t b, fp;
-    join_hash(k, s_log2, b, fp);
-    const uint32_t entry = (fp << 22) | ((uint32_t)(q - tile * q_per_tile) << 12) | (uint32_t)i;
-    // first free slot from the home bucket on: look, then claim it.  The look may be stale (this
-    // CU's L1), but slots only ever go from free to taken, so a stale view can only offer a slot
-    // that is gone - the failed CAS returns what is there and corrects the view.
-    uint4 bk = *reinterpret_cast<const uint4 *>(tb + b * 4);
-    while (true) {
-        const int j = bk.x == kJFree ? 0 : bk.y == kJFree ? 1 : bk.z == kJFree ? 2 : bk.w == kJFree ? 3 : 4;
-        if (j == 4) {                                              // bucket full: next one
-            b = (b + 1) & bmask;
-            bk = *reinterpret_cast<const uint4 *>(tb + b * 4);
-            continue;
+    const uint32_t qfield = (uint32_t)(q - tile * q_per_tile) << 12;
+    for (int i = lane; i < (int)len; i += 64) {
+        int64_t k;
+        if (!canon_key(queries[o + i], k)) continue;               // NaN never matches
+        uint32_t b, fp;
+        join_hash(k, s_log2, b, fp);
+        const uint32_t entry = (fp << 22) | qfield | (uint32_t)i;
+        // first free slot from the home bucket on: look, then claim it.  The look may be stale (this
+        // CU's L1), but slots only ever go from free to taken, so a stale view can only offer a slot
+        // that is gone - the failed CAS returns what is there and corrects the view.
+        uint4 bk = *reinterpret_cast<const uint4 *>(tb + b * 4);
+        while (true) {
+            const int j = bk.x == kJFree ? 0 : bk.y == kJFree ? 1 : bk.z == kJFree ? 2 : bk.w == kJFree ? 3 : 4;
+            if (j == 4) {                                          // bucket full: next one
+                b = (b + 1) & bmask;
+                bk = *reinterpret_cast<const uint4 *>(tb + b * 4);
+                continue;
+            }
+            const uint32_t old = atomicCAS(&tb[b * 4 + j], kJFree, entry);
+            if (old == kJFree) break;
+            if (j == 0) bk.x = old; else if (j == 1) bk.y = old; else if (j == 2) bk.z = old; else bk.w = old;
         }
-        const uint32_t old = atomicCAS(&tb[b * 4 + j], kJFree, entry);
-        if (old == kJFree) return;
-        if (j == 0) bk.x = old; else if (j == 1) bk.y = old; else if (j == 2) bk.z = old; else bk.w = old;
     }
 }
 
@@ -1128,18 +1137,22 @@ __global__ __launch_bounds__(kQ1Block) void ts_match_q1_kernel(
 constexpr int kSelBins = 4098;                // kth -1 .. 4095 exactly, everything above shares the last
 constexpr int kSelMin = 64;                   // lists up to this long are sorted directly (a 512-entry bitonic
                                               // sort per query was 24 us per 1024 queries on a 1/8 shard)
-constexpr int kSelChunk = 1024;
+constexpr int kSelSmallK = 256;               // k up to this: 1024 candidates held at once (12 KiB; with the
+                                              // histogram 29 KiB per block - 5 blocks per CU instead of 3)
 
 __device__ __forceinline__ int sel_bin(int32_t kth) {
     const uint32_t b = (uint32_t)kth + 1u;    // -1 -> 0, NEVER -> 0x80000000
     return b < (uint32_t)(kSelBins - 1) ? (int)b : kSelBins - 1;
 }
 
+template <int kSelCap>
 __global__ __launch_bounds__(kBlock) void ts_topk_select_kernel(
     const int32_t *__restrict__ lists, const int32_t *__restrict__ lists_n, int32_t ns, int32_t Q,
     int32_t cap, int32_t k, int32_t *__restrict__ topk, int32_t mode) {
-    __shared__ uint64_t key[kSortCap];
-    __shared__ int32_t cnt[kSortCap];
+    constexpr int kSelChunk = kSelCap / 2;
+    static_assert(kSelChunk % kBlock == 0, "whole passes of the block");
+    __shared__ uint64_t key[kSelCap];
+    __shared__ int32_t cnt[kSelCap];
     __shared__ uint32_t hist[kSelBins];
     __shared__ uint32_t part[kBlock];
     __shared__ int32_t s_pos, s_bin;
@@ -1197,7 +1210,7 @@ __global__ __launch_bounds__(kBlock) void ts_topk_select_kernel(
         }
         __syncthreads();
         pos = s_pos;
-        if (pos > kSortCap - kSelChunk) {     // no room for another chunk: reduce to the k best
+        if (pos > kSelCap - kSelChunk) {     // no room for another chunk: reduce to the k best
             sort_and_keep();
             if (threadIdx.x == 0) s_pos = pos;
             __syncthreads();
