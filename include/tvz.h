@@ -162,6 +162,21 @@ int tvz_corpus_clear(tvz_corpus *c);
 
 int tvz_corpus_stats(tvz_corpus *c, int64_t *n_rows, int64_t *n_keys, int64_t *arena_keys);
 
+/* Inverted index (no reference counterpart: db.py:83 has no index and reads the whole table per
+ * call).  The handle keeps, next to the row table, key -> rows posting lists over the rows as
+ * they were at the last build, and a DELTA table with the current entry of every row added or
+ * replaced since.  A match with min_match 1..5 is then a lookup (cost ~ postings of the query's
+ * keys, independent of the corpus size) + a sweep of the delta table; results are identical to
+ * a full sweep (every row is in exactly one of the two).
+ * Built by tvz_corpus_upload, when a corpus grown by upserts reaches 4096 rows, when the delta
+ * exceeds max(4096, indexed rows / 8), and by this call.  A build waits for matches in flight.
+ * A corpus with >= 2^32 keys (per GPU) gets no index and is swept. */
+int tvz_corpus_build_index(tvz_corpus *c);
+/* indexed rows / rows in the delta table / postings / distinct keys / builds so far (any may be NULL);
+ * all 0 while there is no index. */
+int tvz_corpus_index_stats(tvz_corpus *c, int64_t *n_indexed_rows, int64_t *n_delta_rows,
+                           int64_t *n_postings, int64_t *n_distinct_keys, int64_t *n_builds);
+
 /* ------------------------------------------------------------------------
  * Corpus match   — replaces db.find_duplicates (inspector/db.py:76-94) and
  * the per-prefix loop around it (inspector/app.py:231-255).
@@ -178,9 +193,12 @@ int tvz_corpus_stats(tvz_corpus *c, int64_t *n_rows, int64_t *n_keys, int64_t *a
  * on which find_duplicates returns row r  <=>  kth == k.
  * ------------------------------------------------------------------------ */
 
-/* Which kernel sweeps the corpus, PER CALL (there is no global knob); results never depend on it.
- *   AUTO : one query (or <= 4 against a small corpus) -> Q1; >= 64 queries x >= 3 M pairs with
- *          min_match 1..2 -> JOIN; else TILE
+/* How the corpus is matched, PER CALL (there is no global knob); results never depend on it.
+ *   AUTO : INDEX when the handle has one and min_match is 1..5.  Otherwise (and for the delta
+ *          table): one query (or <= 4 against a small corpus) -> Q1; >= 64 queries x >= 3 M pairs
+ *          with min_match 1..2 -> JOIN; else TILE
+ *   INDEX: posting-list lookup, one block per query, + a sweep of the delta table (error if the
+ *          handle has no index or min_match is outside 1..5)
  *   Q1   : one corpus sweep per query, the query's keys in a small LDS table, per-lane counters
  *   TILE : one LDS hash table per tile of <= 16 queries
  *   JOIN : device-memory hash join per tile of <= 1024 queries (min_match 1..2; other values take TILE) */
@@ -188,6 +206,7 @@ int tvz_corpus_stats(tvz_corpus *c, int64_t *n_rows, int64_t *n_keys, int64_t *a
 #define TVZ_ALGO_Q1 1
 #define TVZ_ALGO_TILE 2
 #define TVZ_ALGO_JOIN 3
+#define TVZ_ALGO_INDEX 4
 
 /* Scratch for the batched calls below.  k = 0 for tvz_match (tables of the hash join only);
  * k > 0 adds the hit lists + per-shard top-k block of tvz_match_topk / tvz_match_sharded

@@ -1,0 +1,205 @@
+"""GPU parity of the inverted index (tvz_index_kernels.h) against the oracle's restatement of
+db.find_duplicates (inspector/db.py:76-94) and against the sweep kernels: lookup + delta sweep must
+return exactly what a full sweep returns - bit-exact (video_id, count, kth) triples - for every
+min_match the index serves (1..5), through upserts that replace indexed rows, new rows, automatic
+rebuilds, corpora larger than the candidate bitmap, and queries with more candidates than the LDS
+table holds."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle
+from tvidz_amd import _lib, corpus as tc, synth
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture()
+def dc():
+    c = tc.DeviceCorpus(0)
+    yield c
+    c.close()
+
+
+def _expected(ids, offs, keys, q, mm, excl=None):
+    cnt, kth = oracle.match_kth_csr(np.asarray(q, dtype=np.float64), offs, keys, mm)
+    return sorted((int(ids[c]), int(cnt[c]), int(kth[c])) for c in range(len(ids))
+                  if cnt[c] >= mm and (excl is None or ids[c] != excl))
+
+
+def _check(dc, rows, queries, mm, excl=None, cap=None, algo=_lib.ALGO_INDEX):
+    ids, offs, keys = tc.rows_to_csr(rows)
+    d_q, d_off, max_len = tc.pack_queries(queries, DEV)
+    cap = cap or max(len(ids), 1)
+    d_ex = torch.tensor(excl, dtype=torch.int32, device=DEV) if excl is not None else None
+    hits, n = dc.match(d_q, d_off, max_len, mm, cap, d_exclude_ids=d_ex, algo=algo)
+    torch.cuda.synchronize()
+    hits, n = hits.cpu().numpy(), n.cpu().numpy()
+    for qi, q in enumerate(queries):
+        exp = _expected(ids, offs, keys, q, mm, None if excl is None else excl[qi])
+        assert n[qi] == len(exp), (qi, int(n[qi]), len(exp))
+        got = sorted(tuple(int(x) for x in h) for h in hits[qi, :min(n[qi], cap)])
+        if n[qi] > cap:
+            assert len(got) == cap and set(got) <= set(exp)
+        else:
+            assert got == exp, qi
+    return n
+
+
+def _check_single(dc, rows, q, mm, excl=-1):
+    ids, offs, keys = tc.rows_to_csr(rows)
+    got = dc.find_duplicates(q, mm, exclude_id=excl, with_kth=True)
+    assert got == _expected(ids, offs, keys, q, mm, excl if excl >= 0 else None)
+
+
+@pytest.mark.parametrize("C,mean_len,Q", [(300, 40, 9), (3000, 200, 24), (64, 12, 7)])
+def test_index_equals_oracle_and_sweeps(dc, C, mean_len, Q):
+    ids, offs, keys = synth.synth_timestamp_corpus(C, seed=C, mean_len=mean_len, dup_frac=0.05, frag_frac=0.05)
+    rows = [(int(ids[r]), keys[offs[r]:offs[r + 1]].tolist()) for r in range(C)]
+    dc.upload(rows)
+    st = dc.index_stats()
+    assert st["indexed_rows"] == C and st["delta_rows"] == 0 and st["builds"] == 1
+    assert st["postings"] == dc.stats()[1] and 0 < st["distinct_keys"] <= st["postings"]
+    queries = synth.synth_queries(ids, offs, keys, Q, seed=Q, mean_len=mean_len)
+    queries[0] = np.concatenate([queries[0], queries[0][:7]])        # multiplicity
+    queries[1] = np.array([float("nan"), -0.0, 0.0] + queries[1][:5].tolist())
+    queries[2] = np.zeros(0)                                         # empty query
+    excl = [int(ids[(7 * i) % C]) for i in range(Q)]
+    for mm in (1, 2, 3, 5):
+        _check(dc, rows, queries, mm)
+        _check(dc, rows, queries, mm, excl=excl)
+        _check(dc, rows, queries, mm, excl=excl, algo=_lib.ALGO_AUTO)
+        _check(dc, rows, queries, mm, cap=3)                          # overflow keeps the true counts
+        for q in queries[:4]:
+            _check_single(dc, rows, q, mm)
+            _check_single(dc, rows, q, mm, excl=excl[0])
+    for mm in (0, 6):                                                 # not the index's: refused / swept
+        with pytest.raises(RuntimeError, match="min_match 1..5"):
+            _check(dc, rows, queries, mm)
+        _check(dc, rows, queries, mm, algo=_lib.ALGO_AUTO)
+
+
+def test_more_candidates_than_the_lds_table_holds(dc):
+    """A small alphabet: thousands of rows share >= 2 keys with a query (parts > 1), one key is in
+    half of the rows (a posting list of thousands), and a query made of that key alone."""
+    C = 9000
+    rng = np.random.default_rng(3)
+    grid = np.arange(1, 1501) / 8.0
+    rows = []
+    for c in range(C):
+        r = rng.choice(grid, size=int(rng.integers(5, 40)), replace=False)
+        if rng.random() < 0.5:
+            r = np.append(r, 777.125)
+        rows.append((c + 1, r.tolist()))
+    dc.upload(rows)
+    queries = [rng.choice(grid, size=n, replace=False) for n in (20, 160, 600, 1400)]
+    queries.append(np.array([777.125] * 3))
+    queries.append(np.concatenate([grid[:300], grid[:300]]))
+    for mm in (1, 2, 5):
+        n = _check(dc, rows, queries, mm)
+        assert n.max() > 4000                                         # well beyond 1536 table entries
+    _check_single(dc, rows, queries[3], 2)
+    _check_single(dc, rows, queries[4], 1)
+
+
+def test_corpus_larger_than_the_candidate_bitmap(dc):
+    """> 2^17 rows: rows share bits of the seen-once / seen-twice bitmaps; counts stay exact."""
+    C = 150_000
+    rng = np.random.default_rng(5)
+    alphabet = np.arange(1, 40_001) / 4.0
+    lens = rng.integers(2, 6, size=C)
+    offs = np.zeros(C + 1, dtype=np.int64)
+    offs[1:] = np.cumsum(lens)
+    keys = rng.choice(alphabet, size=int(offs[-1]))
+    ids = np.arange(1, C + 1, dtype=np.int32)
+    dc.upload_csr(ids, offs, keys)
+    ids2, offs2, keys2 = ids, offs, keys                              # rows may repeat a key: still a set
+    queries = [rng.choice(alphabet, size=n, replace=False) for n in (50, 400, 3000)]
+    d_q, d_off, max_len = tc.pack_queries(queries, DEV)
+    for mm in (1, 2, 3):
+        hits, n = dc.match(d_q, d_off, max_len, mm, 60000, algo=_lib.ALGO_INDEX)
+        torch.cuda.synchronize()
+        hits, n = hits.cpu().numpy(), n.cpu().numpy()
+        for qi, q in enumerate(queries):
+            exp = _expected(ids2, offs2, keys2, q, mm)
+            assert n[qi] == len(exp) <= 60000
+            assert sorted(tuple(int(x) for x in h) for h in hits[qi, :n[qi]]) == exp
+
+
+def test_upserts_replace_indexed_rows_and_add_new_ones(dc):
+    C = 1200
+    ids, offs, keys = synth.synth_timestamp_corpus(C, seed=11, mean_len=60, dup_frac=0.05)
+    rows = [(int(ids[r]), keys[offs[r]:offs[r + 1]].tolist()) for r in range(C)]
+    dc.upload(rows)
+    rng = np.random.default_rng(12)
+    queries = synth.synth_queries(ids, offs, keys, 12, seed=13, mean_len=60)
+    by_id = {v: i for i, (v, _) in enumerate(rows)}
+    new_id = int(ids.max()) + 1
+    for step in range(40):
+        kind = step % 4
+        if kind == 0:        # an indexed row gets the content of a query: its old postings are stale
+            v = rows[int(rng.integers(0, C))][0]
+            ts = queries[step % len(queries)].tolist()
+        elif kind == 1:      # a brand-new video: lives in the delta table only
+            v, new_id = new_id, new_id + 1
+            ts = np.round(rng.uniform(0, 3000, 50), 2).tolist() + queries[0][:9].tolist()
+        elif kind == 2:      # the same row again (already in the delta table): in-place swap there
+            v = rows[by_id[v]][0]
+            ts = queries[(step + 1) % len(queries)][:20].tolist()
+        else:                # a row emptied
+            v = rows[int(rng.integers(0, len(rows)))][0]
+            ts = []
+        dc.upsert(v, ts)
+        if v in by_id:
+            rows[by_id[v]] = (v, ts)
+        else:
+            by_id[v] = len(rows)
+            rows.append((v, ts))
+        if step % 5 == 4:
+            _check(dc, rows, queries, 2)
+            _check(dc, rows, queries, 2, algo=_lib.ALGO_TILE)          # the full sweep agrees
+            _check_single(dc, rows, queries[step % len(queries)], 2, excl=rows[3][0])
+    st = dc.index_stats()
+    assert st["indexed_rows"] == C and 0 < st["delta_rows"] <= 40 and st["builds"] == 1
+    _check(dc, rows, queries, 1)
+    _check(dc, rows, queries, 5, excl=[rows[i][0] for i in range(len(queries))])
+    dc.build_index()
+    st = dc.index_stats()
+    assert st["indexed_rows"] == len(rows) and st["delta_rows"] == 0 and st["builds"] == 2
+    _check(dc, rows, queries, 2)
+    _check_single(dc, rows, queries[0], 2)
+    # clear: no index, no rows; the next rows are swept until there are enough for an index
+    dc.clear()
+    assert dc.index_stats()["indexed_rows"] == 0
+    assert dc.find_duplicates(queries[0].tolist(), 1) == []
+    dc.upsert(5, queries[0].tolist())
+    assert dc.find_duplicates(queries[0].tolist(), 2) == [(5, len(queries[0]))]
+    with pytest.raises(RuntimeError, match="no index"):
+        _check(dc, [(5, queries[0].tolist())], queries[:2], 2)
+
+
+def test_a_corpus_grown_by_upserts_gets_and_refreshes_its_index(dc):
+    """add_timestamps only (db.py:43-64), as the service does: first index at 4096 rows, rebuilt
+    when the delta table (max(4096, rows / 8) entries) is full; matches are right at every stage."""
+    rng = np.random.default_rng(21)
+    grid = np.arange(1, 30_001) / 10.0
+    rows = []
+    probe = rng.choice(grid, size=30, replace=False)
+    builds = []
+    for v in range(1, 8500):
+        ts = rng.choice(grid, size=12, replace=False).tolist()
+        if v % 500 == 0:
+            ts += probe[:10].tolist()
+        dc.upsert(v, ts)
+        rows.append((v, ts))
+        if v in (100, 4095, 4096, 4097, 6000, 8191, 8193, 8499):
+            builds.append((v, dc.index_stats()))
+            _check_single(dc, rows, probe, 2)
+            if v in (4097, 8499):
+                _check(dc, rows, [probe, np.asarray(rows[10][1])], 2, algo=_lib.ALGO_AUTO)
+    st = dict(builds)
+    assert st[100]["builds"] == 0 and st[4095]["builds"] == 0
+    assert st[4096]["builds"] == 1 and st[4096]["indexed_rows"] == 4096 and st[4096]["delta_rows"] == 0
+    assert st[4097]["delta_rows"] == 1 and st[6000]["delta_rows"] == 6000 - 4096
+    assert st[8499]["builds"] == 2 and st[8499]["indexed_rows"] > 8000     # the delta filled up once

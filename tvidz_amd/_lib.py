@@ -40,6 +40,8 @@ SIGNATURES = {
     "tvz_corpus_upload": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_int64]),
     "tvz_corpus_upsert": (C.c_int, [_P, C.c_int32, _P, C.c_int64]),
     "tvz_corpus_clear": (C.c_int, [_P]),
+    "tvz_corpus_build_index": (C.c_int, [_P]),
+    "tvz_corpus_index_stats": (C.c_int, [_P] + [C.POINTER(C.c_int64)] * 5),
     "tvz_corpus_stats": (C.c_int, [_P, C.POINTER(C.c_int64), C.POINTER(C.c_int64),
                                    C.POINTER(C.c_int64)]),
     "tvz_match_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
@@ -62,7 +64,7 @@ SIGNATURES = {
 }
 
 # per-call selectors of include/tvz.h
-ALGO_AUTO, ALGO_Q1, ALGO_TILE, ALGO_JOIN = 0, 1, 2, 3
+ALGO_AUTO, ALGO_Q1, ALGO_TILE, ALGO_JOIN, ALGO_INDEX = 0, 1, 2, 3, 4
 SHAPE_AUTO = 0
 SHAPE_NO_NT = 1 << 30
 UNIQUE_ID_BYTES = 128

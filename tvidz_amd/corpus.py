@@ -93,6 +93,18 @@ class DeviceCorpus:
         _lib.check(self.lib.tvz_corpus_clear(self._h))
         self._row_bound = 0
 
+    def build_index(self) -> None:
+        """Rebuild the inverted index over the current rows now (upload builds it, and it is rebuilt
+        automatically as the delta table fills); waits for matches in flight."""
+        _lib.check(self.lib.tvz_corpus_build_index(self._h))
+
+    def index_stats(self) -> dict:
+        """indexed_rows / delta_rows / postings / distinct_keys / builds; zeros while there is no index."""
+        v = [C.c_int64() for _ in range(5)]
+        _lib.check(self.lib.tvz_corpus_index_stats(self._h, *[C.byref(x) for x in v]))
+        return dict(zip(("indexed_rows", "delta_rows", "postings", "distinct_keys", "builds"),
+                        (int(x.value) for x in v)))
+
     def stats(self) -> Tuple[int, int, int]:
         a, b, c = C.c_int64(), C.c_int64(), C.c_int64()
         _lib.check(self.lib.tvz_corpus_stats(self._h, C.byref(a), C.byref(b), C.byref(c)))

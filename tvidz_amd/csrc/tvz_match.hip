@@ -26,6 +26,7 @@
 #include <vector>
 
 #include "tvz_match_kernels.h"
+#include "tvz_index_kernels.h"
 
 namespace {
 
@@ -47,6 +48,9 @@ struct Staging {
     int32_t *h_counts = nullptr;     // pinned + mapped: [kQ1MaxBlocks]
     int32_t *dh_counts = nullptr;
     int64_t hit_slots = 0;           // capacity of h_hits in hits
+    int32_t *h_ix_hits = nullptr;    // pinned + mapped: hits of the index lookup [ix_slots][3]
+    int32_t *dh_ix_hits = nullptr;
+    int64_t ix_slots = 0;
     int32_t *d_hits = nullptr;       // device hit list for the paths that need a fix-up pass
     int32_t *d_hits_n = nullptr;
     int64_t d_hit_slots = 0;
@@ -66,6 +70,27 @@ struct RingSlot {
     int64_t *h = nullptr;
     hipEvent_t ev = nullptr;
     bool pending = false;
+};
+
+// Inverted index over rows [0, n_main) as they were when it was built (tvz_index_kernels.h) plus
+// the DELTA table: the current entry of every row that was added or replaced since.  A match with
+// the index = index lookup (rows that are unchanged since the build) + a sweep of the delta table.
+constexpr int64_t kIndexMinRows = 4096;           // a corpus grown by upserts gets its first index here
+constexpr int64_t kIndexMinDelta = 4096;          // rebuilt when the delta exceeds max(this, n_main / 8)
+
+struct Index {
+    DevBuf<DirEnt> dir;
+    int dir_log2 = 0;
+    DevBuf<uint32_t> post;
+    DevBuf<int32_t> ivid;
+    DevBuf<Row> drows;
+    IxBuildInfo *info = nullptr;      // device
+    bool valid = false;
+    int64_t n_main = 0;
+    int64_t n_delta = 0;
+    int64_t n_post = 0, n_distinct = 0;
+    int64_t builds = 0;
+    std::unordered_map<int64_t, int32_t> delta_slot;   // row index -> slot in drows
 };
 
 }  // namespace
@@ -95,6 +120,8 @@ struct tvz_corpus {
     std::vector<Staging *> free_staging;
     std::vector<Staging *> all_staging;   // every staging ever made (checked out or free)
     int64_t stage_rows = 0;          // rows the stagings are sized for
+    Index ix;
+    int64_t ix_next_try_rows = 0;    // a corpus without an index tries to build one from this size on
 };
 
 namespace {
@@ -210,11 +237,73 @@ int compact(tvz_corpus *c) {
     return upload_all(c, 0, 0);
 }
 
+// ---- inverted index: build (caller holds mu exclusively and has drained every reader) --------
+void index_drop(tvz_corpus *c) {
+    Index &ix = c->ix;
+    ix.valid = false;
+    ix.n_main = ix.n_delta = ix.n_post = ix.n_distinct = 0;
+    ix.delta_slot.clear();
+}
+
+int64_t delta_capacity(int64_t n_main) { return std::max<int64_t>(kIndexMinDelta, n_main / 8) + 64; }
+
+int build_index(tvz_corpus *c) {
+    Index &ix = c->ix;
+    index_drop(c);
+    const int64_t n_rows = (int64_t)c->h_rows.size();
+    // posting offsets and counts are 32-bit: a larger shard is swept (shard it over more GPUs)
+    if (n_rows == 0 || c->live_keys >= (int64_t)0xfffffff0LL) return TVZ_OK;
+    hipStream_t st = c->mstream;
+    if (!ix.info) TVZ_HIP(hipMalloc(&ix.info, sizeof(IxBuildInfo)));
+    if (int rc = ensure(ix.post, std::max<int64_t>(c->live_keys, 1), 0)) return rc;
+    if (int rc = ensure(ix.ivid, c->rows.cap, 0)) return rc;
+    if (int rc = ensure(ix.drows, delta_capacity(n_rows), 0)) return rc;
+    // directory: sized for a guess of the distinct keys (a fingerprint corpus repeats its keys many
+    // times over: 442 k distinct in the 19.9 M of config 4), grown if the guess was too small
+    const int64_t guess = std::min<int64_t>(c->live_keys, std::max<int64_t>((int64_t)1 << 20, c->live_keys / 8));
+    int log2 = 12;
+    while (((int64_t)1 << log2) < 2 * guess) ++log2;
+    const int blocks = (int)std::min<int64_t>(tvz::ceil_div(n_rows, kBlock / 64), 256 * 8);
+    IxBuildInfo info{};
+    while (true) {
+        TVZ_REQUIRE(log2 <= 31, "index directory would exceed 2^31 entries");
+        const int64_t dn = (int64_t)1 << log2;
+        if (int rc = ensure(ix.dir, dn, 0)) return rc;
+        hipLaunchKernelGGL(ix_clear_kernel, dim3(1024), dim3(kBlock), 0, st, ix.dir.p, (size_t)dn, ix.info);
+        hipLaunchKernelGGL(ix_count_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, st, c->rows.p, n_rows,
+                           c->keys.p, ix.dir.p, log2, ix.ivid.p, ix.info);
+        TVZ_HIP(hipGetLastError());
+        TVZ_HIP(hipMemcpyAsync(&info, ix.info, sizeof(info), hipMemcpyDeviceToHost, st));
+        TVZ_HIP(hipStreamSynchronize(st));
+        if (!info.failed && (int64_t)info.distinct * 2 <= dn) break;
+        log2 += 2;                                    // too crowded: four times the directory
+    }
+    const int64_t dn = (int64_t)1 << log2;
+    hipLaunchKernelGGL(ix_offsets_kernel, dim3((unsigned)tvz::ceil_div(dn, kBlock)), dim3(kBlock), 0, st, ix.dir.p,
+                       (size_t)dn, ix.info);
+    hipLaunchKernelGGL(ix_fill_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, st, c->rows.p, n_rows, c->keys.p,
+                       ix.dir.p, log2, ix.post.p);
+    TVZ_HIP(hipGetLastError());
+    TVZ_HIP(hipMemcpyAsync(&info, ix.info, sizeof(info), hipMemcpyDeviceToHost, st));
+    TVZ_HIP(hipStreamSynchronize(st));
+    if ((int64_t)info.cursor != c->live_keys)
+        return tvz::fail(TVZ_ERR_INVALID, "internal: index holds %u postings for %lld keys", info.cursor,
+                         (long long)c->live_keys);
+    ix.dir_log2 = log2;
+    ix.n_main = n_rows;
+    ix.n_post = info.cursor;
+    ix.n_distinct = info.distinct;
+    ix.valid = true;
+    ++ix.builds;
+    return TVZ_OK;
+}
+
 // ---- single-query staging --------------------------------------------------------------------
 void staging_free(Staging *s) {
     if (s->h_query) (void)hipHostFree(s->h_query);
     if (s->d_query) (void)hipFree(s->d_query);
     if (s->h_hits) (void)hipHostFree(s->h_hits);
+    if (s->h_ix_hits) (void)hipHostFree(s->h_ix_hits);
     if (s->h_counts) (void)hipHostFree(s->h_counts);
     if (s->d_hits) (void)hipFree(s->d_hits);
     if (s->d_hits_n) (void)hipFree(s->d_hits_n);
@@ -234,6 +323,12 @@ int staging_size(Staging *s, int64_t rows) {
     TVZ_HIP(hipHostMalloc(&s->h_hits, (size_t)slots * 12, hipHostMallocMapped));
     TVZ_HIP(hipHostGetDevicePointer(reinterpret_cast<void **>(&s->dh_hits), s->h_hits, 0));
     s->hit_slots = slots;
+    if (s->h_ix_hits) (void)hipHostFree(s->h_ix_hits);
+    s->h_ix_hits = nullptr;
+    s->ix_slots = 0;
+    TVZ_HIP(hipHostMalloc(&s->h_ix_hits, (size_t)std::max<int64_t>(rows, 1) * 12, hipHostMallocMapped));
+    TVZ_HIP(hipHostGetDevicePointer(reinterpret_cast<void **>(&s->dh_ix_hits), s->h_ix_hits, 0));
+    s->ix_slots = std::max<int64_t>(rows, 1);
     return TVZ_OK;
 }
 
@@ -243,7 +338,7 @@ int staging_new(tvz_corpus *c, Staging **out) {
     TVZ_HIP(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
     TVZ_HIP(hipHostMalloc(&s->h_query, (size_t)(kQueryStageKeys + 2) * 8, hipHostMallocDefault));
     TVZ_HIP(hipMalloc(&s->d_query, (size_t)(kQueryStageKeys + 2) * 8));
-    TVZ_HIP(hipHostMalloc(&s->h_counts, (size_t)kQ1MaxBlocks * 4, hipHostMallocMapped));
+    TVZ_HIP(hipHostMalloc(&s->h_counts, (size_t)(kQ1MaxBlocks + 1) * 4, hipHostMallocMapped));   // + the index lookup's
     TVZ_HIP(hipHostGetDevicePointer(reinterpret_cast<void **>(&s->dh_counts), s->h_counts, 0));
     TVZ_HIP(hipMalloc(&s->d_hits_n, sizeof(int32_t)));
     if (int rc = staging_size(s, c->stage_rows)) return rc;
@@ -381,18 +476,24 @@ int launch_prep(int32_t *d_hits_n, int32_t ns, int32_t Q, void *ones, size_t one
     return TVZ_OK;
 }
 
-int launch_join(tvz_corpus *c, const double *d_queries, const int64_t *d_q_offsets, int32_t Q,
-                int32_t max_query_len, int32_t min_match, const int32_t *d_exclude_ids,
-                int32_t cap, int32_t *d_hits, int32_t *d_hits_n, int32_t ns, unsigned char *ws,
-                size_t ws_bytes, hipStream_t st) {
-    const int64_t n_rows = (int64_t)c->h_rows.size();
+// The rows a sweep reads: the whole row table, or the delta table of an indexed corpus.
+struct RowSpan {
+    const Row *p;
+    int64_t n;
+};
+
+int launch_join(tvz_corpus *c, RowSpan span, bool zero_counts, const double *d_queries,
+                const int64_t *d_q_offsets, int32_t Q, int32_t max_query_len, int32_t min_match,
+                const int32_t *d_exclude_ids, int32_t cap, int32_t *d_hits, int32_t *d_hits_n, int32_t ns,
+                unsigned char *ws, size_t ws_bytes, hipStream_t st) {
+    const int64_t n_rows = span.n;
     const JoinShape j = join_shape(Q, max_query_len);
     if (ws == nullptr || ws_bytes < j.bytes())
         return tvz::fail(TVZ_ERR_WORKSPACE, "hash join needs a workspace of %zu bytes (got %zu): size it "
                                             "with tvz_match_workspace_bytes", j.bytes(), ws_bytes);
     uint32_t *table = reinterpret_cast<uint32_t *>(ws);
     // one launch: hit counters = 0, every table slot = free
-    if (int rc = launch_prep(d_hits_n, ns, Q, table, j.bytes(), nullptr, 0, st)) return rc;
+    if (int rc = launch_prep(d_hits_n, ns, zero_counts ? Q : 0, table, j.bytes(), nullptr, 0, st)) return rc;
     hipLaunchKernelGGL(ts_join_build_kernel, dim3((unsigned)tvz::ceil_div(Q, kBlock / 64)), dim3(kBlock), 0, st, d_queries, d_q_offsets, Q, max_query_len, j.q_per_tile, j.s_log2,
                        table, d_hits_n, ns);
     TVZ_HIP(hipGetLastError());
@@ -403,7 +504,7 @@ int launch_join(tvz_corpus *c, const double *d_queries, const int64_t *d_q_offse
     // videos over 8 GPUs) that latency is the sweep.
     const int64_t chunks = std::max<int64_t>(1, std::min<int64_t>(512, tvz::ceil_div(n_rows, kJoinWaves)));
     for (int t = 0; t < j.n_tiles; ++t) {
-        hipLaunchKernelGGL(ts_match_join_kernel, dim3((unsigned)chunks), dim3(kJoinBlock), kJoinLds, st, c->rows.p,
+        hipLaunchKernelGGL(ts_match_join_kernel, dim3((unsigned)chunks), dim3(kJoinBlock), kJoinLds, st, span.p,
                            n_rows, c->keys.p, d_queries, d_q_offsets, table, j.s_log2, Q, j.q_per_tile, t,
                            min_match, d_exclude_ids, cap, d_hits, d_hits_n, ns);
         TVZ_HIP(hipGetLastError());
@@ -412,18 +513,18 @@ int launch_join(tvz_corpus *c, const double *d_queries, const int64_t *d_q_offse
 }
 
 template <bool HOSTOUT>
-int launch_q1(tvz_corpus *c, const double *d_queries, const int64_t *d_q_offsets, int32_t Q,
+int launch_q1(tvz_corpus *c, RowSpan span, const double *d_queries, const int64_t *d_q_offsets, int32_t Q,
               int32_t max_query_len, int32_t min_match, const int32_t *d_exclude_ids,
               int32_t exclude_one, int32_t cap, int32_t *d_hits, int32_t *d_hits_n, int32_t ns,
               int blocks_x, HostOut ho, hipStream_t st, const QByVal *byval = nullptr) {
     static const QByVal kNoQuery = {};
     const QByVal &qv = byval ? *byval : kNoQuery;
-    const int64_t n_rows = (int64_t)c->h_rows.size();
+    const int64_t n_rows = span.n;
     const int s_log2 = q1_slots_log2(max_query_len);
     const size_t lds = q1_lds_bytes(s_log2);
     const dim3 grid((unsigned)blocks_x, (unsigned)Q);
 #define TVZ_Q1(MODE)                                                                              \
-    hipLaunchKernelGGL((ts_match_q1_kernel<MODE, HOSTOUT>), grid, dim3(kQ1Block), lds, st, c->rows.p, \
+    hipLaunchKernelGGL((ts_match_q1_kernel<MODE, HOSTOUT>), grid, dim3(kQ1Block), lds, st, span.p, \
                        n_rows, c->keys.p, d_queries, d_q_offsets, min_match, d_exclude_ids,          \
                        exclude_one, cap, d_hits, d_hits_n, ns, s_log2, ho, qv)
     if (min_match <= 0 || min_match > kTop) TVZ_Q1(kQ1ModeCount);
@@ -443,28 +544,20 @@ int q1_blocks(int64_t n_rows, int32_t Q) {
     return (int)b;
 }
 
-int launch_match(tvz_corpus *c, const double *d_queries, const int64_t *d_q_offsets, int32_t Q,
-                 int32_t max_query_len, int32_t min_match, const int32_t *d_exclude_ids,
-                 int32_t cap, int32_t *d_hits, int32_t *d_hits_n, int32_t ns, unsigned char *ws,
-                 size_t ws_bytes, int32_t algo, hipStream_t st) {
-    if (max_query_len > kMaxQueryLen)
-        return tvz::fail(TVZ_ERR_UNSUPPORTED, "query of %d timestamps exceeds the supported %d",
-                         max_query_len, kMaxQueryLen);
-    TVZ_REQUIRE(algo >= TVZ_ALGO_AUTO && algo <= TVZ_ALGO_JOIN, "unknown algo %d", algo);
-    if (int rc = wait_mutations(c, st)) return rc;
-    const int64_t n_rows = (int64_t)c->h_rows.size();
-    int a = pick_algo(algo, Q, n_rows, max_query_len, min_match);
-    // AUTO never fails for want of scratch: without the join's tables it takes the LDS tile
-    if (a == TVZ_ALGO_JOIN && algo == TVZ_ALGO_AUTO && (ws == nullptr || ws_bytes < join_shape(Q, max_query_len).bytes()))
-        a = TVZ_ALGO_TILE;
-    if (n_rows == 0 || a != TVZ_ALGO_JOIN)
+// one sweep of `span` with a resolved scan algorithm (Q1 / TILE / JOIN); appends to the hit lists
+int launch_scan(tvz_corpus *c, RowSpan span, int a, bool zero_counts, const double *d_queries,
+                const int64_t *d_q_offsets, int32_t Q, int32_t max_query_len, int32_t min_match,
+                const int32_t *d_exclude_ids, int32_t cap, int32_t *d_hits, int32_t *d_hits_n, int32_t ns,
+                unsigned char *ws, size_t ws_bytes, hipStream_t st) {
+    const int64_t n_rows = span.n;
+    if (zero_counts && (n_rows == 0 || a != TVZ_ALGO_JOIN))
         if (int rc = launch_prep(d_hits_n, ns, Q, nullptr, 0, nullptr, 0, st)) return rc;
     if (n_rows == 0 || Q == 0) return TVZ_OK;
     if (a == TVZ_ALGO_JOIN)
-        return launch_join(c, d_queries, d_q_offsets, Q, max_query_len, min_match, d_exclude_ids, cap,
-                           d_hits, d_hits_n, ns, ws, ws_bytes, st);
+        return launch_join(c, span, zero_counts, d_queries, d_q_offsets, Q, max_query_len, min_match,
+                           d_exclude_ids, cap, d_hits, d_hits_n, ns, ws, ws_bytes, st);
     if (a == TVZ_ALGO_Q1) {
-        if (int rc = launch_q1<false>(c, d_queries, d_q_offsets, Q, max_query_len, min_match,
+        if (int rc = launch_q1<false>(c, span, d_queries, d_q_offsets, Q, max_query_len, min_match,
                                       d_exclude_ids, -1, cap, d_hits, d_hits_n, ns, q1_blocks(n_rows, Q),
                                       HostOut{nullptr, nullptr, 0}, st))
             return rc;
@@ -484,22 +577,75 @@ int launch_match(tvz_corpus *c, const double *d_queries, const int64_t *d_q_offs
             return tvz::fail(TVZ_ERR_UNSUPPORTED, "too many query tiles (%lld)", (long long)tiles);
         if (min_match <= 2)
             hipLaunchKernelGGL(ts_match_tile_kernel<false>, dim3((unsigned)chunks, (unsigned)tiles),
-                               dim3(kTileBlock), kTileLds, st, c->rows.p, n_rows, c->keys.p, d_queries,
+                               dim3(kTileBlock), kTileLds, st, span.p, n_rows, c->keys.p, d_queries,
                                d_q_offsets, Q, nq, min_match, d_exclude_ids, cap, d_hits, d_hits_n, ns,
                                (int32_t)rpb);
         else
             hipLaunchKernelGGL(ts_match_tile_kernel<true>, dim3((unsigned)chunks, (unsigned)tiles),
-                               dim3(kTileBlock), kTileLds, st, c->rows.p, n_rows, c->keys.p, d_queries,
+                               dim3(kTileBlock), kTileLds, st, span.p, n_rows, c->keys.p, d_queries,
                                d_q_offsets, Q, nq, min_match, d_exclude_ids, cap, d_hits, d_hits_n, ns,
                                (int32_t)rpb);
         TVZ_HIP(hipGetLastError());
     }
     if (min_match > kTop) {
-        hipLaunchKernelGGL(ts_kth_fixup_kernel, dim3((unsigned)Q), dim3(kBlock), 0, st, c->rows.p,
+        hipLaunchKernelGGL(ts_kth_fixup_kernel, dim3((unsigned)Q), dim3(kBlock), 0, st, span.p,
                            c->keys.p, d_queries, d_q_offsets, min_match, cap, d_hits, d_hits_n, ns);
         TVZ_HIP(hipGetLastError());
     }
     return TVZ_OK;
+}
+
+// the index answers min_match 1..5 (the five smallest query positions per candidate give kth)
+bool index_usable(const tvz_corpus *c, int32_t min_match) {
+    return c->ix.valid && min_match >= 1 && min_match <= kTop;
+}
+
+// index lookup of Q queries (one block each); WRITES every query's counter (no prep launch)
+int launch_index(tvz_corpus *c, const double *d_queries, const int64_t *d_q_offsets, int32_t Q,
+                 int32_t max_query_len, int32_t min_match, const int32_t *d_exclude_ids, int32_t exclude_one,
+                 int32_t cap, int32_t *d_hits, int32_t *d_hits_n, int32_t ns, hipStream_t st,
+                 const QByVal *byval = nullptr) {
+    static const QByVal kNoQuery = {};
+    const Index &ix = c->ix;
+    hipLaunchKernelGGL(ts_match_index_kernel, dim3((unsigned)Q), dim3(kIxBlock), ix_lds_bytes(max_query_len), st,
+                       ix.dir.p, ix.dir_log2, ix.post.p, ix.ivid.p, ix.n_main, d_queries, d_q_offsets,
+                       max_query_len, min_match, d_exclude_ids, exclude_one, cap, d_hits, d_hits_n, ns,
+                       byval ? *byval : kNoQuery);
+    TVZ_HIP(hipGetLastError());
+    return TVZ_OK;
+}
+
+int launch_match(tvz_corpus *c, const double *d_queries, const int64_t *d_q_offsets, int32_t Q,
+                 int32_t max_query_len, int32_t min_match, const int32_t *d_exclude_ids,
+                 int32_t cap, int32_t *d_hits, int32_t *d_hits_n, int32_t ns, unsigned char *ws,
+                 size_t ws_bytes, int32_t algo, hipStream_t st) {
+    if (max_query_len > kMaxQueryLen)
+        return tvz::fail(TVZ_ERR_UNSUPPORTED, "query of %d timestamps exceeds the supported %d",
+                         max_query_len, kMaxQueryLen);
+    TVZ_REQUIRE(algo >= TVZ_ALGO_AUTO && algo <= TVZ_ALGO_INDEX, "unknown algo %d", algo);
+    if (int rc = wait_mutations(c, st)) return rc;
+    RowSpan span{c->rows.p, (int64_t)c->h_rows.size()};
+    bool zero_counts = true;
+    if (algo == TVZ_ALGO_INDEX && !index_usable(c, min_match))
+        return tvz::fail(TVZ_ERR_UNSUPPORTED, "TVZ_ALGO_INDEX: %s", c->ix.valid
+                             ? "the index answers min_match 1..5 only" : "this corpus has no index (tvz_corpus_build_index)");
+    if ((algo == TVZ_ALGO_AUTO || algo == TVZ_ALGO_INDEX) && index_usable(c, min_match) && Q > 0) {
+        // unchanged rows through the index, rows added or replaced since its build through a sweep
+        // of the delta table - a row is in exactly one of the two
+        if (int rc = launch_index(c, d_queries, d_q_offsets, Q, max_query_len, min_match, d_exclude_ids, -1,
+                                  cap, d_hits, d_hits_n, ns, st))
+            return rc;
+        if (c->ix.n_delta == 0) return TVZ_OK;
+        span = RowSpan{c->ix.drows.p, c->ix.n_delta};
+        zero_counts = false;
+        algo = TVZ_ALGO_AUTO;
+    }
+    int a = pick_algo(algo, Q, span.n, max_query_len, min_match);
+    // AUTO never fails for want of scratch: without the join's tables it takes the LDS tile
+    if (a == TVZ_ALGO_JOIN && algo == TVZ_ALGO_AUTO && (ws == nullptr || ws_bytes < join_shape(Q, max_query_len).bytes()))
+        a = TVZ_ALGO_TILE;
+    return launch_scan(c, span, a, zero_counts, d_queries, d_q_offsets, Q, max_query_len, min_match,
+                       d_exclude_ids, cap, d_hits, d_hits_n, ns, ws, ws_bytes, st);
 }
 
 int launch_topk_local(const int32_t *d_hits, const int32_t *d_hits_n, int32_t ns, int32_t Q, int32_t cap,
@@ -580,6 +726,8 @@ static int tvz_corpus_create_impl(tvz_corpus **out, int device) {
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)kTileLds));
     TVZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(ts_match_join_kernel),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)kJoinLds));
+    TVZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(ts_match_index_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)ix_lds_bytes(kMaxQueryLen)));
     const int q1max = (int)q1_lds_bytes(kQ1MaxLog2);
 #define TVZ_Q1_ATTR(M, H)                                                                     \
     TVZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(ts_match_q1_kernel<M, H>),       \
@@ -618,6 +766,11 @@ static int tvz_corpus_destroy_impl(tvz_corpus *c) {
         }
         if (c->keys.p) (void)hipFree(c->keys.p);
         if (c->rows.p) (void)hipFree(c->rows.p);
+        if (c->ix.dir.p) (void)hipFree(c->ix.dir.p);
+        if (c->ix.post.p) (void)hipFree(c->ix.post.p);
+        if (c->ix.ivid.p) (void)hipFree(c->ix.ivid.p);
+        if (c->ix.drows.p) (void)hipFree(c->ix.drows.p);
+        if (c->ix.info) (void)hipFree(c->ix.info);
         for (int i = 0; i < tvz_corpus::kEvents; ++i)
             if (c->events[i]) (void)hipEventDestroy(c->events[i]);
         if (c->mut_done) (void)hipEventDestroy(c->mut_done);
@@ -673,7 +826,10 @@ static int tvz_corpus_upload_impl(tvz_corpus *c, const int32_t *h_video_ids,
     // room for the table to double before anything has to grow
     const int64_t want_rows = 2 * n_rows + 1024, want_keys = 2 * (int64_t)c->h_keys.size() + 65536;
     if (int rc = upload_all(c, want_rows, want_keys)) return rc;
-    return reserve_locked(c, want_rows, want_keys);
+    if (int rc = reserve_locked(c, want_rows, want_keys)) return rc;
+    // a failed index build leaves the corpus without one (every match sweeps): not an upload error
+    (void)build_index(c);
+    return TVZ_OK;
 }
 
 static int tvz_corpus_upsert_impl(tvz_corpus *c, int32_t video_id, const double *h_keys, int64_t n) {
@@ -705,11 +861,35 @@ static int tvz_corpus_upsert_impl(tvz_corpus *c, int32_t video_id, const double 
         c->h_rows[r] = new_row;
     }
     c->live_keys += len - (is_new ? 0 : old_row.len);
+    // with an index: the row's current entry also goes to the delta table (which the sweeps read),
+    // and an indexed row that changes for the first time has its stale postings marked dead
+    Index &ix = c->ix;
+    int32_t slot = -1;
+    bool slot_new = false;
+    if (ix.valid) {
+        auto ds = ix.delta_slot.find(r);
+        if (ds != ix.delta_slot.end()) {
+            slot = ds->second;
+        } else if (ix.n_delta < ix.drows.cap) {
+            slot = (int32_t)ix.n_delta++;
+            slot_new = true;
+            ix.delta_slot.emplace(r, slot);
+        }
+    }
+    // no room in the delta table (it is sized at max(4096, rows / 8)), or a corpus grown by upserts
+    // reached the size for its first index: rebuild after this write
+    const bool ix_rebuild = ix.valid ? slot < 0
+                                     : (int64_t)c->h_rows.size() >= std::max(kIndexMinRows, c->ix_next_try_rows);
     auto rollback = [&]() {
         c->h_keys.resize((size_t)off);
         c->live_keys -= len - (is_new ? 0 : old_row.len);
         if (is_new) { c->h_rows.pop_back(); c->first_row.erase(video_id); }
         else c->h_rows[r] = old_row;
+        if (slot_new) { ix.delta_slot.erase(r); --ix.n_delta; }
+    };
+    auto rebuild_index = [&]() {
+        c->ix_next_try_rows = 2 * (int64_t)c->h_rows.size();   // if this build fails: not at every upsert
+        (void)build_index(c);
     };
     // garbage-collect the arena when more than half of it is dead, or grow what is full: the only
     // paths that wait for matches in flight (amortised: reservations double)
@@ -721,7 +901,9 @@ static int tvz_corpus_upsert_impl(tvz_corpus *c, int32_t video_id, const double 
         if (!rc && !gc) rc = upload_all(c, 2 * (int64_t)c->h_rows.size() + 1024,
                                         2 * (int64_t)c->h_keys.size() + 65536);
         if (!rc) rc = reserve_locked(c, 2 * (int64_t)c->h_rows.size() + 1024, 0);
-        if (rc) rollback();
+        if (rc) { rollback(); index_drop(c); return rc; }
+        // compaction moved every row's keys: the delta table's offsets are stale - start afresh
+        if (ix.valid || ix_rebuild) rebuild_index();
         return rc;
     }
     // fast path: payload -> pinned ring slot -> async copy into FRESH arena space -> 16-byte row
@@ -751,7 +933,11 @@ static int tvz_corpus_upsert_impl(tvz_corpus *c, int32_t video_id, const double 
         }
         s.pending = true;
     }
-    hipLaunchKernelGGL(ts_row_write_kernel, dim3(1), dim3(1), 0, c->mstream, c->rows.p + r, new_row);
+    if (slot >= 0)
+        hipLaunchKernelGGL(ts_row_write3_kernel, dim3(1), dim3(1), 0, c->mstream, c->rows.p + r, ix.drows.p + slot,
+                           (slot_new && r < ix.n_main) ? ix.ivid.p + r : nullptr, new_row);
+    else
+        hipLaunchKernelGGL(ts_row_write_kernel, dim3(1), dim3(1), 0, c->mstream, c->rows.p + r, new_row);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipEventRecord(c->mut_done, c->mstream);
     if (e != hipSuccess) {
@@ -759,6 +945,10 @@ static int tvz_corpus_upsert_impl(tvz_corpus *c, int32_t video_id, const double 
         return tvz::fail(TVZ_ERR_HIP, "upsert row swap failed: %s", hipGetErrorString(e));
     }
     c->mut_any = true;
+    if (ix_rebuild) {
+        if (int rc = drain(c)) return rc;
+        rebuild_index();
+    }
     return TVZ_OK;
 }
 
@@ -771,6 +961,8 @@ static int tvz_corpus_clear_impl(tvz_corpus *c) {
     c->h_rows.clear();
     c->first_row.clear();
     c->live_keys = 0;
+    index_drop(c);
+    c->ix_next_try_rows = 0;
     return TVZ_OK;
 }
 
@@ -781,6 +973,28 @@ static int tvz_corpus_stats_impl(tvz_corpus *c, int64_t *n_rows, int64_t *n_keys
     if (n_rows) *n_rows = (int64_t)c->h_rows.size();
     if (n_keys) *n_keys = c->live_keys;
     if (arena_keys) *arena_keys = (int64_t)c->h_keys.size();
+    return TVZ_OK;
+}
+
+static int tvz_corpus_build_index_impl(tvz_corpus *c) {
+    TVZ_REQUIRE(c != nullptr, "corpus is NULL");
+    DeviceGuard dg(c->device);
+    std::unique_lock<std::shared_mutex> lk(c->mu);
+    if (int rc = drain(c)) return rc;
+    c->ix_next_try_rows = 2 * (int64_t)c->h_rows.size();
+    return build_index(c);
+}
+
+static int tvz_corpus_index_stats_impl(tvz_corpus *c, int64_t *n_indexed, int64_t *n_delta, int64_t *n_post,
+                                       int64_t *n_distinct, int64_t *n_builds) {
+    TVZ_REQUIRE(c != nullptr, "corpus is NULL");
+    std::shared_lock<std::shared_mutex> lk(c->mu);
+    const Index &ix = c->ix;
+    if (n_indexed) *n_indexed = ix.valid ? ix.n_main : 0;
+    if (n_delta) *n_delta = ix.valid ? ix.n_delta : 0;
+    if (n_post) *n_post = ix.valid ? ix.n_post : 0;
+    if (n_distinct) *n_distinct = ix.valid ? ix.n_distinct : 0;
+    if (n_builds) *n_builds = ix.builds;
     return TVZ_OK;
 }
 
@@ -870,48 +1084,76 @@ static int tvz_find_duplicates_impl(tvz_corpus *c, const double *h_query, int64_
             memcpy(s->h_query + 2, h_query, (size_t)n * 8);
             TVZ_HIP(hipMemcpyAsync(s->d_query, s->h_query, (size_t)(n + 2) * 8, hipMemcpyHostToDevice, s->stream));
         }
-        int blocks = 0, region = 0;
-        {
-            std::shared_lock<std::shared_mutex> lk(c->mu);
-            const int64_t n_rows = (int64_t)c->h_rows.size();
-            if (n_rows) {
-                if (n_rows > c->stage_rows || n_rows + (int64_t)kQ1MaxBlocks * kQ1Groups > s->hit_slots) {
-                    // the corpus outgrew its reservation (see tvz_corpus_reserve): grow this staging
-                    if (int rc = staging_size(s, std::max<int64_t>(2 * n_rows, c->stage_rows))) return rc;
-                }
-                if (int rc = wait_mutations(c, s->stream)) return rc;
-                blocks = q1_blocks(n_rows, 1);
-                region = (int)(tvz::ceil_div(n_rows, (int64_t)blocks * kQ1Groups) * kQ1Groups);
-                const HostOut ho{s->dh_hits, s->dh_counts, region};
-                s->busy.store(1, std::memory_order_release);         // drain() waits for this sweep
-                if (int rc = launch_q1<true>(c, by_value ? nullptr : reinterpret_cast<const double *>(s->d_query + 2),
-                                             by_value ? nullptr : s->d_query, 1, (int32_t)n, min_match, nullptr,
-                                             excl, 0, nullptr, nullptr, 1, blocks, ho, s->stream,
-                                             by_value ? &qv : nullptr)) {
-                    s->busy.store(0, std::memory_order_release);
-                    return rc;
-                }
-            }
-        }
-        // (polling the per-block counts from the host instead was tried: it needs a system-scope
-        // release per block, which saved 1.5 us at 5k rows and cost 60 us at 100k)
-        {
-            const hipError_t e = hipStreamSynchronize(s->stream);
-            if (e != hipSuccess) {
-                s->busy.store(0, std::memory_order_release);
-                return tvz::fail(TVZ_ERR_HIP, "single-query sweep failed: %s", hipGetErrorString(e));
-            }
-        }
-        s->busy.store(0, std::memory_order_release);
-        // compact the per-block regions in place (block order; sorted below anyway)
         Hit *hh = reinterpret_cast<Hit *>(s->h_hits);
         int64_t w = 0;
-        for (int b = 0; b < blocks; ++b) {
-            const int32_t nb = s->h_counts[b];
-            if (nb < 0) return tvz::fail(TVZ_ERR_INVALID, "internal: query table overflow");
-            const Hit *src = hh + (int64_t)b * region;
-            if (src != hh + w) memmove(hh + w, src, (size_t)nb * sizeof(Hit));
-            w += nb;
+        // with an index: rows unchanged since its build are answered by the lookup kernel (one
+        // block), rows in the delta table by the sweep - both write to pinned host memory, one
+        // synchronisation for the two.  A query the lookup refuses (> 4 G postings) is swept.
+        for (int attempt = 0; attempt < 2; ++attempt) {
+            int blocks = 0, region = 0;
+            bool used_index = false;
+            {
+                std::shared_lock<std::shared_mutex> lk(c->mu);
+                const int64_t n_rows = (int64_t)c->h_rows.size();
+                if (n_rows) {
+                    if (n_rows > c->stage_rows || n_rows + (int64_t)kQ1MaxBlocks * kQ1Groups > s->hit_slots ||
+                        n_rows > s->ix_slots) {
+                        // the corpus outgrew its reservation (see tvz_corpus_reserve): grow this staging
+                        if (int rc = staging_size(s, std::max<int64_t>(2 * n_rows, c->stage_rows))) return rc;
+                        hh = reinterpret_cast<Hit *>(s->h_hits);
+                    }
+                    if (int rc = wait_mutations(c, s->stream)) return rc;
+                    const double *dq = by_value ? nullptr : reinterpret_cast<const double *>(s->d_query + 2);
+                    const int64_t *dqo = by_value ? nullptr : s->d_query;
+                    RowSpan span{c->rows.p, n_rows};
+                    s->busy.store(1, std::memory_order_release);         // drain() waits for this sweep
+                    if (attempt == 0 && index_usable(c, min_match)) {
+                        used_index = true;
+                        if (int rc = launch_index(c, dq, dqo, 1, (int32_t)n, min_match, nullptr, excl,
+                                                  (int32_t)std::min<int64_t>(s->ix_slots, INT32_MAX), s->dh_ix_hits,
+                                                  s->dh_counts + kQ1MaxBlocks, 1, s->stream, by_value ? &qv : nullptr)) {
+                            s->busy.store(0, std::memory_order_release);
+                            return rc;
+                        }
+                        span = RowSpan{c->ix.drows.p, c->ix.n_delta};
+                    }
+                    if (span.n) {
+                        blocks = q1_blocks(span.n, 1);
+                        region = (int)(tvz::ceil_div(span.n, (int64_t)blocks * kQ1Groups) * kQ1Groups);
+                        const HostOut ho{s->dh_hits, s->dh_counts, region};
+                        if (int rc = launch_q1<true>(c, span, dq, dqo, 1, (int32_t)n, min_match, nullptr, excl, 0,
+                                                     nullptr, nullptr, 1, blocks, ho, s->stream,
+                                                     by_value ? &qv : nullptr)) {
+                            s->busy.store(0, std::memory_order_release);
+                            return rc;
+                        }
+                    }
+                }
+            }
+            // (polling the per-block counts from the host instead was tried: it needs a system-scope
+            // release per block, which saved 1.5 us at 5k rows and cost 60 us at 100k)
+            {
+                const hipError_t e = hipStreamSynchronize(s->stream);
+                s->busy.store(0, std::memory_order_release);
+                if (e != hipSuccess)
+                    return tvz::fail(TVZ_ERR_HIP, "single-query match failed: %s", hipGetErrorString(e));
+            }
+            if (used_index && s->h_counts[kQ1MaxBlocks] < 0) continue;     // refused: sweep everything
+            // compact the per-block regions in place (block order; sorted below anyway)
+            w = 0;
+            for (int b = 0; b < blocks; ++b) {
+                const int32_t nb = s->h_counts[b];
+                if (nb < 0) return tvz::fail(TVZ_ERR_INVALID, "internal: query table overflow");
+                const Hit *src = hh + (int64_t)b * region;
+                if (src != hh + w) memmove(hh + w, src, (size_t)nb * sizeof(Hit));
+                w += nb;
+            }
+            if (used_index) {
+                const int64_t n_ix = std::min<int64_t>(s->h_counts[kQ1MaxBlocks], s->ix_slots);
+                if (n_ix) memcpy(hh + w, s->h_ix_hits, (size_t)n_ix * sizeof(Hit));
+                w += n_ix;
+            }
+            break;
         }
         found = hh;
         n_found = n_have = w;
@@ -980,7 +1222,7 @@ static int tvz_find_duplicates_impl(tvz_corpus *c, const double *h_query, int64_
                                        s->d_hits_n);
                     TVZ_HIP(hipGetLastError());
                 } else {
-                    if (int rc = launch_q1<false>(c, reinterpret_cast<const double *>(d_q + 2), d_q, 1, (int32_t)n,
+                    if (int rc = launch_q1<false>(c, RowSpan{c->rows.p, n_rows}, reinterpret_cast<const double *>(d_q + 2), d_q, 1, (int32_t)n,
                                                   min_match, nullptr, -1, (int32_t)want, s->d_hits, s->d_hits_n, 1,
                                                   q1_blocks(n_rows, 1), HostOut{nullptr, nullptr, 0}, s->stream))
                         return rc;
@@ -1112,6 +1354,15 @@ TVZ_EXPORT int tvz_corpus_upload(tvz_corpus *c, const int32_t *h_video_ids,
                                  const int64_t *h_offsets, const double *h_keys, int64_t n_rows,
                                  int64_t n_keys) {
     TVZ_GUARDED(tvz_corpus_upload_impl(c, h_video_ids, h_offsets, h_keys, n_rows, n_keys));
+}
+
+TVZ_EXPORT int tvz_corpus_build_index(tvz_corpus *c) {
+    TVZ_GUARDED(tvz_corpus_build_index_impl(c));
+}
+
+TVZ_EXPORT int tvz_corpus_index_stats(tvz_corpus *c, int64_t *n_indexed_rows, int64_t *n_delta_rows,
+                                      int64_t *n_postings, int64_t *n_distinct_keys, int64_t *n_builds) {
+    TVZ_GUARDED(tvz_corpus_index_stats_impl(c, n_indexed_rows, n_delta_rows, n_postings, n_distinct_keys, n_builds));
 }
 
 TVZ_EXPORT int tvz_corpus_upsert(tvz_corpus *c, int32_t video_id, const double *h_keys, int64_t n) {
