@@ -172,7 +172,8 @@ int tvz_corpus_stats(tvz_corpus *c, int64_t *n_rows, int64_t *n_keys, int64_t *a
  * exceeds max(4096, indexed rows / 8), and by this call.  A build waits for matches in flight.
  * A corpus with >= 2^32 keys (per GPU) gets no index and is swept. */
 int tvz_corpus_build_index(tvz_corpus *c);
-/* indexed rows / rows in the delta table / postings / distinct keys / builds so far (any may be NULL);
+/* indexed rows / rows in the delta table / postings / most distinct keys in one sub-index of 32768
+ * rows / builds so far (any may be NULL);
  * all 0 while there is no index. */
 int tvz_corpus_index_stats(tvz_corpus *c, int64_t *n_indexed_rows, int64_t *n_delta_rows,
                            int64_t *n_postings, int64_t *n_distinct_keys, int64_t *n_builds);

@@ -8,6 +8,10 @@ counter row can be attributed by kernel name alone:
      tile   : C=100k x Q=64, min_match 2, forced LDS tile kernel                       tag C100000_Q64
      topk   : C=100k x Q=4096 match_topk (sweep + select top-k) + merge                tag C100000_Q4096
      shard8 : rank 0's 1/8 shard (12.5k rows) x Q=4096, match_topk + merge              tag C12500_Q4096
+     index  : C=100k x Q=4096, inverted-index lookup (ts_match_index_kernel)           tag C100000_Q4096
+     index1 : C=100k x Q=1 lookup + find_duplicates latency                            tag C100000_Q1
+     index1_5k : the same at C=5k                                                      tag C5000_Q1
+   topk / shard8 take the index too (AUTO); `join`, `tile`, `q1_*` force the sweep kernels.
 Prints one JSON line with the event-timed median of the call."""
 import json
 import os
@@ -26,7 +30,9 @@ MM = int(sys.argv[3]) if len(sys.argv) > 3 else 2
 dev = torch.device("cuda:0")
 C, Q, algo = {"join": (100000, 4096, _lib.ALGO_JOIN), "q1_100k": (100000, 1, _lib.ALGO_Q1),
               "q1_5k": (5000, 1, _lib.ALGO_Q1), "tile": (100000, 64, _lib.ALGO_TILE),
-              "topk": (100000, 4096, _lib.ALGO_AUTO), "shard8": (100000, 4096, _lib.ALGO_AUTO)}[which]
+              "topk": (100000, 4096, _lib.ALGO_AUTO), "shard8": (100000, 4096, _lib.ALGO_AUTO),
+              "index": (100000, 4096, _lib.ALGO_INDEX), "index1": (100000, 1, _lib.ALGO_INDEX),
+              "index1_5k": (5000, 1, _lib.ALGO_INDEX)}[which]
 ids, offs, keys = synth.synth_timestamp_corpus(C, seed=synth.CORPUS_SEED)
 queries = synth.synth_queries(ids, offs, keys, max(Q, 64), seed=synth.CORPUS_SEED + 1)
 dc = tc.DeviceCorpus(0)
@@ -57,7 +63,7 @@ for r in range(reps):
     ts.append(a.elapsed_time(b))
 res = {"workload": which, "C": C, "Q": Q, "min_match": MM, "median_ms": round(float(np.median(ts[2:])), 4),
        "hits": int(n.sum().item()) if which not in ("topk", "shard8") else None}
-if which == "q1_5k":
+if which in ("q1_5k", "index1", "index1_5k"):     # find_duplicates takes the index when there is one
     lat = []
     for i in range(200):
         t = time.perf_counter()
@@ -65,6 +71,7 @@ if which == "q1_5k":
         lat.append(time.perf_counter() - t)
     res["find_duplicates_us"] = round(float(np.median(lat[20:])) * 1e6, 1)
     res["find_duplicates_p10_p90_us"] = [round(float(np.percentile(lat[20:], p)) * 1e6, 1) for p in (10, 90)]
+res["index"] = dc.index_stats()
 rows, nkeys, _ = dc.stats()
 res["corpus_image_bytes"] = 16 * rows + 8 * nkeys
 print(json.dumps(res))

@@ -4,24 +4,30 @@
 // query elements are `in` the row.  The sweep kernels answer by reading every row; the index
 // answers from the other side: for every query element, which rows contain it.
 //
-//   dir  : open-addressing directory of the DISTINCT canonical keys of the indexed rows,
-//          16 B per entry {key, first posting, number of postings}, load <= 0.5
-//   post : posting lists, one uint32 row index per (row, key) pair, contiguous per key
+// The indexed rows are cut into SUB-INDEXES of 2^15 rows.  Per sub-index:
+//   dir  : open-addressing directory of the distinct canonical keys of its rows, 16 B per entry
+//          {key, first posting, number of postings}, load <= 0.5 (all directories the same size)
+//   post : posting lists, one uint16 LOCAL row number per (row, key) pair, contiguous per key
+// and over all of them
 //   ivid : video_id per indexed row; -1 once the row was replaced by an upsert (its postings are
 //          then stale and ignored; the row's current content lives in the delta table, which the
-//          sweep kernels read)
+//          sweep kernels read).
 //
-// A query of n elements with p postings in total costs n directory probes + 2 p posting reads,
-// whatever the corpus size: ~9,000 postings (36 KB) per query on the config-4 corpus against
-// 160 MB for a sweep.  Counting per (query, row) pair happens in LDS, one block per query:
+// One block per (query, sub-index).  A query of n elements whose keys have p postings in the
+// sub-index costs n directory probes + 2 p two-byte posting reads, whatever the corpus size
+// (config 4: ~32,000 postings = 64 KB per query over 4 sub-indexes, against 160 MB for a sweep):
 //   pass A  every posting sets its row's bit in `seen1`, or in `seen2` if seen1 was set already:
-//           only rows in seen2 (seen1 for min_match 1) can reach min_match;
-//   pass B  the postings are walked again and the candidates' (count, five smallest query
-//           positions) are accumulated in an LDS hash table keyed by row index - in P parts (by a
-//           hash of the row) when there are more candidates than the table holds;
-//   emit    rows with count >= min_match: (video_id, count, kth) exactly as the sweeps emit them.
-// Rows beyond the bitmap size share bits (row mod bits): a shared bit only adds candidates, counts
-// come from the table, which is keyed by the row itself.
+//           only rows in seen2 (seen1 for min_match 1) can reach min_match; the bitmaps cover the
+//           sub-index exactly (32,768 bits), so the candidates are known row by row;
+//   rank    prefix popcount of the candidate bitmap: candidate -> dense slot, no hashing;
+//   pass B  the postings are walked again; a candidate's (count, five smallest query positions)
+//           accumulate in its slot - 2,048 slots at a time if there are more candidates; the walk
+//           reads the (row, position) pairs pass A left in LDS, not the posting lists again;
+//   emit    candidates with count >= min_match, (video_id, count, kth) exactly as the sweeps emit
+//           them: one reservation per block in the query's hit list (or the block's own region of
+//           pinned host memory for tvz_find_duplicates).
+// The walks are laid out so that every wave owns a contiguous range of the flattened postings:
+// consecutive lanes read consecutive postings and a lane's list pointer only moves forward.
 //
 // Build (on the corpus' mutation stream, readers drained): count postings per key with
 // find-or-insert, hand out posting ranges with one atomic per wave, fill.  No sort.
@@ -39,18 +45,26 @@ static_assert(sizeof(DirEnt) == 16, "DirEnt must be 16 bytes");
 
 struct IxBuildInfo {       // device-side build status, read back by the host
     uint32_t cursor;       // postings handed out
-    uint32_t distinct;     // directory entries in use
-    uint32_t failed;       // a probe sequence ran too long: directory too small, rebuild larger
+    uint32_t max_distinct; // most directory entries in use in one sub-index
+    uint32_t failed;       // a probe sequence ran too long: directories too small, rebuild larger
     uint32_t pad;
 };
 
 constexpr int kIxMaxProbe = 4096;
+#ifndef TVZ_IX_SUB_LOG2
+#define TVZ_IX_SUB_LOG2 14
+#endif
+constexpr int kSubLog2 = TVZ_IX_SUB_LOG2;            // rows per sub-index (local row numbers are uint16)
+constexpr int kSubRows = 1 << kSubLog2;
 
 __device__ __forceinline__ uint32_t ix_slot(int64_t k, int dir_log2) {
     return (q1_mix(k) * 0x9E3779B1u) >> (32 - dir_log2);
 }
 
-__global__ __launch_bounds__(kBlock) void ix_clear_kernel(DirEnt *__restrict__ dir, size_t n, IxBuildInfo *info) {
+// directories = every key free; per-sub-index distinct counters = 0
+__global__ __launch_bounds__(kBlock) void ix_clear_kernel(DirEnt *__restrict__ dir, size_t n,
+                                                          uint32_t *__restrict__ sub_distinct, int n_sub,
+                                                          IxBuildInfo *info) {
     const size_t i0 = (size_t)blockIdx.x * kBlock + threadIdx.x, step = (size_t)gridDim.x * kBlock;
     int4 e;
     e.x = (int32_t)(uint32_t)(uint64_t)kEmpty;
@@ -58,7 +72,8 @@ __global__ __launch_bounds__(kBlock) void ix_clear_kernel(DirEnt *__restrict__ d
     e.z = 0;
     e.w = 0;
     for (size_t i = i0; i < n; i += step) reinterpret_cast<int4 *>(dir)[i] = e;
-    if (i0 == 0) { info->cursor = 0; info->distinct = 0; info->failed = 0; info->pad = 0; }
+    for (size_t i = i0; i < (size_t)n_sub; i += step) sub_distinct[i] = 0;
+    if (i0 == 0) { info->cursor = 0; info->max_distinct = 0; info->failed = 0; info->pad = 0; }
 }
 
 // find (or, with INSERT, claim) the directory entry of key k; returns the slot or -1
@@ -69,7 +84,7 @@ __device__ __forceinline__ int64_t ix_find(DirEnt *dir, int dir_log2, int64_t k,
     is_new = false;
     for (int probes = 0; probes < kIxMaxProbe; ++probes) {
         // look first: keys only ever go from free to taken, a stale view is corrected by the CAS
-        int64_t cur = *reinterpret_cast<volatile int64_t *>(&dir[s].key);
+        const int64_t cur = INSERT ? *reinterpret_cast<volatile int64_t *>(&dir[s].key) : dir[s].key;
         if (cur == k) return s;
         if (cur == kEmpty) {
             if (!INSERT) return -1;
@@ -87,27 +102,29 @@ __device__ __forceinline__ int64_t ix_find(DirEnt *dir, int dir_log2, int64_t k,
 __global__ __launch_bounds__(kBlock) void ix_count_kernel(const Row *__restrict__ rows, int64_t n_rows,
                                                           const int64_t *__restrict__ keys, DirEnt *dir,
                                                           int dir_log2, int32_t *__restrict__ ivid,
+                                                          uint32_t *__restrict__ sub_distinct,
                                                           IxBuildInfo *info) {
-    __shared__ uint32_t s_new;
-    if (threadIdx.x == 0) s_new = 0;
-    __syncthreads();
     const int lane = threadIdx.x & 63;
-    uint32_t mine = 0;
     for (int64_t r = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6); r < n_rows;
          r += (int64_t)gridDim.x * (kBlock / 64)) {
         const Row row = load_row(rows + r);
         if (lane == 0) ivid[r] = row.vid;
+        DirEnt *d = dir + ((size_t)(r >> kSubLog2) << dir_log2);
+        uint32_t mine = 0;
         for (int i = lane; i < row.len; i += 64) {
             bool is_new;
-            const int64_t s = ix_find<true>(dir, dir_log2, keys[row.off + i], is_new);
+            const int64_t s = ix_find<true>(d, dir_log2, keys[row.off + i], is_new);
             if (s < 0) { info->failed = 1; continue; }
-            atomicAdd(&dir[s].len, 1u);
+            atomicAdd(&d[s].len, 1u);
             mine += is_new ? 1u : 0u;
         }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o);
+        if (lane == 0 && mine) {
+            const uint32_t now = atomicAdd(&sub_distinct[r >> kSubLog2], mine) + mine;
+            atomicMax(&info->max_distinct, now);
+        }
     }
-    if (mine) atomicAdd(&s_new, mine);
-    __syncthreads();
-    if (threadIdx.x == 0 && s_new) atomicAdd(&info->distinct, s_new);
 }
 
 // hand out posting ranges: off = END of the range (the fill pass counts it down to the start)
@@ -130,17 +147,18 @@ __global__ __launch_bounds__(kBlock) void ix_offsets_kernel(DirEnt *dir, size_t 
 
 __global__ __launch_bounds__(kBlock) void ix_fill_kernel(const Row *__restrict__ rows, int64_t n_rows,
                                                          const int64_t *__restrict__ keys, DirEnt *dir,
-                                                         int dir_log2, uint32_t *__restrict__ post) {
+                                                         int dir_log2, uint16_t *__restrict__ post) {
     const int lane = threadIdx.x & 63;
     for (int64_t r = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6); r < n_rows;
          r += (int64_t)gridDim.x * (kBlock / 64)) {
         const Row row = load_row(rows + r);
+        DirEnt *d = dir + ((size_t)(r >> kSubLog2) << dir_log2);
         for (int i = lane; i < row.len; i += 64) {
             bool is_new;
-            const int64_t s = ix_find<false>(dir, dir_log2, keys[row.off + i], is_new);
+            const int64_t s = ix_find<false>(d, dir_log2, keys[row.off + i], is_new);
             if (s < 0) continue;                       // cannot happen after a successful count pass
-            const uint32_t p = atomicSub(&dir[s].off, 1u) - 1u;
-            post[p] = (uint32_t)r;
+            const uint32_t p = atomicSub(&d[s].off, 1u) - 1u;
+            post[p] = (uint16_t)(r & (kSubRows - 1));
         }
     }
 }
@@ -158,59 +176,80 @@ __global__ void ts_row_write3_kernel(Row *dst, Row *delta_dst, int32_t *ivid_dea
     if (ivid_dead) *ivid_dead = -1;
 }
 
-// ---- lookup: one block per query ---------------------------------------------------------------
-constexpr int kIxBlock = 1024;
-constexpr int kIxBitsLog2 = 17;                      // 2 x 16 KiB of bitmaps
-constexpr int kIxTableLog2 = 11;                     // 2048 candidates x 16 B = 32 KiB
-constexpr int kIxTable = 1 << kIxTableLog2;
-constexpr int kIxTableFill = kIxTable * 3 / 4;
-constexpr int kIxMaxTries = 128;                    // longer probe runs mean a crowded table
+// ---- lookup: one block per (query, sub-index) -------------------------------------------------
+#ifndef TVZ_IX_SLOT_BITS
+#define TVZ_IX_SLOT_BITS 10
+#endif
+#ifndef TVZ_IX_CACHE
+#define TVZ_IX_CACHE 4096
+#endif
+constexpr int kIxWords = kSubRows / 32;              // words per bitmap
+constexpr int kIxBlock = kIxWords;                   // one bitmap word per thread
+constexpr int kIxWaves = kIxBlock / 64;
+constexpr int kIxSlotBits = TVZ_IX_SLOT_BITS;
+constexpr int kIxSlots = 1 << kIxSlotBits;           // candidate slots per part (12 B each)
+constexpr int kIxCache = TVZ_IX_CACHE;               // (row, position) of postings kept in LDS between the passes
+static_assert(kSubLog2 <= 16 && kSubLog2 + 12 <= 32 && kSubLog2 + kIxSlotBits <= 32, "packed LDS entries");
 
-// dynamic LDS: [bm1][bm2][tkey][tcnt][ttop][s_off[L]][s_pre[L + 1]]
+// dynamic LDS: [bm1][bm2][rank][tcnt][ttop][elist][cache][s_off[L]][s_pre[L + 1]][s_pos[L]] - 76 KiB + 10 L:
+// two 16-wave blocks (32 waves) per CU for queries of up to ~400 timestamps
 inline size_t ix_lds_bytes(int max_len) {
-    return (size_t)2 * ((size_t)1 << kIxBitsLog2) / 8 + (size_t)kIxTable * 16 + (size_t)(2 * max_len + 2) * 4;
+    return (size_t)3 * kIxWords * 4 + (size_t)kIxSlots * 16 + (size_t)kIxCache * 4 +
+           (size_t)(2 * max_len + 2) * 4 + (size_t)(max_len + 2) * 2;
 }
 
+template <bool HOSTOUT>
 __global__ __launch_bounds__(kIxBlock) void ts_match_index_kernel(
-    const DirEnt *__restrict__ dir, int dir_log2, const uint32_t *__restrict__ post,
+    const DirEnt *__restrict__ dir_all, int dir_log2, const uint16_t *__restrict__ post,
     const int32_t *__restrict__ ivid, int64_t n_indexed, const double *__restrict__ queries,
     const int64_t *__restrict__ q_offsets, int32_t max_len, int32_t min_match,
     const int32_t *__restrict__ exclude_ids, int32_t exclude_one, int32_t cap,
     int32_t *__restrict__ hits, int32_t *__restrict__ hits_n, int32_t ns, const QByVal qv) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int kWords = (1 << kIxBitsLog2) / 32;
     uint32_t *bm1 = reinterpret_cast<uint32_t *>(smem);
-    uint32_t *bm2 = bm1 + kWords;
-    uint32_t *tkey = bm2 + kWords;                                      // row + 1, 0 = free
-    uint32_t *tcnt = tkey + kIxTable;
-    unsigned long long *ttop = reinterpret_cast<unsigned long long *>(tcnt + kIxTable);
-    uint32_t *s_off = reinterpret_cast<uint32_t *>(ttop + kIxTable);
-    uint32_t *s_pre = s_off + max_len;                                  // [n + 1] exclusive prefix of list lengths
-    __shared__ uint32_t s_cand, s_ovf, s_nout, s_big;
-    __shared__ uint32_t s_wsum[kIxBlock / 64];
+    uint32_t *bm2 = bm1 + kIxWords;
+    uint32_t *rank = bm2 + kIxWords;                                    // candidates before word j
+    uint32_t *tcnt = rank + kIxWords;
+    unsigned long long *ttop = reinterpret_cast<unsigned long long *>(tcnt + kIxSlots);
+    uint32_t *elist = reinterpret_cast<uint32_t *>(ttop + kIxSlots);    // emit list of one part
+    uint32_t *pcache = elist + kIxSlots;                                // first kIxCache postings: row | position << kSubLog2
+    uint32_t *s_off = reinterpret_cast<uint32_t *>(pcache + kIxCache);  // first posting of list j
+    uint32_t *s_pre = s_off + max_len;                                  // [m + 1] postings before list j
+    uint16_t *s_pos = reinterpret_cast<uint16_t *>(s_pre + max_len + 1);  // query position of list j
+    __shared__ uint32_t s_wsum[kIxWaves], s_lsum[kIxWaves];
+    __shared__ uint32_t s_base, s_m, s_total, s_nlist;
+    __shared__ int32_t s_emitted;
 
     const int q = blockIdx.x;
+    const int sub = blockIdx.y;
     const bool byval = q_offsets == nullptr;
     const int64_t qo = byval ? 0 : q_offsets[q];
     const int64_t n64 = byval ? qv.n : q_offsets[q + 1] - qo;
-    int32_t *out_n = hits_n + (size_t)q * ns;
+    // HOSTOUT: the block's own hit region [sub][kSubRows][3] and count in pinned host memory
+    int32_t *out_n = HOSTOUT ? hits_n + sub : hits_n + (size_t)q * ns;
+    int32_t *out_hits = HOSTOUT ? hits + (int64_t)sub * kSubRows * 3 : hits + (int64_t)q * cap * 3;
     if (n64 > max_len) {       // max_query_len was not an upper bound (the LDS arrays are sized from it)
         if (threadIdx.x == 0) *out_n = INT32_MIN;
         return;
     }
     const int n = (int)n64;
+#if defined(TVZ_IX_STOP) && TVZ_IX_STOP == 0
+    return;
+#endif
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (threadIdx.x == 0) { s_cand = 0; s_ovf = 0; s_nout = 0; s_big = 0; }
-    for (int i = threadIdx.x; i < kWords; i += kIxBlock) { bm1[i] = 0; bm2[i] = 0; }
-    for (int i = threadIdx.x; i < kIxTable; i += kIxBlock) { tkey[i] = 0; tcnt[i] = 0; ttop[i] = kTopNone; }
+    if (threadIdx.x == 0) { s_m = 0; s_total = 0; s_emitted = 0; s_nlist = 0; }
+    for (int i = threadIdx.x; i < kIxWords; i += kIxBlock) { bm1[i] = 0; bm2[i] = 0; }
+    for (int i = threadIdx.x; i < kIxSlots; i += kIxBlock) { tcnt[i] = 0; ttop[i] = kTopNone; }
+    __syncthreads();
 
-    // ---- directory: posting list of every query position (NaN / absent key: empty list) ----
+    // ---- directory: the NON-EMPTY posting lists of the query's positions, compacted ----
+    const DirEnt *dir = dir_all + ((size_t)sub << dir_log2);
     const uint32_t dmask = (1u << dir_log2) - 1u;
     for (int i0 = 0; i0 < n; i0 += kIxBlock) {
         const int i = i0 + threadIdx.x;
         uint32_t off = 0, len = 0;
         int64_t k;
-        if (i < n && canon_key(byval ? qv.k[i] : queries[qo + i], k)) {
+        if (i < n && canon_key(byval ? qv.k[i] : queries[qo + i], k)) {   // NaN never matches
             uint32_t s = ix_slot(k, dir_log2);
             for (int probes = 0; probes < kIxMaxProbe; ++probes) {
                 const int4 e = *reinterpret_cast<const int4 *>(dir + s);
@@ -220,161 +259,210 @@ __global__ __launch_bounds__(kIxBlock) void ts_match_index_kernel(
                 s = (s + 1) & dmask;
             }
         }
-        // exclusive prefix of len over the block (wave scan + wave sums), carried across chunks
-        uint32_t incl = len;
+        // block-wide exclusive prefixes of (len, len != 0), continued from the previous chunk
+        uint32_t incl = len, lincl = len ? 1u : 0u;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t o = __shfl_up(incl, d), lo = __shfl_up(lincl, d);
+            if (lane >= d) { incl += o; lincl += lo; }
+        }
+        if (lane == 63) { s_wsum[wave] = incl; s_lsum[wave] = lincl; }
+        __syncthreads();
+        uint32_t pbase = s_total, lbase = s_m;
+        for (int w = 0; w < wave; ++w) { pbase += s_wsum[w]; lbase += s_lsum[w]; }
+        if (len) {
+            const uint32_t j = lbase + lincl - 1u;
+            s_off[j] = off;
+            s_pre[j] = pbase + incl - len;
+            s_pos[j] = (uint16_t)i;
+        }
+        __syncthreads();
+        if (threadIdx.x == kIxBlock - 1) { s_total = pbase + incl; s_m = lbase + lincl; }
+        __syncthreads();
+    }
+#if defined(TVZ_IX_STOP) && TVZ_IX_STOP == 1
+    return;
+#endif
+    const int m = (int)s_m;
+    const uint32_t total = s_total;                    // <= 4095 lists x 32768 rows: fits 32 bits
+    if (threadIdx.x == 0) s_pre[m] = total;
+    __syncthreads();
+
+    // every wave owns a contiguous range of the flattened postings; a lane's list pointer only
+    // moves forward (by a bounded binary search when it has to skip short lists)
+    const uint32_t w_lo = (uint32_t)(((unsigned long long)total * wave) / kIxWaves);
+    const uint32_t w_hi = (uint32_t)(((unsigned long long)total * (wave + 1)) / kIxWaves);
+    auto seek = [&](int j, uint32_t t) -> int {        // largest j' >= j with s_pre[j'] <= t
+        if (s_pre[j + 1] > t) return j;
+        int lo = j + 1, hi = m;                        // s_pre[lo] <= t < s_pre[hi] = total
+        if (hi - lo > 64 && s_pre[lo + 64] > t) hi = lo + 64;
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (s_pre[mid] <= t) lo = mid; else hi = mid;
+        }
+        return lo;
+    };
+    // ---- pass A: which rows are touched (twice); eight posting loads in flight per lane ----
+    {
+        int j = 0;
+        for (uint32_t t0 = w_lo; t0 < w_hi; t0 += 512u) {   // 8 x 64 postings
+            uint32_t r[8];
+            uint16_t pj[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                // unconditional (clamped) loads: a branch around a load makes the compiler wait for
+                // every load before it
+                const uint32_t t = t0 + (uint32_t)(u * 64 + lane);
+                const uint32_t tc = t < w_hi ? t : w_hi - 1u;
+                j = seek(j, tc);
+                const uint32_t v = post[s_off[j] + (tc - s_pre[j])];
+                r[u] = t < w_hi ? v : 0xffffffffu;
+                pj[u] = s_pos[j];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (r[u] == 0xffffffffu) continue;
+                const uint32_t t = t0 + (uint32_t)(u * 64 + lane);
+                if (t < (uint32_t)kIxCache) pcache[t] = r[u] | ((uint32_t)pj[u] << kSubLog2);
+                const uint32_t bit = 1u << (r[u] & 31u);
+                const uint32_t old = atomicOr(&bm1[r[u] >> 5], bit);
+                if (min_match >= 2 && (old & bit)) atomicOr(&bm2[r[u] >> 5], bit);
+            }
+        }
+    }
+#if defined(TVZ_IX_STOP) && TVZ_IX_STOP == 2
+    return;
+#endif
+    __syncthreads();
+    const uint32_t *cand = min_match >= 2 ? bm2 : bm1;
+    // ---- rank: candidates before every bitmap word (512 words, one per thread) ----
+    {
+        const uint32_t c = __popc(cand[threadIdx.x]);
+        uint32_t incl = c;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
             const uint32_t o = __shfl_up(incl, d);
             if (lane >= d) incl += o;
         }
-        __syncthreads();                               // s_wsum / s_pre[i0] of the previous chunk are consumed
         if (lane == 63) s_wsum[wave] = incl;
         __syncthreads();
-        uint32_t wbase = (i0 == 0) ? 0u : s_pre[i0];
-        unsigned long long wide = wbase;
-        for (int w = 0; w < wave; ++w) { wbase += s_wsum[w]; wide += s_wsum[w]; }
-        if (wide + incl > 0xffffffffULL) s_big = 1;    // > 4 G postings for one query: not this kernel's job
-        if (i < n) { s_off[i] = off; s_pre[i] = wbase + incl - len; }
-        const int last = (i0 + kIxBlock < n ? i0 + kIxBlock : n) - 1;
-        __syncthreads();
-        if (i == last) s_pre[i + 1] = wbase + incl;
+        uint32_t base = 0;
+        for (int w = 0; w < wave; ++w) base += s_wsum[w];
+        rank[threadIdx.x] = base + incl - c;
+        if (threadIdx.x == kIxBlock - 1) s_base = base + incl;         // candidates in all
         __syncthreads();
     }
-    if (n == 0 && threadIdx.x == 0) s_pre[0] = 0;
-    __syncthreads();
-    if (s_big) {
-        if (threadIdx.x == 0) *out_n = INT32_MIN;
-        return;
-    }
-    const uint32_t total = s_pre[n];
-    constexpr uint32_t bmask = (1u << kIxBitsLog2) - 1u;
-    // posting t of the flattened lists -> (query position, row)
-    auto locate = [&](uint32_t t, int &pos) -> uint32_t {
-        int lo = 0, hi = n;                            // largest pos with s_pre[pos] <= t
-        while (hi - lo > 1) {
-            const int mid = (lo + hi) >> 1;
-            if (s_pre[mid] <= t) lo = mid; else hi = mid;
-        }
-        pos = lo;
-        return post[s_off[lo] + (t - s_pre[lo])];
-    };
-
-    // ---- pass A: which rows are touched twice ----
-    const uint32_t *cand_bm = bm1;
-    if (min_match >= 2) {
-        cand_bm = bm2;
-        for (uint32_t t0 = threadIdx.x; t0 < total; t0 += 4u * kIxBlock) {
-            uint32_t r[4];
-            int pos;
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const uint32_t t = t0 + (uint32_t)u * kIxBlock;
-                r[u] = t < total ? locate(t, pos) : 0xffffffffu;
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                if (r[u] == 0xffffffffu) continue;
-                const uint32_t b = r[u] & bmask, bit = 1u << (b & 31u);
-                const uint32_t old = atomicOr(&bm1[b >> 5], bit);
-                if (old & bit) atomicOr(&bm2[b >> 5], bit);
-            }
-        }
-    } else {
-        for (uint32_t t = threadIdx.x; t < total; t += kIxBlock) {
-            int pos;
-            const uint32_t r = locate(t, pos);
-            const uint32_t b = r & bmask;
-            atomicOr(&bm1[b >> 5], 1u << (b & 31u));
-        }
-    }
-    __syncthreads();
-    {
-        uint32_t c = 0;
-        for (int i = threadIdx.x; i < kWords; i += kIxBlock) c += __popc(cand_bm[i]);
-#pragma unroll
-        for (int d = 32; d > 0; d >>= 1) c += __shfl_xor(c, d);
-        if (lane == 0 && c) atomicAdd(&s_cand, c);
-    }
-    __syncthreads();
-    // parts: enough that a part's candidates fit the table (exact when rows <= bitmap bits; rows
-    // sharing a bit can exceed the estimate - the overflow path below doubles P and starts over)
-    int p_log2 = 0;
-    while (((uint32_t)kIxTableFill << p_log2) < s_cand && p_log2 < 20) ++p_log2;
+    static_assert(kIxWords == kIxBlock, "one bitmap word per thread");
+    static_assert(kIxSlots % kIxBlock == 0, "whole rounds of the block over the emit list");
+#if defined(TVZ_IX_STOP) && TVZ_IX_STOP == 3
+    return;
+#endif
+    const uint32_t n_cand = s_base;
     const int32_t excl = exclude_ids ? exclude_ids[q] : exclude_one;
+    const int64_t row0 = (int64_t)sub << kSubLog2;
 
-    // ---- pass B + emit, part by part ----
-    while (true) {
-        bool restart = false;
-        for (uint32_t part = 0; part < (1u << p_log2); ++part) {
-            for (uint32_t t0 = threadIdx.x; t0 < total; t0 += 4u * kIxBlock) {
-                uint32_t r[4];
-                int pos[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const uint32_t t = t0 + (uint32_t)u * kIxBlock;
-                    pos[u] = 0;
-                    r[u] = t < total ? locate(t, pos[u]) : 0xffffffffu;
+    // ---- pass B + emit, kIxSlots candidates at a time ----
+    for (uint32_t lo = 0; lo < n_cand; lo += kIxSlots) {
+        {
+            int j = 0;
+            for (uint32_t t = w_lo + lane; t < w_hi; t += 64u) {
+                uint32_t r, pos;
+                if (t < (uint32_t)kIxCache) {
+                    const uint32_t e = pcache[t];
+                    r = e & (uint32_t)(kSubRows - 1);
+                    pos = e >> kSubLog2;
+                } else {                                                  // beyond the LDS copy: read it again
+                    j = seek(j, t);
+                    r = post[s_off[j] + (t - s_pre[j])];
+                    pos = s_pos[j];
                 }
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    if (r[u] == 0xffffffffu) continue;
-                    const uint32_t b = r[u] & bmask;
-                    if (!((cand_bm[b >> 5] >> (b & 31u)) & 1u)) continue;
-                    if (p_log2 && ((r[u] * 0x85EBCA6Bu) >> (32 - p_log2)) != part) continue;
-                    uint32_t s = (r[u] * 0x9E3779B1u) >> (32 - kIxTableLog2);
-                    int tries = 0;
-                    for (; tries < kIxMaxTries; ++tries) {
-                        const uint32_t old = atomicCAS(&tkey[s], 0u, r[u] + 1u);
-                        if (old == 0u || old == r[u] + 1u) break;
-                        s = (s + 1) & (uint32_t)(kIxTable - 1);
-                    }
-                    if (tries == kIxMaxTries) { s_ovf = 1; continue; }   // crowded part: split further
-                    atomicAdd(&tcnt[s], 1u);
-                    unsigned long long seen = ttop[s];
-                    while (true) {
-                        if (((uint32_t)(seen >> (12 * (kTop - 1))) & 0xfffu) <= (uint32_t)pos[u]) break;
-                        const unsigned long long old = atomicCAS(&ttop[s], seen, top5_insert(seen, (uint32_t)pos[u]));
-                        if (old == seen) break;
-                        seen = old;
-                    }
+                const uint32_t w = cand[r >> 5], bit = r & 31u;
+                if (!((w >> bit) & 1u)) continue;
+                const uint32_t idx = rank[r >> 5] + __popc(w & ((1u << bit) - 1u)) - lo;
+                if (idx >= (uint32_t)kIxSlots) continue;                 // another part's (wraps below lo)
+                atomicAdd(&tcnt[idx], 1u);
+                unsigned long long seen = ttop[idx];
+                while (true) {
+                    if (((uint32_t)(seen >> (12 * (kTop - 1))) & 0xfffu) <= pos) break;   // not among the 5 smallest
+                    const unsigned long long old = atomicCAS(&ttop[idx], seen, top5_insert(seen, pos));
+                    if (old == seen) break;
+                    seen = old;
                 }
             }
-            __syncthreads();
-            if (s_ovf) { restart = true; }
-            if (!restart) {
-                for (int i = threadIdx.x; i < kIxTable; i += kIxBlock) {
-                    const uint32_t rk = tkey[i];
-                    if (rk == 0u) continue;
-                    const int32_t c = (int32_t)tcnt[i];
-                    if (c >= min_match && (int64_t)(rk - 1u) < n_indexed) {
-                        const int32_t vid = ivid[rk - 1u];
-                        if (vid >= 0 && vid != excl) {
-                            const int32_t kth = (int32_t)((uint32_t)(ttop[i] >> (12 * (min_match - 1))) & 0xfffu);
-                            const uint32_t o = atomicAdd(&s_nout, 1u);
-                            if ((int64_t)o < (int64_t)cap) {
-                                int32_t *hp = hits + ((int64_t)q * cap + o) * 3;
-                                hp[0] = vid;
-                                hp[1] = c;
-                                hp[2] = kth;
-                            }
-                        }
-                    }
-                }
-            }
-            __syncthreads();
-            for (int i = threadIdx.x; i < kIxTable; i += kIxBlock) { tkey[i] = 0; tcnt[i] = 0; ttop[i] = kTopNone; }
-            if (threadIdx.x == 0) s_ovf = 0;
-            __syncthreads();
-            if (restart) break;
         }
-        if (!restart) break;
-        // more candidates in one part than the table holds: twice the parts, from the start (what was
-        // emitted so far is overwritten)
-        if (threadIdx.x == 0) s_nout = 0;
-        ++p_log2;
+#if defined(TVZ_IX_STOP) && TVZ_IX_STOP == 4
+        return;
+#endif
+        __syncthreads();
+        // emit, stage 1: thread <-> bitmap word; candidates of this part that reached min_match go to
+        // an LDS list (row in the sub-index << kIxSlotBits | slot).  Looking their video ids up right here,
+        // bit after bit, was one dependent global load per bit and 60 % of the kernel.
+        {
+            const uint32_t w = cand[threadIdx.x];
+            const uint32_t rk = rank[threadIdx.x];
+            for (uint32_t rest = w, i = 0; rest; rest &= rest - 1, ++i) {
+                const uint32_t idx = rk + i - lo;
+                if (idx >= (uint32_t)kIxSlots || (int32_t)tcnt[idx] < min_match) continue;
+                const uint32_t bit = (uint32_t)__ffs(rest) - 1u;
+                elist[atomicAdd(&s_nlist, 1u)] = ((threadIdx.x * 32u + bit) << kIxSlotBits) | idx;
+            }
+        }
+        __syncthreads();
+        // stage 2: one list entry per thread and round (<= 2 rounds): video id, filters, one
+        // reservation per block, write
+        const uint32_t n_list = s_nlist;
+        uint32_t e[kIxSlots / kIxBlock];
+        int32_t vid[kIxSlots / kIxBlock];
+        uint32_t mine = 0;
+#pragma unroll
+        for (int u = 0; u < kIxSlots / kIxBlock; ++u) {
+            const uint32_t k = (uint32_t)u * kIxBlock + threadIdx.x;
+            e[u] = k < n_list ? elist[k] : 0u;
+            const int64_t row = row0 + (e[u] >> kIxSlotBits);
+            vid[u] = ivid[k < n_list && row < n_indexed ? row : row0];  // unconditional load
+            // replaced since the build (-1) / the query's own video: not a hit
+            if (k >= n_list || row >= n_indexed || vid[u] < 0 || vid[u] == excl) vid[u] = -1;
+            mine += vid[u] >= 0 ? 1u : 0u;
+        }
+        uint32_t incl = mine;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t o = __shfl_up(incl, d);
+            if (lane >= d) incl += o;
+        }
+        if (lane == 63) s_wsum[wave] = incl;
+        __syncthreads();
+        uint32_t base = 0, all = 0;
+        for (int x = 0; x < kIxWaves; ++x) { if (x < wave) base += s_wsum[x]; all += s_wsum[x]; }
+        if (threadIdx.x == 0) {
+            s_base = (HOSTOUT || all == 0) ? (uint32_t)s_emitted : (uint32_t)atomicAdd(out_n, (int32_t)all);
+            s_emitted += (int32_t)all;
+            s_nlist = 0;
+        }
+        __syncthreads();
+#if defined(TVZ_IX_STOP) && TVZ_IX_STOP == 5
+        return;
+#endif
+        uint32_t o = s_base + base + incl - mine;
+        const int64_t room = HOSTOUT ? (int64_t)kSubRows : (int64_t)cap;
+#pragma unroll
+        for (int u = 0; u < kIxSlots / kIxBlock; ++u) {
+            if (vid[u] < 0) continue;
+            const uint32_t idx = e[u] & (uint32_t)(kIxSlots - 1);
+            if ((int64_t)o < room) {
+                int32_t *hp = out_hits + (int64_t)o * 3;
+                hp[0] = vid[u];
+                hp[1] = (int32_t)tcnt[idx];
+                hp[2] = (int32_t)((uint32_t)(ttop[idx] >> (12 * (min_match - 1))) & 0xfffu);
+            }
+            ++o;
+        }
+        __syncthreads();
+        if (lo + kIxSlots < n_cand)
+            for (int i = threadIdx.x; i < kIxSlots; i += kIxBlock) { tcnt[i] = 0; ttop[i] = kTopNone; }
         __syncthreads();
     }
-    if (threadIdx.x == 0) *out_n = (int32_t)s_nout;
+    if (HOSTOUT && threadIdx.x == 0) *out_n = s_emitted;
 }
 
 }  // namespace

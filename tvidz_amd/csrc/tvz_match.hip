@@ -79,9 +79,11 @@ constexpr int64_t kIndexMinRows = 4096;           // a corpus grown by upserts g
 constexpr int64_t kIndexMinDelta = 4096;          // rebuilt when the delta exceeds max(this, n_main / 8)
 
 struct Index {
-    DevBuf<DirEnt> dir;
+    DevBuf<DirEnt> dir;               // n_sub directories of 2^dir_log2 entries
     int dir_log2 = 0;
-    DevBuf<uint32_t> post;
+    int n_sub = 0;                    // sub-indexes of kSubRows rows
+    DevBuf<uint16_t> post;
+    DevBuf<uint32_t> sub_distinct;
     DevBuf<int32_t> ivid;
     DevBuf<Row> drows;
     IxBuildInfo *info = nullptr;      // device
@@ -242,6 +244,7 @@ void index_drop(tvz_corpus *c) {
     Index &ix = c->ix;
     ix.valid = false;
     ix.n_main = ix.n_delta = ix.n_post = ix.n_distinct = 0;
+    ix.n_sub = 0;
     ix.delta_slot.clear();
 }
 
@@ -258,27 +261,31 @@ int build_index(tvz_corpus *c) {
     if (int rc = ensure(ix.post, std::max<int64_t>(c->live_keys, 1), 0)) return rc;
     if (int rc = ensure(ix.ivid, c->rows.cap, 0)) return rc;
     if (int rc = ensure(ix.drows, delta_capacity(n_rows), 0)) return rc;
-    // directory: sized for a guess of the distinct keys (a fingerprint corpus repeats its keys many
-    // times over: 442 k distinct in the 19.9 M of config 4), grown if the guess was too small
-    const int64_t guess = std::min<int64_t>(c->live_keys, std::max<int64_t>((int64_t)1 << 20, c->live_keys / 8));
-    int log2 = 12;
-    while (((int64_t)1 << log2) < 2 * guess) ++log2;
+    // directories (one per sub-index, all the same size): sized for a guess of the distinct keys of a
+    // sub-index - a fingerprint corpus repeats its keys many times over - and grown if too crowded
+    const int n_sub = (int)tvz::ceil_div(n_rows, kSubRows);
+    TVZ_REQUIRE(n_sub <= 65535, "too many rows for the index (%lld)", (long long)n_rows);
+    if (int rc = ensure(ix.sub_distinct, n_sub, 0)) return rc;
+    const int64_t per_sub = tvz::ceil_div(c->live_keys, n_sub);
+    int log2 = 10;
+    while (((int64_t)1 << log2) < per_sub / 2) ++log2;
     const int blocks = (int)std::min<int64_t>(tvz::ceil_div(n_rows, kBlock / 64), 256 * 8);
     IxBuildInfo info{};
     while (true) {
-        TVZ_REQUIRE(log2 <= 31, "index directory would exceed 2^31 entries");
-        const int64_t dn = (int64_t)1 << log2;
+        TVZ_REQUIRE(log2 <= 28, "index directories would exceed 2^28 entries each");
+        const int64_t dn = (int64_t)n_sub << log2;
         if (int rc = ensure(ix.dir, dn, 0)) return rc;
-        hipLaunchKernelGGL(ix_clear_kernel, dim3(1024), dim3(kBlock), 0, st, ix.dir.p, (size_t)dn, ix.info);
+        hipLaunchKernelGGL(ix_clear_kernel, dim3(1024), dim3(kBlock), 0, st, ix.dir.p, (size_t)dn,
+                           ix.sub_distinct.p, n_sub, ix.info);
         hipLaunchKernelGGL(ix_count_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, st, c->rows.p, n_rows,
-                           c->keys.p, ix.dir.p, log2, ix.ivid.p, ix.info);
+                           c->keys.p, ix.dir.p, log2, ix.ivid.p, ix.sub_distinct.p, ix.info);
         TVZ_HIP(hipGetLastError());
         TVZ_HIP(hipMemcpyAsync(&info, ix.info, sizeof(info), hipMemcpyDeviceToHost, st));
         TVZ_HIP(hipStreamSynchronize(st));
-        if (!info.failed && (int64_t)info.distinct * 2 <= dn) break;
-        log2 += 2;                                    // too crowded: four times the directory
+        if (!info.failed && (int64_t)info.max_distinct * 2 <= ((int64_t)1 << log2)) break;
+        ++log2;                                       // too crowded: twice the directories
     }
-    const int64_t dn = (int64_t)1 << log2;
+    const int64_t dn = (int64_t)n_sub << log2;
     hipLaunchKernelGGL(ix_offsets_kernel, dim3((unsigned)tvz::ceil_div(dn, kBlock)), dim3(kBlock), 0, st, ix.dir.p,
                        (size_t)dn, ix.info);
     hipLaunchKernelGGL(ix_fill_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, st, c->rows.p, n_rows, c->keys.p,
@@ -289,10 +296,11 @@ int build_index(tvz_corpus *c) {
     if ((int64_t)info.cursor != c->live_keys)
         return tvz::fail(TVZ_ERR_INVALID, "internal: index holds %u postings for %lld keys", info.cursor,
                          (long long)c->live_keys);
+    ix.n_sub = n_sub;
     ix.dir_log2 = log2;
     ix.n_main = n_rows;
     ix.n_post = info.cursor;
-    ix.n_distinct = info.distinct;
+    ix.n_distinct = info.max_distinct;
     ix.valid = true;
     ++ix.builds;
     return TVZ_OK;
@@ -326,9 +334,15 @@ int staging_size(Staging *s, int64_t rows) {
     if (s->h_ix_hits) (void)hipHostFree(s->h_ix_hits);
     s->h_ix_hits = nullptr;
     s->ix_slots = 0;
-    TVZ_HIP(hipHostMalloc(&s->h_ix_hits, (size_t)std::max<int64_t>(rows, 1) * 12, hipHostMallocMapped));
+    // index lookups: one region of kSubRows hits and one count per sub-index
+    const int64_t subs = tvz::ceil_div(std::max<int64_t>(rows, 1), kSubRows);
+    TVZ_HIP(hipHostMalloc(&s->h_ix_hits, (size_t)subs * kSubRows * 12, hipHostMallocMapped));
     TVZ_HIP(hipHostGetDevicePointer(reinterpret_cast<void **>(&s->dh_ix_hits), s->h_ix_hits, 0));
-    s->ix_slots = std::max<int64_t>(rows, 1);
+    s->ix_slots = subs * kSubRows;
+    if (s->h_counts) (void)hipHostFree(s->h_counts);
+    s->h_counts = nullptr;
+    TVZ_HIP(hipHostMalloc(&s->h_counts, (size_t)(kQ1MaxBlocks + subs) * 4, hipHostMallocMapped));
+    TVZ_HIP(hipHostGetDevicePointer(reinterpret_cast<void **>(&s->dh_counts), s->h_counts, 0));
     return TVZ_OK;
 }
 
@@ -338,8 +352,6 @@ int staging_new(tvz_corpus *c, Staging **out) {
     TVZ_HIP(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
     TVZ_HIP(hipHostMalloc(&s->h_query, (size_t)(kQueryStageKeys + 2) * 8, hipHostMallocDefault));
     TVZ_HIP(hipMalloc(&s->d_query, (size_t)(kQueryStageKeys + 2) * 8));
-    TVZ_HIP(hipHostMalloc(&s->h_counts, (size_t)(kQ1MaxBlocks + 1) * 4, hipHostMallocMapped));   // + the index lookup's
-    TVZ_HIP(hipHostGetDevicePointer(reinterpret_cast<void **>(&s->dh_counts), s->h_counts, 0));
     TVZ_HIP(hipMalloc(&s->d_hits_n, sizeof(int32_t)));
     if (int rc = staging_size(s, c->stage_rows)) return rc;
     g.s = nullptr;
@@ -600,17 +612,19 @@ bool index_usable(const tvz_corpus *c, int32_t min_match) {
     return c->ix.valid && min_match >= 1 && min_match <= kTop;
 }
 
-// index lookup of Q queries (one block each); WRITES every query's counter (no prep launch)
+// index lookup of Q queries, one block per (query, sub-index); the blocks ADD to the queries'
+// counters (zeroed by the caller) - or, HOSTOUT, each writes its own region and count
+template <bool HOSTOUT>
 int launch_index(tvz_corpus *c, const double *d_queries, const int64_t *d_q_offsets, int32_t Q,
                  int32_t max_query_len, int32_t min_match, const int32_t *d_exclude_ids, int32_t exclude_one,
                  int32_t cap, int32_t *d_hits, int32_t *d_hits_n, int32_t ns, hipStream_t st,
                  const QByVal *byval = nullptr) {
     static const QByVal kNoQuery = {};
     const Index &ix = c->ix;
-    hipLaunchKernelGGL(ts_match_index_kernel, dim3((unsigned)Q), dim3(kIxBlock), ix_lds_bytes(max_query_len), st,
-                       ix.dir.p, ix.dir_log2, ix.post.p, ix.ivid.p, ix.n_main, d_queries, d_q_offsets,
-                       max_query_len, min_match, d_exclude_ids, exclude_one, cap, d_hits, d_hits_n, ns,
-                       byval ? *byval : kNoQuery);
+    hipLaunchKernelGGL(ts_match_index_kernel<HOSTOUT>, dim3((unsigned)Q, (unsigned)ix.n_sub), dim3(kIxBlock),
+                       ix_lds_bytes(max_query_len), st, ix.dir.p, ix.dir_log2, ix.post.p, ix.ivid.p, ix.n_main,
+                       d_queries, d_q_offsets, max_query_len, min_match, d_exclude_ids, exclude_one, cap, d_hits,
+                       d_hits_n, ns, byval ? *byval : kNoQuery);
     TVZ_HIP(hipGetLastError());
     return TVZ_OK;
 }
@@ -632,8 +646,9 @@ int launch_match(tvz_corpus *c, const double *d_queries, const int64_t *d_q_offs
     if ((algo == TVZ_ALGO_AUTO || algo == TVZ_ALGO_INDEX) && index_usable(c, min_match) && Q > 0) {
         // unchanged rows through the index, rows added or replaced since its build through a sweep
         // of the delta table - a row is in exactly one of the two
-        if (int rc = launch_index(c, d_queries, d_q_offsets, Q, max_query_len, min_match, d_exclude_ids, -1,
-                                  cap, d_hits, d_hits_n, ns, st))
+        if (int rc = launch_prep(d_hits_n, ns, Q, nullptr, 0, nullptr, 0, st)) return rc;
+        if (int rc = launch_index<false>(c, d_queries, d_q_offsets, Q, max_query_len, min_match, d_exclude_ids,
+                                         -1, cap, d_hits, d_hits_n, ns, st))
             return rc;
         if (c->ix.n_delta == 0) return TVZ_OK;
         span = RowSpan{c->ix.drows.p, c->ix.n_delta};
@@ -726,7 +741,9 @@ static int tvz_corpus_create_impl(tvz_corpus **out, int device) {
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)kTileLds));
     TVZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(ts_match_join_kernel),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)kJoinLds));
-    TVZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(ts_match_index_kernel),
+    TVZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(ts_match_index_kernel<false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)ix_lds_bytes(kMaxQueryLen)));
+    TVZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(ts_match_index_kernel<true>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)ix_lds_bytes(kMaxQueryLen)));
     const int q1max = (int)q1_lds_bytes(kQ1MaxLog2);
 #define TVZ_Q1_ATTR(M, H)                                                                     \
@@ -768,6 +785,7 @@ static int tvz_corpus_destroy_impl(tvz_corpus *c) {
         if (c->rows.p) (void)hipFree(c->rows.p);
         if (c->ix.dir.p) (void)hipFree(c->ix.dir.p);
         if (c->ix.post.p) (void)hipFree(c->ix.post.p);
+        if (c->ix.sub_distinct.p) (void)hipFree(c->ix.sub_distinct.p);
         if (c->ix.ivid.p) (void)hipFree(c->ix.ivid.p);
         if (c->ix.drows.p) (void)hipFree(c->ix.drows.p);
         if (c->ix.info) (void)hipFree(c->ix.info);
@@ -1090,7 +1108,7 @@ static int tvz_find_duplicates_impl(tvz_corpus *c, const double *h_query, int64_
         // block), rows in the delta table by the sweep - both write to pinned host memory, one
         // synchronisation for the two.  A query the lookup refuses (> 4 G postings) is swept.
         for (int attempt = 0; attempt < 2; ++attempt) {
-            int blocks = 0, region = 0;
+            int blocks = 0, region = 0, n_sub = 0;
             bool used_index = false;
             {
                 std::shared_lock<std::shared_mutex> lk(c->mu);
@@ -1109,9 +1127,10 @@ static int tvz_find_duplicates_impl(tvz_corpus *c, const double *h_query, int64_
                     s->busy.store(1, std::memory_order_release);         // drain() waits for this sweep
                     if (attempt == 0 && index_usable(c, min_match)) {
                         used_index = true;
-                        if (int rc = launch_index(c, dq, dqo, 1, (int32_t)n, min_match, nullptr, excl,
-                                                  (int32_t)std::min<int64_t>(s->ix_slots, INT32_MAX), s->dh_ix_hits,
-                                                  s->dh_counts + kQ1MaxBlocks, 1, s->stream, by_value ? &qv : nullptr)) {
+                        n_sub = c->ix.n_sub;
+                        if (int rc = launch_index<true>(c, dq, dqo, 1, (int32_t)n, min_match, nullptr, excl, 0,
+                                                        s->dh_ix_hits, s->dh_counts + kQ1MaxBlocks, 1, s->stream,
+                                                        by_value ? &qv : nullptr)) {
                             s->busy.store(0, std::memory_order_release);
                             return rc;
                         }
@@ -1138,7 +1157,9 @@ static int tvz_find_duplicates_impl(tvz_corpus *c, const double *h_query, int64_
                 if (e != hipSuccess)
                     return tvz::fail(TVZ_ERR_HIP, "single-query match failed: %s", hipGetErrorString(e));
             }
-            if (used_index && s->h_counts[kQ1MaxBlocks] < 0) continue;     // refused: sweep everything
+            bool refused = false;
+            for (int b = 0; b < n_sub; ++b) refused = refused || s->h_counts[kQ1MaxBlocks + b] < 0;
+            if (refused) continue;                                        // sweep everything instead
             // compact the per-block regions in place (block order; sorted below anyway)
             w = 0;
             for (int b = 0; b < blocks; ++b) {
@@ -1148,11 +1169,13 @@ static int tvz_find_duplicates_impl(tvz_corpus *c, const double *h_query, int64_
                 if (src != hh + w) memmove(hh + w, src, (size_t)nb * sizeof(Hit));
                 w += nb;
             }
-            if (used_index) {
-                const int64_t n_ix = std::min<int64_t>(s->h_counts[kQ1MaxBlocks], s->ix_slots);
-                if (n_ix) memcpy(hh + w, s->h_ix_hits, (size_t)n_ix * sizeof(Hit));
-                w += n_ix;
+            for (int b = 0; b < n_sub; ++b) {                              // the lookup's regions, one per sub-index
+                const int64_t nb = std::min<int64_t>(s->h_counts[kQ1MaxBlocks + b], kSubRows);
+                if (nb) memcpy(hh + w, reinterpret_cast<const Hit *>(s->h_ix_hits) + (int64_t)b * kSubRows,
+                               (size_t)nb * sizeof(Hit));
+                w += nb;
             }
+            (void)used_index;
             break;
         }
         found = hh;
