@@ -262,15 +262,27 @@ def bench_match(args, rank, world, dev):
     n_over = int((totals < 0).sum().item())            # negative total = a shard's list overflowed
     mean_hits = float(totals.abs().float().mean().item())
     # the dominant kernel of a batch, timed on its own with HIP events on its stream (rank-local
-    # shard; prep + build + sweep launches of one tvz_match call)
+    # shard; every launch of one tvz_match call): once as the service runs it (AUTO: inverted-index
+    # lookup, the delta table is empty here) and once forced onto the corpus sweep (hash join)
     st = torch.cuda.Stream(dev)
     ws = torch.empty(tc.workspace_bytes(Q, max_len), dtype=torch.uint8, device=dev)
     hits = torch.empty((Q, CAP, 3), dtype=torch.int32, device=dev)
     n_h = torch.empty(Q, dtype=torch.int32, device=dev)
-    sweep_ms = kernel_ms(lambda: dc.match(d_q, d_off, max_len, 2, CAP, out_hits=hits, out_n=n_h, stream=st,
+    index_ms = kernel_ms(lambda: dc.match(d_q, d_off, max_len, 2, CAP, out_hits=hits, out_n=n_h, stream=st,
                                           workspace=ws), st)
+    n_hits = int(n_h.clamp(min=0).sum().item())
+    sweep_ms = kernel_ms(lambda: dc.match(d_q, d_off, max_len, 2, CAP, out_hits=hits, out_n=n_h, stream=st,
+                                          workspace=ws, algo=_lib.ALGO_JOIN), st)
     shard_rows, shard_keys, _ = dc.stats()
+    ix = dc.index_stats()
     corpus_bytes = 16.0 * shard_rows + 8.0 * shard_keys
+    # postings the batch walks on this shard: for every query element, the rows that hold its key
+    uk, uc = np.unique(s_keys.view(np.int64), return_counts=True)
+    qk = np.concatenate([np.asarray(q, dtype=np.float64) for q in queries]).view(np.int64)
+    pos = np.searchsorted(uk, qk)
+    pos[pos >= len(uk)] = 0
+    postings = int(uc[pos][uk[pos] == qk].sum())
+    n_sub = -(-shard_rows // 16384)
     # tvz_match.hip join_shape(): tiles of <= 1024 queries whose elements fit a 2 MiB table at load 0.55
     q_per_tile = max(1, min(1024, int(0.55 * (1 << 19)) // max(max_len, 1), Q))
     n_tiles = -(-Q // q_per_tile)
@@ -279,32 +291,52 @@ def bench_match(args, rank, world, dev):
     out = {"value": pairs / wall, "unit": "pairs/s", "corpus_videos": C, "queries_per_batch": Q,
            "mean_cuts_per_video": round(mean_len, 1), "min_match": 2, "steps": args.match_steps,
            "ms_per_batch": wall * 1e3 / args.match_steps,
+           "algo": "AUTO = inverted-index lookup (one block per query and sub-index of 16384 rows) + sweep of the "
+                   "delta table (empty here); identical hits to the full sweep (tests/test_index_gpu.py)",
+           "index": ix,
            "collective": (f"tvz_match_sharded (C ABI): one ncclAllGather of [Q,{K_TOP + 1},3] int32 per batch "
-                          f"(top-{K_TOP} + hit totals), overlapped with the next batch's sweep") if sm.collective else "none",
+                          f"(top-{K_TOP} + hit totals), overlapped with the next batch's match") if sm.collective else "none",
            "queries_with_hits": n_dups, "mean_hits_per_query": round(mean_hits, 1),
            "hit_list_capacity": CAP, "queries_with_overflowed_shard_lists": n_over,
            "scaling": "strong (the same corpus is sharded over the ranks)",
-           "sweep_ms_per_batch_rank0": sweep_ms,
+           "match_ms_per_batch_rank0": index_ms, "sweep_ms_per_batch_rank0": sweep_ms,
            "predicted_scaling": "profiles/r2_predicted_scaling.json (single-GPU shard timings)"}
     tag = f"C{C}_Q{Q}"
-    traffic = pmc_traffic("ts_match_join", tag=tag) if world == 1 else None
-    alg = corpus_bytes * n_tiles + mean_hits * Q * 12
+    # ---- roofline of the kernel the batch spends its time in: the index lookup ----
+    alg_ix = postings * 2.0 + len(qk) * n_sub * 16.0 + len(qk) * 8.0 * n_sub + n_hits * 12.0
     out["roofline"] = {
         "bound": "hbm",
-        "kernel": f"ts_match_join_kernel: {n_tiles} corpus sweep(s), one per tile of <= {q_per_tile} queries (the event "
-                  "pair also covers ts_prep + ts_join_build + the counter gather, < 10 % of it)",
-        "achieved": alg / (sweep_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-        "frac": alg / (sweep_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
-        "algorithmic_bytes_per_launch": alg, "avg_launch_ms": sweep_ms,
-        "limiter": "not HBM: the sweep streams this rank's corpus image once per tile (16 B row entry + 8 B per key) and "
-                   "is bound by wave-instruction issue and L2-hit probe latency of the 2 MiB fingerprint table "
-                   "(profiles/r2_match_pmc.txt: ~240 M wave-instructions per 1024-query sweep of 100k rows, L2 hit "
-                   "78 %, 66 % of wave-cycles waiting); `traffic` is FETCH_SIZE x2 + WRITE_SIZE of the committed PMC "
-                   "pass for this workload tag (" + tag + ") and includes Infinity-Cache hits"}
+        "kernel": "ts_match_index_kernel (the event pair also covers ts_prep and the counter gather, < 2 % of it)",
+        "achieved": alg_ix / (index_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": alg_ix / (index_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+        "traffic": pmc_traffic("ts_match_index", tag=tag + "_index") if world == 1 else None,
+        "algorithmic_bytes_per_launch": alg_ix, "avg_launch_ms": index_ms,
+        "algorithmic_bytes": f"{postings} postings x 2 B + one 16 B directory entry and one 8 B query key per (query "
+                             f"element, sub-index) ({len(qk)} x {n_sub}) + {n_hits} hits x 12 B",
+        "limiter": "not HBM bandwidth: a block is a chain of dependent accesses (query offsets -> keys -> directory "
+                   "-> postings -> video ids -> hit list) with LDS-atomic counting in between; random 16 B directory "
+                   "probes and short posting lists fetch whole lines, so `traffic` (FETCH_SIZE x2 + WRITE_SIZE of "
+                   "the committed PMC pass) is ~3x the algorithmic bytes (profiles/r2_match_pmc.txt)"}
+    # ---- the same batch forced onto the corpus sweep (what AUTO runs without an index) ----
+    alg = corpus_bytes * n_tiles + n_hits * 12.0
+    out["sweep"] = {
+        "pairs_per_s_rank0": Q * shard_rows / (sweep_ms * 1e-3),
+        "roofline": {
+            "bound": "hbm",
+            "kernel": f"ts_match_join_kernel: {n_tiles} corpus sweep(s), one per tile of <= {q_per_tile} queries (the "
+                      "event pair also covers ts_prep + ts_join_build + the counter gather, < 10 % of it)",
+            "achieved": alg / (sweep_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": alg / (sweep_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "traffic": pmc_traffic("ts_match_join", tag=tag) if world == 1 else None,
+            "algorithmic_bytes_per_launch": alg, "avg_launch_ms": sweep_ms,
+            "limiter": "not HBM: the sweep streams this rank's corpus image once per tile (16 B row entry + 8 B per "
+                       "key) and is bound by the probe rate of the 2 MiB fingerprint table (one random 16 B bucket "
+                       "per corpus key: L2 hit 78 %, 66 % of wave-cycles waiting, profiles/r2_match_pmc.txt)"}}
     out["nominal_hbm_equiv"] = {"GBps_per_gpu": pairs * bytes_per_pair / wall / 1e9 / world,
                                 "x_hbm_peak": pairs * bytes_per_pair / wall / 1e9 / world / HBM_PEAK_GBS,
-                                "note": "SURVEY 8d nominal 8*L+8 B per (query,row) pair; not a roofline: one probe of a "
-                                        "corpus key serves a whole tile of up to 1024 queries"}
+                                "note": "SURVEY 8d nominal 8*L+8 B per (query,row) pair; not a roofline: the index "
+                                        "reads only the posting lists of the query's keys, the sweep serves a tile of "
+                                        "up to 1024 queries per probe"}
     dc.close()
     # configs[2]: ONE query vs a 5k-video corpus on one GPU (+ the batch-size sweep SURVEY 8d asks for)
     if rank == 0 and world == 1:
@@ -338,19 +370,24 @@ def bench_match_q1(args, dev, Q):
             t = time.perf_counter()
             dc5.find_duplicates(q5[i % len(q5)], 2)
             lat.append(time.perf_counter() - t)
-        q1_ms = by_q["1"]["kernel_ms"]
-        # the same sweep with min_match 5 (the reference's default: a handful of hits instead of the
-        # thousands of accidental min_match=2 collisions, each a serialised append to one hit list)
+        # the same single query forced onto the corpus sweep (what a corpus without an index runs), at
+        # min_match 2 and at the reference's default 5 (a handful of hits instead of the thousands of
+        # accidental min_match=2 collisions, each an append to one hit list)
         dq, do, ml = tc.pack_queries(q5[:1], dev)
         hits = torch.empty((1, 4096, 3), dtype=torch.int32, device=dev)
         n_h = torch.empty(1, dtype=torch.int32, device=dev)
         ws = torch.empty(tc.workspace_bytes(1, ml), dtype=torch.uint8, device=dev)
-        q1_mm5 = kernel_ms(lambda: dc5.match(dq, do, ml, 5, 4096, out_hits=hits, out_n=n_h, stream=st, workspace=ws),
-                           st, reps=24, skip=4)
-        entry = {"kernel_by_batch_size": by_q, "q1_kernel_ms_min_match5": round(q1_mm5, 4),
+        q1_ms = kernel_ms(lambda: dc5.match(dq, do, ml, 2, 4096, out_hits=hits, out_n=n_h, stream=st, workspace=ws,
+                                            algo=_lib.ALGO_Q1), st, reps=24, skip=4)
+        q1_mm5 = kernel_ms(lambda: dc5.match(dq, do, ml, 5, 4096, out_hits=hits, out_n=n_h, stream=st, workspace=ws,
+                                             algo=_lib.ALGO_Q1), st, reps=24, skip=4)
+        entry = {"kernel_by_batch_size": by_q, "index": dc5.index_stats(),
+                 "q1_sweep_kernel_ms": round(q1_ms, 4), "q1_sweep_kernel_ms_min_match5": round(q1_mm5, 4),
                  "find_duplicates_latency_us": round(float(np.median(lat[10:])) * 1e6, 1),
-                 "roofline_q1": {"bound": "hbm", "kernel": "ts_match_q1_kernel (one query, whole corpus image streamed "
-                                                           "once; event pair also covers ts_prep + the counter gather)",
+                 "roofline_q1": {"bound": "hbm", "kernel": "ts_match_q1_kernel, forced (one query, whole corpus image "
+                                                           "streamed once; event pair also covers ts_prep + the counter "
+                                                           "gather); AUTO answers from the index instead, see "
+                                                           "kernel_by_batch_size",
                                  "algorithmic_bytes_per_launch": image,
                                  "achieved": image / (q1_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                  "frac": image / (q1_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,

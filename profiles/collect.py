@@ -21,7 +21,7 @@ for name, out in (("bench.json", f"{tag}_bench.json"), ("predicted_scaling.json"
         shutil.copy(p, os.path.join(dst, out))
 # the kernel-trace stats of each matcher workload (rocprofv3 --kernel-trace --stats)
 import glob
-for w in ("join", "q1_100k", "q1_5k", "tile", "shard8"):
+for w in ("index", "index1", "join", "q1_100k", "q1_5k", "tile", "shard8"):
     f = glob.glob(os.path.join(root, "gpurun_out", f"pmc_match_{tag}", w, "trace", "**", "*kernel_stats.csv"), recursive=True)
     if f:
         shutil.copy(f[0], os.path.join(dst, f"{tag}_match_{w}_kernel_stats.csv"))

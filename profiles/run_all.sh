@@ -9,7 +9,7 @@ OUT=$REPO/gpurun_out/final_$TAG
 mkdir -p $OUT
 echo "== bench (un-profiled)";            python bench.py --steps 20 --warmup 5 > $OUT/bench.json 2> $OUT/bench.err; echo rc=$?
 echo "== scene kernel trace + FETCH/WRITE"; bash profiles/run_profile.sh $TAG > $OUT/run_profile.log 2>&1; echo rc=$?
-echo "== matcher trace + counters";       bash profiles/pmc_match.sh $TAG join q1_100k q1_5k tile shard8 > $OUT/pmc_match.log 2>&1; echo rc=$?
+echo "== matcher trace + counters";       bash profiles/pmc_match.sh $TAG index index1 join q1_100k q1_5k tile shard8 > $OUT/pmc_match.log 2>&1; echo rc=$?
 echo "== predicted scaling";              python profiles/predict_scaling.py 4096 2>/dev/null | tail -1 > $OUT/predicted_scaling.json; python profiles/predict_scaling.py 1024 2>/dev/null | tail -1 >> $OUT/predicted_scaling.json
 echo "== find_duplicates latency (C ABI, no Python)"
 gcc -O2 -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -Iinclude profiles/find_dup_latency.c -o /tmp/fdl -Ltvidz_amd -ltvz \

@@ -665,12 +665,24 @@ int launch_match(tvz_corpus *c, const double *d_queries, const int64_t *d_q_offs
 
 int launch_topk_local(const int32_t *d_hits, const int32_t *d_hits_n, int32_t ns, int32_t Q, int32_t cap,
                       int32_t k, int32_t *d_out, int mode, hipStream_t st) {
+    // (one WAVE per query for the short lists of a small shard - registers + DPP minimum, k rounds -
+    // was tried: ~4,000 wave-instructions per query, 28 us per 4096 queries, no faster than a block
+    // each with the kth histogram)
     if (k <= kSelSmallK)
         hipLaunchKernelGGL(ts_topk_select_kernel<4 * kSelSmallK>, dim3((unsigned)Q), dim3(kBlock), 0, st, d_hits,
                            d_hits_n, ns, Q, cap, k, d_out, mode);
     else
         hipLaunchKernelGGL(ts_topk_select_kernel<kSortCap>, dim3((unsigned)Q), dim3(kBlock), 0, st, d_hits,
                            d_hits_n, ns, Q, cap, k, d_out, mode);
+    TVZ_HIP(hipGetLastError());
+    return TVZ_OK;
+}
+
+// merge of n_lists per-rank blocks of k + 1 rows (mode 2) / plain top-k over n_lists lists (mode 0)
+int launch_topk_lists(const int32_t *d_lists, const int32_t *d_lists_n, int32_t n_lists, int32_t Q, int32_t cap,
+                      int32_t k, int32_t *d_topk, int mode, int32_t *d_totals, hipStream_t st) {
+    hipLaunchKernelGGL(ts_topk_kernel, dim3((unsigned)Q), dim3(kBlock), 0, st, d_lists, d_lists_n, n_lists, Q,
+                       cap, k, d_topk, mode, d_totals);
     TVZ_HIP(hipGetLastError());
     return TVZ_OK;
 }
@@ -1304,10 +1316,7 @@ static int tvz_topk_impl(const int32_t *d_lists, const int32_t *d_lists_n, int32
     TVZ_REQUIRE((d_lists || cap == 0) && d_topk, "NULL argument");
     hipStream_t st = reinterpret_cast<hipStream_t>(hip_stream);
     if (n_lists == 1) return launch_topk_local(d_lists, d_lists_n, 1, Q, cap, k, d_topk, 0, st);
-    hipLaunchKernelGGL(ts_topk_kernel, dim3((unsigned)Q), dim3(kBlock), 0, st, d_lists, d_lists_n,
-                       n_lists, Q, cap, k, d_topk, 0, nullptr);
-    TVZ_HIP(hipGetLastError());
-    return TVZ_OK;
+    return launch_topk_lists(d_lists, d_lists_n, n_lists, Q, cap, k, d_topk, 0, nullptr, st);
 }
 
 static int tvz_topk_shard_impl(const int32_t *d_hits, const int32_t *d_hits_n, int32_t Q,
@@ -1325,11 +1334,8 @@ static int tvz_topk_merge_impl(const int32_t *d_gathered, int32_t n_ranks, int32
     TVZ_REQUIRE(k >= 1 && k <= kSortCap / 2, "k=%d out of range [1, %d]", k, kSortCap / 2);
     if (Q == 0) return TVZ_OK;
     TVZ_REQUIRE(d_gathered && d_topk, "NULL argument");
-    hipLaunchKernelGGL(ts_topk_kernel, dim3((unsigned)Q), dim3(kBlock), 0,
-                       reinterpret_cast<hipStream_t>(hip_stream), d_gathered, nullptr, n_ranks, Q,
-                       k + 1, k, d_topk, 2, d_totals);
-    TVZ_HIP(hipGetLastError());
-    return TVZ_OK;
+    return launch_topk_lists(d_gathered, nullptr, n_ranks, Q, k + 1, k, d_topk, 2, d_totals,
+                             reinterpret_cast<hipStream_t>(hip_stream));
 }
 
 static int tvz_align_impl(tvz_corpus *c, const double *d_query, int32_t n, double eps,

@@ -1174,13 +1174,30 @@ __global__ __launch_bounds__(kBlock) void ts_topk_select_kernel(
         for (int b = threadIdx.x * kPer; b < (threadIdx.x + 1) * kPer && b < kSelBins; ++b) s += hist[b];
         part[threadIdx.x] = s;
         __syncthreads();
-        if (threadIdx.x == 0) {
-            uint32_t cum = 0;
-            int t = 0;
-            while (t < kBlock - 1 && cum + part[t] < (uint32_t)k) cum += part[t++];
-            int b = t * kPer;
-            while (b < kSelBins - 1 && cum + hist[b] < (uint32_t)k) cum += hist[b++];
-            s_bin = b;
+        // threshold bin = first bin whose inclusive prefix reaches k.  One wave: lane l owns the
+        // partial sums of threads 4l..4l+3 (a serial walk by one thread was ~10 us of dependent LDS
+        // reads per block - most of this kernel)
+        if (threadIdx.x < 64) {
+            const int l = threadIdx.x;
+            const uint32_t p0 = part[4 * l], p1 = part[4 * l + 1], p2 = part[4 * l + 2], p3 = part[4 * l + 3];
+            uint32_t incl = p0 + p1 + p2 + p3;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t o = __shfl_up(incl, d);
+                if (l >= d) incl += o;
+            }
+            const unsigned long long reach = __ballot(incl >= (uint32_t)k);
+            const int owner = reach ? __ffsll((long long)reach) - 1 : 63;
+            if (l == owner) {
+                uint32_t cum = incl - (p0 + p1 + p2 + p3);
+                int t = 4 * l;
+                if (cum + p0 < (uint32_t)k) { cum += p0; ++t;
+                    if (cum + p1 < (uint32_t)k) { cum += p1; ++t;
+                        if (cum + p2 < (uint32_t)k) { cum += p2; ++t; } } }
+                int b = t * kPer;
+                while (b < kSelBins - 1 && cum + hist[b] < (uint32_t)k) cum += hist[b++];
+                s_bin = b;
+            }
         }
         __syncthreads();
         limit = s_bin;
