@@ -42,6 +42,15 @@ int main(void) {
     int64_t nr, nk, na;
     CHECK(tvz_corpus_stats(c, &nr, &nk, &na));
     EXPECT(nr == 3 && nk == 15);
+    /* the index upload built covers rows 1 and 2; row 3 arrived by upsert and sits in the delta table */
+    int64_t ix_rows, ix_delta, ix_post, ix_keys, ix_builds;
+    CHECK(tvz_corpus_index_stats(c, &ix_rows, &ix_delta, &ix_post, &ix_keys, &ix_builds));
+    EXPECT(ix_rows == 2 && ix_delta == 1 && ix_post == 10 && ix_builds == 1);
+    CHECK(tvz_corpus_build_index(c));
+    CHECK(tvz_corpus_index_stats(c, &ix_rows, &ix_delta, &ix_post, &ix_keys, &ix_builds));
+    EXPECT(ix_rows == 3 && ix_delta == 0 && ix_post == 15 && ix_keys == 10 && ix_builds == 2);
+    CHECK(tvz_find_duplicates(c, third, 5, 5, -1, 8, oid, ocnt, okth, &n));
+    EXPECT(n == 2 && oid[0] == 1 && oid[1] == 3 && okth[0] == 4);
     EXPECT(tvz_find_duplicates(NULL, q1, 5, 5, -1, 8, oid, ocnt, okth, &n) == TVZ_ERR_INVALID);
     EXPECT(strlen(tvz_last_error()) > 0);
     CHECK(tvz_corpus_destroy(c));

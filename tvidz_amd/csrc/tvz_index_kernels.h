@@ -198,7 +198,9 @@ inline size_t ix_lds_bytes(int max_len) {
            (size_t)(2 * max_len + 2) * 4 + (size_t)(max_len + 2) * 2;
 }
 
-template <bool HOSTOUT>
+// TOP5 = false (min_match 1..2): a slot keeps the two smallest positions in two atomicMin words -
+// two plain LDS atomics per candidate posting instead of the 5 x 12-bit CAS loop (min_match 3..5).
+template <bool HOSTOUT, bool TOP5>
 __global__ __launch_bounds__(kIxBlock) void ts_match_index_kernel(
     const DirEnt *__restrict__ dir_all, int dir_log2, const uint16_t *__restrict__ post,
     const int32_t *__restrict__ ivid, int64_t n_indexed, const double *__restrict__ queries,
@@ -211,6 +213,7 @@ __global__ __launch_bounds__(kIxBlock) void ts_match_index_kernel(
     uint32_t *rank = bm2 + kIxWords;                                    // candidates before word j
     uint32_t *tcnt = rank + kIxWords;
     unsigned long long *ttop = reinterpret_cast<unsigned long long *>(tcnt + kIxSlots);
+    uint32_t *m1 = reinterpret_cast<uint32_t *>(ttop), *m2 = m1 + kIxSlots;   // !TOP5: the same 8 B per slot
     uint32_t *elist = reinterpret_cast<uint32_t *>(ttop + kIxSlots);    // emit list of one part
     uint32_t *pcache = elist + kIxSlots;                                // first kIxCache postings: row | position << kSubLog2
     uint32_t *s_off = reinterpret_cast<uint32_t *>(pcache + kIxCache);  // first posting of list j
@@ -239,7 +242,10 @@ __global__ __launch_bounds__(kIxBlock) void ts_match_index_kernel(
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (threadIdx.x == 0) { s_m = 0; s_total = 0; s_emitted = 0; s_nlist = 0; }
     for (int i = threadIdx.x; i < kIxWords; i += kIxBlock) { bm1[i] = 0; bm2[i] = 0; }
-    for (int i = threadIdx.x; i < kIxSlots; i += kIxBlock) { tcnt[i] = 0; ttop[i] = kTopNone; }
+    for (int i = threadIdx.x; i < kIxSlots; i += kIxBlock) {
+        tcnt[i] = 0;
+        if (TOP5) ttop[i] = kTopNone; else { m1[i] = 0xffffffffu; m2[i] = 0xffffffffu; }
+    }
     __syncthreads();
 
     // ---- directory: the NON-EMPTY posting lists of the query's positions, compacted ----
@@ -381,12 +387,17 @@ __global__ __launch_bounds__(kIxBlock) void ts_match_index_kernel(
                 const uint32_t idx = rank[r >> 5] + __popc(w & ((1u << bit) - 1u)) - lo;
                 if (idx >= (uint32_t)kIxSlots) continue;                 // another part's (wraps below lo)
                 atomicAdd(&tcnt[idx], 1u);
-                unsigned long long seen = ttop[idx];
-                while (true) {
-                    if (((uint32_t)(seen >> (12 * (kTop - 1))) & 0xfffu) <= pos) break;   // not among the 5 smallest
-                    const unsigned long long old = atomicCAS(&ttop[idx], seen, top5_insert(seen, pos));
-                    if (old == seen) break;
-                    seen = old;
+                if constexpr (TOP5) {
+                    unsigned long long seen = ttop[idx];
+                    while (true) {
+                        if (((uint32_t)(seen >> (12 * (kTop - 1))) & 0xfffu) <= pos) break;   // not among the 5 smallest
+                        const unsigned long long old = atomicCAS(&ttop[idx], seen, top5_insert(seen, pos));
+                        if (old == seen) break;
+                        seen = old;
+                    }
+                } else {
+                    const uint32_t o = atomicMin(&m1[idx], pos);         // positions of one row are distinct
+                    atomicMin(&m2[idx], o > pos ? o : pos);              // larger of two hits >= 2nd smallest
                 }
             }
         }
@@ -453,13 +464,17 @@ __global__ __launch_bounds__(kIxBlock) void ts_match_index_kernel(
                 int32_t *hp = out_hits + (int64_t)o * 3;
                 hp[0] = vid[u];
                 hp[1] = (int32_t)tcnt[idx];
-                hp[2] = (int32_t)((uint32_t)(ttop[idx] >> (12 * (min_match - 1))) & 0xfffu);
+                hp[2] = TOP5 ? (int32_t)((uint32_t)(ttop[idx] >> (12 * (min_match - 1))) & 0xfffu)
+                             : (int32_t)(min_match == 1 ? m1[idx] : m2[idx]);
             }
             ++o;
         }
         __syncthreads();
         if (lo + kIxSlots < n_cand)
-            for (int i = threadIdx.x; i < kIxSlots; i += kIxBlock) { tcnt[i] = 0; ttop[i] = kTopNone; }
+            for (int i = threadIdx.x; i < kIxSlots; i += kIxBlock) {
+                tcnt[i] = 0;
+                if (TOP5) ttop[i] = kTopNone; else { m1[i] = 0xffffffffu; m2[i] = 0xffffffffu; }
+            }
         __syncthreads();
     }
     if (HOSTOUT && threadIdx.x == 0) *out_n = s_emitted;

@@ -621,10 +621,13 @@ int launch_index(tvz_corpus *c, const double *d_queries, const int64_t *d_q_offs
                  const QByVal *byval = nullptr) {
     static const QByVal kNoQuery = {};
     const Index &ix = c->ix;
-    hipLaunchKernelGGL(ts_match_index_kernel<HOSTOUT>, dim3((unsigned)Q, (unsigned)ix.n_sub), dim3(kIxBlock),
-                       ix_lds_bytes(max_query_len), st, ix.dir.p, ix.dir_log2, ix.post.p, ix.ivid.p, ix.n_main,
-                       d_queries, d_q_offsets, max_query_len, min_match, d_exclude_ids, exclude_one, cap, d_hits,
-                       d_hits_n, ns, byval ? *byval : kNoQuery);
+#define TVZ_IX(TOP5)                                                                                        \
+    hipLaunchKernelGGL((ts_match_index_kernel<HOSTOUT, TOP5>), dim3((unsigned)Q, (unsigned)ix.n_sub),        \
+                       dim3(kIxBlock), ix_lds_bytes(max_query_len), st, ix.dir.p, ix.dir_log2, ix.post.p,    \
+                       ix.ivid.p, ix.n_main, d_queries, d_q_offsets, max_query_len, min_match, d_exclude_ids, \
+                       exclude_one, cap, d_hits, d_hits_n, ns, byval ? *byval : kNoQuery)
+    if (min_match <= 2) TVZ_IX(false); else TVZ_IX(true);
+#undef TVZ_IX
     TVZ_HIP(hipGetLastError());
     return TVZ_OK;
 }
@@ -753,10 +756,11 @@ static int tvz_corpus_create_impl(tvz_corpus **out, int device) {
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)kTileLds));
     TVZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(ts_match_join_kernel),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)kJoinLds));
-    TVZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(ts_match_index_kernel<false>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)ix_lds_bytes(kMaxQueryLen)));
-    TVZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(ts_match_index_kernel<true>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)ix_lds_bytes(kMaxQueryLen)));
+#define TVZ_IX_ATTR(H, T)                                                                          \
+    TVZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(ts_match_index_kernel<H, T>),           \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)ix_lds_bytes(kMaxQueryLen)))
+    TVZ_IX_ATTR(false, false); TVZ_IX_ATTR(false, true); TVZ_IX_ATTR(true, false); TVZ_IX_ATTR(true, true);
+#undef TVZ_IX_ATTR
     const int q1max = (int)q1_lds_bytes(kQ1MaxLog2);
 #define TVZ_Q1_ATTR(M, H)                                                                     \
     TVZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(ts_match_q1_kernel<M, H>),       \
