@@ -327,7 +327,8 @@ def bench_match(args, rank, world, dev):
                       "event pair also covers ts_prep + ts_join_build + the counter gather, < 10 % of it)",
             "achieved": alg / (sweep_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": alg / (sweep_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-            "traffic": pmc_traffic("ts_match_join", tag=tag) if world == 1 else None,
+            # the committed counter pass averages per LAUNCH; a batch is one launch per tile
+            "traffic": (lambda t: t * n_tiles if t else None)(pmc_traffic("ts_match_join", tag=tag)) if world == 1 else None,
             "algorithmic_bytes_per_launch": alg, "avg_launch_ms": sweep_ms,
             "limiter": "not HBM: the sweep streams this rank's corpus image once per tile (16 B row entry + 8 B per "
                        "key) and is bound by the probe rate of the 2 MiB fingerprint table (one random 16 B bucket "

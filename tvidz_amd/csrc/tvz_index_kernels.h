@@ -4,7 +4,7 @@
 // query elements are `in` the row.  The sweep kernels answer by reading every row; the index
 // answers from the other side: for every query element, which rows contain it.
 //
-// The indexed rows are cut into SUB-INDEXES of 2^15 rows.  Per sub-index:
+// The indexed rows are cut into SUB-INDEXES of 2^14 rows.  Per sub-index:
 //   dir  : open-addressing directory of the distinct canonical keys of its rows, 16 B per entry
 //          {key, first posting, number of postings}, load <= 0.5 (all directories the same size)
 //   post : posting lists, one uint16 LOCAL row number per (row, key) pair, contiguous per key
@@ -15,13 +15,13 @@
 //
 // One block per (query, sub-index).  A query of n elements whose keys have p postings in the
 // sub-index costs n directory probes + 2 p two-byte posting reads, whatever the corpus size
-// (config 4: ~32,000 postings = 64 KB per query over 4 sub-indexes, against 160 MB for a sweep):
+// (config 4: ~16,500 postings = 33 KB per query over 7 sub-indexes, against 160 MB for a sweep):
 //   pass A  every posting sets its row's bit in `seen1`, or in `seen2` if seen1 was set already:
 //           only rows in seen2 (seen1 for min_match 1) can reach min_match; the bitmaps cover the
-//           sub-index exactly (32,768 bits), so the candidates are known row by row;
+//           sub-index exactly (16,384 bits), so the candidates are known row by row;
 //   rank    prefix popcount of the candidate bitmap: candidate -> dense slot, no hashing;
 //   pass B  the postings are walked again; a candidate's (count, five smallest query positions)
-//           accumulate in its slot - 2,048 slots at a time if there are more candidates; the walk
+//           accumulate in its slot - 1,024 slots at a time if there are more candidates; the walk
 //           reads the (row, position) pairs pass A left in LDS, not the posting lists again;
 //   emit    candidates with count >= min_match, (video_id, count, kth) exactly as the sweeps emit
 //           them: one reservation per block in the query's hit list (or the block's own region of
