@@ -203,3 +203,56 @@ def test_a_corpus_grown_by_upserts_gets_and_refreshes_its_index(dc):
     assert st[4096]["builds"] == 1 and st[4096]["indexed_rows"] == 4096 and st[4096]["delta_rows"] == 0
     assert st[4097]["delta_rows"] == 1 and st[6000]["delta_rows"] == 6000 - 4096
     assert st[8499]["builds"] == 2 and st[8499]["indexed_rows"] > 8000     # the delta filled up once
+
+
+def test_lookups_stay_exact_while_upserts_rebuild_the_index(dc):
+    """Threads call find_duplicates (index lookup + delta sweep, host in / host out) and tvz_match
+    while another thread upserts thousands of unrelated videos, which fills the delta table and
+    rebuilds the index several times under them (a rebuild waits for the matches in flight and
+    replaces the directories, postings and video-id table).  The probes' hits never change."""
+    import threading
+    rng = np.random.default_rng(31)
+    grid = np.arange(1, 20_001) / 10.0
+    probe = rng.choice(grid, size=40, replace=False)
+    rows = [(v, rng.choice(grid, size=10, replace=False).tolist()) for v in range(1, 5001)]
+    for v in (17, 1234, 4999):
+        rows[v - 1] = (v, rows[v - 1][1][:6] + probe[:12].tolist())       # the probe's duplicates
+    dc.upload(rows)
+    ids, offs, keys = tc.rows_to_csr(rows)
+    base = _expected(ids, offs, keys, probe, 5)
+    assert [h[0] for h in base] == [17, 1234, 4999]
+    stop = threading.Event()
+    errs = []
+
+    def finder():
+        try:
+            while not stop.is_set():
+                got = dc.find_duplicates(probe, 5, with_kth=True)
+                assert got == base, got
+        except Exception as e:                                            # pragma: no cover
+            errs.append(e)
+
+    def batcher():
+        try:
+            d_q, d_off, max_len = tc.pack_queries([probe] * 8, DEV)
+            while not stop.is_set():
+                hits, n = dc.match(d_q, d_off, max_len, 5, 64)
+                torch.cuda.synchronize()
+                h, nn = hits.cpu().numpy(), n.cpu().numpy()
+                for qi in range(8):
+                    assert sorted(tuple(int(x) for x in r) for r in h[qi, :nn[qi]]) == base
+        except Exception as e:                                            # pragma: no cover
+            errs.append(e)
+    th = [threading.Thread(target=finder) for _ in range(3)] + [threading.Thread(target=batcher)]
+    [t.start() for t in th]
+    try:
+        # far from the probe's keys (> 2000.0), so none of them can become a hit
+        for v in range(10_000, 10_000 + 9500):
+            dc.upsert(v, (2500.0 + rng.integers(0, 100_000, size=8) / 7.0).tolist())
+    finally:
+        stop.set()
+        [t.join(60) for t in th]
+    assert not errs, errs[:1]
+    st = dc.index_stats()
+    assert st["builds"] >= 3 and st["indexed_rows"] > 5000
+    assert dc.find_duplicates(probe, 5, with_kth=True) == base
