@@ -256,3 +256,56 @@ def test_lookups_stay_exact_while_upserts_rebuild_the_index(dc):
     st = dc.index_stats()
     assert st["builds"] >= 3 and st["indexed_rows"] > 5000
     assert dc.find_duplicates(probe, 5, with_kth=True) == base
+
+
+def test_index_through_compaction_growth_long_rows_and_duplicate_ids(dc):
+    """The slow paths of add_timestamps with an index in place: the arena is garbage-collected
+    (every row's key offset moves), the row table and arena grow beyond their reservation, a row is
+    longer than a pinned ring slot (> 8192 cuts: synchronous copy), and two rows carry the same
+    video_id (the reference has no UNIQUE constraint, db.py:21-27: both are matched, the upsert
+    replaces the first)."""
+    rng = np.random.default_rng(41)
+    grid = np.arange(1, 50_001) / 20.0
+    rows = [(v, rng.choice(grid, size=int(rng.integers(3, 30)), replace=False).tolist()) for v in range(1, 301)]
+    rows.append((7, rng.choice(grid, size=12, replace=False).tolist()))          # second row of video 7
+    dc.upload(rows)
+    q = np.asarray(rows[6][1][:8] + rows[-1][1][:8] + rows[100][1][:5])
+    _check(dc, rows, [q], 2)
+    _check_single(dc, rows, q, 2)
+    # replace the same few rows over and over: dead arena space piles up until a compaction
+    _, _, arena0 = dc.stats()
+    compacted = False
+    for it in range(400):
+        v = 1 + (it % 5)
+        ts = rng.choice(grid, size=500, replace=False).tolist()
+        dc.upsert(v, ts)
+        rows[v - 1] = (v, ts)
+        _, live, arena = dc.stats()
+        compacted = compacted or arena < arena0
+        arena0 = arena
+    assert compacted
+    st = dc.index_stats()
+    assert st["builds"] >= 2 and st["delta_rows"] <= 5          # the compaction rebuilt the index
+    q2 = np.asarray(rows[2][1][:20] + rows[200][1][:6])
+    for mm in (1, 2, 5):
+        _check(dc, rows, [q, q2], mm)
+        _check(dc, rows, [q, q2], mm, algo=_lib.ALGO_TILE)
+    _check_single(dc, rows, q2, 2, excl=3)
+    # a row of 9000 cuts (longer than a ring slot) and growth past the reservation
+    long_ts = (np.arange(9000) * 0.25 + 5000.0).tolist()
+    dc.upsert(9001, long_ts)
+    rows.append((9001, long_ts))
+    for v in range(20_000, 20_000 + 3000):                       # default reservation: 64 Ki rows, 2 Mi keys
+        ts = rng.choice(grid, size=800, replace=False).tolist()
+        dc.upsert(v, ts)
+        rows.append((v, ts))
+    q3 = np.asarray(long_ts[100:130] + rows[-1][1][:10])
+    _check(dc, rows, [q2, q3], 2)
+    _check_single(dc, rows, q3, 5)
+    # upsert of a duplicated id replaces its FIRST row only (db.py:54-62 .first())
+    dc.upsert(7, rows[-1][1][:15])
+    rows[6] = (7, rows[-1][1][:15])
+    _check(dc, rows, [q, q3], 2)
+    dc.build_index()
+    _check(dc, rows, [q, q3], 2)
+    _check_single(dc, rows, q3, 2, excl=7)
