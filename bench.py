@@ -168,48 +168,6 @@ def cpu_baseline_match(ids, offs, keys, queries, n_threads: int = 0):
                                                  f"{n_threads} threads, {dt_c:.2f} s = {dt_c * n_threads:.0f} core-seconds"}}
 
 
-class LocalMatcher:
-    """world size 1 without a process group: the same data path minus the all-gather
-    (tvz_match_topk -> tvz_topk_merge of the single block), two streams deep like the sharded one."""
-
-    def __init__(self, corpus, k, cap, dev):
-        self.corpus, self.k, self.cap, self.dev = corpus, k, cap, dev
-        self.streams = [torch.cuda.Stream(dev) for _ in range(2)]
-        self.ws = [None, None]
-        self.out = [None, None]
-        self._i = 0
-        self.collective = False
-        self.world = 1
-
-    def submit(self, d_q, d_off, max_len, mm, excl=None):
-        i = self._i
-        self._i ^= 1
-        st = self.streams[i]
-        Q = d_off.numel() - 1
-        need = tc.workspace_bytes(Q, max_len, self.cap, self.k)
-        if self.ws[i] is None or self.ws[i].numel() < need:
-            self.ws[i] = torch.empty(need, dtype=torch.uint8, device=self.dev)
-            self.out[i] = torch.empty((Q, self.k + 1, 3), dtype=torch.int32, device=self.dev)
-        st.wait_stream(torch.cuda.current_stream(self.dev))
-        with torch.cuda.stream(st):
-            blk = self.corpus.match_topk(d_q, d_off, max_len, mm, self.cap, self.k, d_exclude_ids=excl,
-                                         out=self.out[i], workspace=self.ws[i], stream=st)
-            merged, totals = tc.topk_merge(blk.view(1, Q, self.k + 1, 3), self.k, stream=st)
-        merged.record_stream(st)
-        totals.record_stream(st)
-        ev = torch.cuda.Event()
-        ev.record(st)
-        return merged, totals, ev
-
-    def finish(self, ticket):
-        merged, totals, ev = ticket
-        torch.cuda.current_stream(self.dev).wait_event(ev)
-        return merged, totals
-
-    def match_topk(self, *a):
-        return self.finish(self.submit(*a))
-
-
 def kernel_ms(fn, stream, reps=12, skip=2):
     """Median duration of fn() in ms, HIP events on the stream fn launches on."""
     ts = []
@@ -233,14 +191,11 @@ def bench_match(args, rank, world, dev):
     K_TOP = 16          # per-shard top-k travelling in the all-gather: [Q,17,3] int32 per rank
     CAP = 16384         # per-shard hit-list capacity per query (synthetic corpora: ~2,100 hits per
     #                     query at min_match=2 over 100k videos; overflows are counted below)
-    comm = None
-    if dist.is_initialized():
-        # the collective lives behind the C ABI (tvz_match_sharded: sweep -> top-k -> ncclAllGather ->
-        # merge); torch.distributed only ships the 128-byte RCCL id
-        comm = sharded.make_comm(dev.index)
-        sm = sharded.RcclShardedMatcher(dc, comm, k=K_TOP, cap=CAP)
-    else:
-        sm = LocalMatcher(dc, K_TOP, CAP, dev)
+    # the collective lives behind the C ABI (tvz_match_sharded: match -> top-k -> ncclAllGather ->
+    # merge) at every N, a single process included (one-rank communicator); torch.distributed only
+    # ships the 128-byte RCCL id
+    comm = sharded.make_comm(dev.index)
+    sm = sharded.RcclShardedMatcher(dc, comm, k=K_TOP, cap=CAP)
     for _ in range(3):
         merged, totals = sm.match_topk(d_q, d_off, max_len, 2)
     barrier_sync(world)
@@ -286,8 +241,7 @@ def bench_match(args, rank, world, dev):
     # tvz_match.hip join_shape(): tiles of <= 1024 queries whose elements fit a 2 MiB table at load 0.55
     q_per_tile = max(1, min(1024, int(0.55 * (1 << 19)) // max(max_len, 1), Q))
     n_tiles = -(-Q // q_per_tile)
-    if comm is not None:
-        comm.close()
+    comm.close()
     out = {"value": pairs / wall, "unit": "pairs/s", "corpus_videos": C, "queries_per_batch": Q,
            "mean_cuts_per_video": round(mean_len, 1), "min_match": 2, "steps": args.match_steps,
            "ms_per_batch": wall * 1e3 / args.match_steps,
@@ -295,7 +249,7 @@ def bench_match(args, rank, world, dev):
                    "delta table (empty here); identical hits to the full sweep (tests/test_index_gpu.py)",
            "index": ix,
            "collective": (f"tvz_match_sharded (C ABI): one ncclAllGather of [Q,{K_TOP + 1},3] int32 per batch "
-                          f"(top-{K_TOP} + hit totals), overlapped with the next batch's match") if sm.collective else "none",
+                          f"(top-{K_TOP} + hit totals) over {world} rank(s), overlapped with the next batch's match"),
            "queries_with_hits": n_dups, "mean_hits_per_query": round(mean_hits, 1),
            "hit_list_capacity": CAP, "queries_with_overflowed_shard_lists": n_over,
            "scaling": "strong (the same corpus is sharded over the ranks)",

@@ -2,9 +2,10 @@
 """Predicted 1/2/4/8-GPU strong scaling of the sharded corpus match from SINGLE-GPU shard timings
 (the 8-GPU node is the driver's, not ours): for N in 1,2,4,8 the rank-0 shard of the 100k-video
 corpus (C/N rows, balanced by keys) is matched against the same Q queries through the same data
-path bench.py times (tvz_match_topk on two streams + tvz_topk_merge; the all-gather of
-[Q,17,3] int32 per rank runs on the second stream behind the next batch's sweep and is modelled as
-hidden unless it is longer than a batch).   python profiles/predict_scaling.py [Q] [C]"""
+path bench.py times (tvz_match_sharded on two streams with a ONE-rank communicator: match, top-k,
+ncclAllGather of [Q,17,3] int32, merge; with N ranks the gather moves N blocks and the merge reads
+N lists - both run on the second stream behind the next batch's match and are modelled as hidden
+unless they are longer than a batch).   python profiles/predict_scaling.py [Q] [C]"""
 import json
 import os
 import sys
@@ -14,7 +15,6 @@ import numpy as np
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import bench  # noqa: E402  (LocalMatcher: the world-size-1 pipeline)
 from tvidz_amd import corpus as tc, sharded, synth  # noqa: E402
 
 Q = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
@@ -24,11 +24,12 @@ ids, offs, keys = synth.synth_timestamp_corpus(C, seed=synth.CORPUS_SEED)
 queries = synth.synth_queries(ids, offs, keys, Q, seed=synth.CORPUS_SEED + 1)
 d_q, d_off, max_len = tc.pack_queries(queries, dev)
 rows = []
+comm = sharded.make_comm(0)
 for N in (1, 2, 4, 8):
     s_ids, s_offs, s_keys = sharded.shard_csr(ids, offs, keys, 0, N)
     dc = tc.DeviceCorpus(0)
     dc.upload_csr(s_ids, s_offs, s_keys)
-    sm = bench.LocalMatcher(dc, 16, 16384, dev)
+    sm = sharded.RcclShardedMatcher(dc, comm, k=16, cap=16384)
     for _ in range(3):
         sm.match_topk(d_q, d_off, max_len, 2)
     torch.cuda.synchronize()
@@ -44,6 +45,7 @@ for N in (1, 2, 4, 8):
     ms = (time.perf_counter() - t0) * 1e3 / steps
     rows.append({"n_gpus": N, "shard_rows": int(len(s_ids)), "ms_per_batch": round(ms, 4)})
     dc.close()
+comm.close()
 t1 = rows[0]["ms_per_batch"]
 for r in rows:
     r["predicted_speedup"] = round(t1 / r["ms_per_batch"], 2)

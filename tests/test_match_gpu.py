@@ -225,6 +225,44 @@ def test_topk_merges_gathered_shards(dc):
         assert [tuple(int(x) for x in r) for r in out[q]] == exp
 
 
+@pytest.mark.parametrize("R,k", [(8, 16), (16, 64), (3, 1), (8, 40), (20, 64)])
+def test_merge_of_gathered_rank_blocks(dc, R, k):
+    """tvz_topk_merge over [R, Q, k+1, 3] blocks as the all-gather delivers them (one wave per query
+    while R*k <= 1024, the block kernel beyond): order (kth, video_id, count), padding, totals =
+    sum of |n| negated when any shard overflowed; ties of hundreds of entries in one kth (true
+    duplicates on every rank) take the wave kernel's k-rounds path."""
+    rng = np.random.default_rng(R * 100 + k)
+    Q = 37
+    g = np.zeros((R, Q, k + 1, 3), dtype=np.int32)
+    exp_tot = []
+    for q in range(Q):
+        tot, over = 0, False
+        style = q % 4           # 0: spread kth, 1: everything kth == 3 (a big tie), 2: sparse, 3: empty
+        for r in range(R):
+            m = {0: k, 1: k, 2: int(rng.integers(0, 3)), 3: 0}[style]
+            ent = []
+            for _ in range(m):
+                kth = 3 if style == 1 else int(rng.integers(0, 50))
+                ent.append((kth, int(rng.integers(0, 2000)), int(rng.integers(1, 9))))
+            ent.sort()
+            for j in range(k):
+                g[r, q, j] = (ent[j][1], ent[j][2], ent[j][0]) if j < m else (-1, 0, NEVER)
+            n = m + int(rng.integers(0, 5))
+            neg = bool(rng.random() < 0.15) and n > 0
+            g[r, q, k] = (-1, -n if neg else n, NEVER)
+            tot += n
+            over = over or neg
+        exp_tot.append(-tot if over else tot)
+    merged, totals = tc.topk_merge(torch.from_numpy(g).to(DEV), k)
+    merged, totals = merged.cpu().numpy(), totals.cpu().numpy()
+    assert totals.tolist() == exp_tot
+    for q in range(Q):
+        flat = [tuple(int(x) for x in e) for r in range(R) for e in g[r, q, :k] if e[0] >= 0]
+        exp = sorted(flat, key=lambda h: (h[2], h[0], h[1]))[:k]
+        exp += [(-1, 0, NEVER)] * (k - len(exp))
+        assert [tuple(int(x) for x in r) for r in merged[q]] == exp, q
+
+
 def test_concurrent_find_duplicates_threads(dc):
     import threading
     ids, offs, keys = synth.synth_timestamp_corpus(1500, seed=8, mean_len=50, dup_frac=0.05)

@@ -136,7 +136,8 @@ static int tvz_match_sharded_impl(tvz_corpus *c, tvz_comm *comm, const double *d
     const size_t count = (size_t)Q * (size_t)(k + 1) * 3;
     if (int rc = g_api.AllGather(local, gathered, count, kNcclInt32, comm->comm, st))
         return nccl_fail("ncclAllGather", rc);
-    return tvz_topk_merge(gathered, comm->n_ranks, Q, k, d_topk, d_totals, hip_stream);
+    return tvz_topk_merge_ws(gathered, comm->n_ranks, Q, k, d_topk, d_totals, d_workspace, max_query_len, cap,
+                             hip_stream);
 }
 
 TVZ_EXPORT int tvz_comm_unique_id(void *out_id) { TVZ_GUARDED(tvz_comm_unique_id_impl(out_id)); }

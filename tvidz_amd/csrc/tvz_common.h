@@ -62,5 +62,7 @@ int tvz_match_topk_local(tvz_corpus *c, const double *d_queries, const int64_t *
                          const int32_t *d_exclude_ids, int32_t cap, int32_t k, int32_t *d_out,
                          void *d_workspace, size_t workspace_bytes, int32_t n_ranks, int32_t algo,
                          void *hip_stream, int32_t **gathered_out);
+int tvz_topk_merge_ws(const int32_t *d_gathered, int32_t n_ranks, int32_t Q, int32_t k, int32_t *d_topk,
+                      int32_t *d_totals, void *d_workspace, int32_t max_query_len, int32_t cap, void *hip_stream);
 int32_t *tvz_ws_local_block(void *d_workspace, int32_t Q, int32_t max_query_len, int32_t cap,
                             int32_t k, int32_t n_ranks);

@@ -426,6 +426,7 @@ struct WsLayout {
     int32_t *hits_n = nullptr;      // [Q]
     int32_t *local = nullptr;       // [Q][k+1][3]
     int32_t *gathered = nullptr;    // [n_ranks][Q][k+1][3]
+    int32_t *flags = nullptr;       // [Q] queries the one-wave top-k left to the block kernels
     size_t total = 0;
 };
 
@@ -450,6 +451,8 @@ WsLayout ws_layout(void *base, int32_t Q, int32_t max_query_len, int32_t cap, in
         p += al256((size_t)Q * (size_t)(k + 1) * 12);
         w.gathered = reinterpret_cast<int32_t *>(p);
         p += al256((size_t)(n_ranks > 1 ? n_ranks : 1) * (size_t)Q * (size_t)(k + 1) * 12);
+        w.flags = reinterpret_cast<int32_t *>(p);
+        p += al256((size_t)Q * 4);
     }
     w.total = (size_t)(p - p0) + 256;
     return w;
@@ -666,26 +669,45 @@ int launch_match(tvz_corpus *c, const double *d_queries, const int64_t *d_q_offs
                        d_exclude_ids, cap, d_hits, d_hits_n, ns, ws, ws_bytes, st);
 }
 
+constexpr int kTopkFallbackBlocks = 256 * 5;     // the block kernels behind the one-wave kernel: a chip-full, grid-stride
+
 int launch_topk_local(const int32_t *d_hits, const int32_t *d_hits_n, int32_t ns, int32_t Q, int32_t cap,
-                      int32_t k, int32_t *d_out, int mode, hipStream_t st) {
-    // (one WAVE per query for the short lists of a small shard - registers + DPP minimum, k rounds -
-    // was tried: ~4,000 wave-instructions per query, 28 us per 4096 queries, no faster than a block
-    // each with the kth histogram)
+                      int32_t k, int32_t *d_out, int mode, int32_t *d_flags, hipStream_t st) {
+    // with a flag array (the batched calls' workspace): short lists by one wave each, the block kernel
+    // follows with a small grid for the queries that were flagged
+    const int32_t *flags = nullptr;
+    unsigned grid = (unsigned)Q;
+    if (d_flags && k <= kWsK) {
+        hipLaunchKernelGGL(ts_topk_wave_kernel, dim3((unsigned)tvz::ceil_div(Q, kBlock / 64)), dim3(kBlock), 0, st,
+                           d_hits, d_hits_n, ns, 1, Q, cap, k, d_out, mode, nullptr, d_flags);
+        flags = d_flags;
+        grid = (unsigned)std::min<int64_t>(Q, kTopkFallbackBlocks);
+    }
     if (k <= kSelSmallK)
-        hipLaunchKernelGGL(ts_topk_select_kernel<4 * kSelSmallK>, dim3((unsigned)Q), dim3(kBlock), 0, st, d_hits,
-                           d_hits_n, ns, Q, cap, k, d_out, mode);
+        hipLaunchKernelGGL(ts_topk_select_kernel<4 * kSelSmallK>, dim3(grid), dim3(kBlock), 0, st, d_hits,
+                           d_hits_n, ns, Q, cap, k, d_out, mode, flags);
     else
-        hipLaunchKernelGGL(ts_topk_select_kernel<kSortCap>, dim3((unsigned)Q), dim3(kBlock), 0, st, d_hits,
-                           d_hits_n, ns, Q, cap, k, d_out, mode);
+        hipLaunchKernelGGL(ts_topk_select_kernel<kSortCap>, dim3(grid), dim3(kBlock), 0, st, d_hits,
+                           d_hits_n, ns, Q, cap, k, d_out, mode, flags);
     TVZ_HIP(hipGetLastError());
     return TVZ_OK;
 }
 
 // merge of n_lists per-rank blocks of k + 1 rows (mode 2) / plain top-k over n_lists lists (mode 0)
 int launch_topk_lists(const int32_t *d_lists, const int32_t *d_lists_n, int32_t n_lists, int32_t Q, int32_t cap,
-                      int32_t k, int32_t *d_topk, int mode, int32_t *d_totals, hipStream_t st) {
-    hipLaunchKernelGGL(ts_topk_kernel, dim3((unsigned)Q), dim3(kBlock), 0, st, d_lists, d_lists_n, n_lists, Q,
-                       cap, k, d_topk, mode, d_totals);
+                      int32_t k, int32_t *d_topk, int mode, int32_t *d_totals, int32_t *d_flags, hipStream_t st) {
+    const int32_t *flags = nullptr;
+    unsigned grid = (unsigned)Q;
+    (void)d_flags;
+    if (mode == 2 && k <= kWsK && (int64_t)n_lists * k <= kWsMax) {
+        // n_lists x k entries fit one wave's registers: no block kernel, no flags
+        hipLaunchKernelGGL(ts_topk_wave_kernel, dim3((unsigned)tvz::ceil_div(Q, kBlock / 64)), dim3(kBlock), 0, st,
+                           d_lists, nullptr, 1, n_lists, Q, cap, k, d_topk, 2, d_totals, nullptr);
+        TVZ_HIP(hipGetLastError());
+        return TVZ_OK;
+    }
+    hipLaunchKernelGGL(ts_topk_kernel, dim3(grid), dim3(kBlock), 0, st, d_lists, d_lists_n, n_lists, Q,
+                       cap, k, d_topk, mode, d_totals, flags);
     TVZ_HIP(hipGetLastError());
     return TVZ_OK;
 }
@@ -724,8 +746,16 @@ int tvz_match_topk_local(tvz_corpus *c, const double *d_queries, const int64_t *
     if (int rc = launch_match(c, d_queries, d_q_offsets, Q, max_query_len, min_match, d_exclude_ids,
                               cap, w.hits, w.counters, kCountStride, w.join, w.join_bytes, algo, st))
         return rc;
-    if (int rc = launch_topk_local(w.hits, w.counters, kCountStride, Q, cap, k, d_out, 1, st)) return rc;
+    if (int rc = launch_topk_local(w.hits, w.counters, kCountStride, Q, cap, k, d_out, 1, w.flags, st)) return rc;
     return record(c, st);
+}
+
+// merge of the gathered per-rank blocks with the workspace's flag array (tvz_match_sharded)
+int tvz_topk_merge_ws(const int32_t *d_gathered, int32_t n_ranks, int32_t Q, int32_t k, int32_t *d_topk,
+                      int32_t *d_totals, void *d_workspace, int32_t max_query_len, int32_t cap, void *hip_stream) {
+    const WsLayout w = ws_layout(d_workspace, Q, max_query_len, cap, k, n_ranks);
+    return launch_topk_lists(d_gathered, nullptr, n_ranks, Q, k + 1, k, d_topk, 2, d_totals, w.flags,
+                             reinterpret_cast<hipStream_t>(hip_stream));
 }
 
 int32_t *tvz_ws_local_block(void *d_workspace, int32_t Q, int32_t max_query_len, int32_t cap,
@@ -1319,8 +1349,8 @@ static int tvz_topk_impl(const int32_t *d_lists, const int32_t *d_lists_n, int32
     if (Q == 0) return TVZ_OK;
     TVZ_REQUIRE((d_lists || cap == 0) && d_topk, "NULL argument");
     hipStream_t st = reinterpret_cast<hipStream_t>(hip_stream);
-    if (n_lists == 1) return launch_topk_local(d_lists, d_lists_n, 1, Q, cap, k, d_topk, 0, st);
-    return launch_topk_lists(d_lists, d_lists_n, n_lists, Q, cap, k, d_topk, 0, nullptr, st);
+    if (n_lists == 1) return launch_topk_local(d_lists, d_lists_n, 1, Q, cap, k, d_topk, 0, nullptr, st);
+    return launch_topk_lists(d_lists, d_lists_n, n_lists, Q, cap, k, d_topk, 0, nullptr, nullptr, st);
 }
 
 static int tvz_topk_shard_impl(const int32_t *d_hits, const int32_t *d_hits_n, int32_t Q,
@@ -1329,7 +1359,7 @@ static int tvz_topk_shard_impl(const int32_t *d_hits, const int32_t *d_hits_n, i
     TVZ_REQUIRE(k >= 1 && k <= kSortCap / 2, "k=%d out of range [1, %d]", k, kSortCap / 2);
     if (Q == 0) return TVZ_OK;
     TVZ_REQUIRE((d_hits || cap == 0) && d_hits_n && d_out, "NULL argument");
-    return launch_topk_local(d_hits, d_hits_n, 1, Q, cap, k, d_out, 1, reinterpret_cast<hipStream_t>(hip_stream));
+    return launch_topk_local(d_hits, d_hits_n, 1, Q, cap, k, d_out, 1, nullptr, reinterpret_cast<hipStream_t>(hip_stream));
 }
 
 static int tvz_topk_merge_impl(const int32_t *d_gathered, int32_t n_ranks, int32_t Q, int32_t k,
@@ -1338,7 +1368,7 @@ static int tvz_topk_merge_impl(const int32_t *d_gathered, int32_t n_ranks, int32
     TVZ_REQUIRE(k >= 1 && k <= kSortCap / 2, "k=%d out of range [1, %d]", k, kSortCap / 2);
     if (Q == 0) return TVZ_OK;
     TVZ_REQUIRE(d_gathered && d_topk, "NULL argument");
-    return launch_topk_lists(d_gathered, nullptr, n_ranks, Q, k + 1, k, d_topk, 2, d_totals,
+    return launch_topk_lists(d_gathered, nullptr, n_ranks, Q, k + 1, k, d_topk, 2, d_totals, nullptr,
                              reinterpret_cast<hipStream_t>(hip_stream));
 }
 

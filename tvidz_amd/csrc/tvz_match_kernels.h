@@ -728,15 +728,19 @@ __global__ __launch_bounds__(kBlock) void ts_topk_kernel(const int32_t *__restri
                                                          const int32_t *__restrict__ lists_n,
                                                          int32_t n_lists, int32_t Q, int32_t cap,
                                                          int32_t k, int32_t *__restrict__ topk,
-                                                         int32_t mode, int32_t *__restrict__ totals) {
+                                                         int32_t mode, int32_t *__restrict__ totals,
+                                                         const int32_t *__restrict__ flags) {
     // mode 0: plain.  mode 1 (shard side): the output has k+1 rows per query, row k carries the
     // true number of hits as (-1, n, NEVER) so one all-gather moves lists and totals together; n is
     // NEGATED when the shard's hit list overflowed its capacity (its top-k may then be inexact).
     // mode 2 (merge side): every input list ends with such a row; |n| is summed into totals[q], and
     // the sum is negated if any shard overflowed, so the caller knows to re-run with a larger cap.
+    // flags != NULL: ts_topk_wave_kernel went first; this kernel is launched with a small grid and
+    // takes only the queries it flagged (block-uniform loop).
     __shared__ uint64_t key[kSortCap];
     __shared__ int32_t cnt[kSortCap];
-    const int q = blockIdx.x;
+    for (int q = blockIdx.x; q < Q; q += gridDim.x) {
+    if (flags && flags[q] == 0) continue;
     int pos = 0;  // block-uniform fill level
     long long total = 0;
     bool overflow = false;
@@ -799,6 +803,8 @@ __global__ __launch_bounds__(kBlock) void ts_topk_kernel(const int32_t *__restri
             o[1] = cnt[i];
             o[2] = (int32_t)(uint32_t)(kk >> 32) - 1;
         }
+    }
+    __syncthreads();
     }
 }
 
@@ -1148,7 +1154,7 @@ __device__ __forceinline__ int sel_bin(int32_t kth) {
 template <int kSelCap>
 __global__ __launch_bounds__(kBlock) void ts_topk_select_kernel(
     const int32_t *__restrict__ lists, const int32_t *__restrict__ lists_n, int32_t ns, int32_t Q,
-    int32_t cap, int32_t k, int32_t *__restrict__ topk, int32_t mode) {
+    int32_t cap, int32_t k, int32_t *__restrict__ topk, int32_t mode, const int32_t *__restrict__ flags) {
     constexpr int kSelChunk = kSelCap / 2;
     static_assert(kSelChunk % kBlock == 0, "whole passes of the block");
     __shared__ uint64_t key[kSelCap];
@@ -1156,7 +1162,9 @@ __global__ __launch_bounds__(kBlock) void ts_topk_select_kernel(
     __shared__ uint32_t hist[kSelBins];
     __shared__ uint32_t part[kBlock];
     __shared__ int32_t s_pos, s_bin;
-    const int q = blockIdx.x;
+    // flags != NULL: ts_topk_wave_kernel went first and flagged the queries it left to this kernel
+    for (int q = blockIdx.x; q < Q; q += gridDim.x) {
+    if (flags && flags[q] == 0) continue;
     const int32_t total = lists_n ? lists_n[(size_t)q * ns] : cap;
     const bool overflow = total > cap;
     const int n = total > cap ? cap : (total < 0 ? 0 : total);
@@ -1252,6 +1260,233 @@ __global__ __launch_bounds__(kBlock) void ts_topk_select_kernel(
             o[0] = (int32_t)(uint32_t)kk;
             o[1] = cnt[i];
             o[2] = (int32_t)(uint32_t)(kk >> 32) - 1;
+        }
+    }
+    __syncthreads();
+    }
+}
+
+// ---- top-k of SHORT inputs: one wave per query, no block barrier ---------------------------
+// A 1/8 shard's hit list (~260 hits per query) and the merge of the gathered per-rank lists
+// (n_ranks x k entries) are a few hundred entries; a 256-thread block each, with ~30 block barriers,
+// spent 30 us + 15 us per 4096-query batch on them - a third of a sharded batch - and most of that
+// is the launch rate of 4096 blocks and barrier latency, not work.  Here a wave takes a query of up
+// to 1024 entries (16 per lane, in registers): a histogram of kth in the wave's own LDS (two 16-bit
+// bins per word) gives the threshold bin; the entries up to that bin - k plus the ties of one bin,
+// normally a handful more than k - are compacted one per lane and sorted by a bitonic network over
+// the lanes (more than 64 of them: k rounds of wave-minimum instead).  Same order and output rows
+// as ts_topk_select_kernel / ts_topk_kernel.  A list of more than 1024 entries is FLAGGED and left
+// to the block kernel, which follows with a small grid and takes only the flagged queries.
+constexpr int kWsE = 16;
+constexpr int kWsMax = 64 * kWsE;
+constexpr int kWsK = 64;                                      // lane i writes output row i
+constexpr int kWsPerLane = ((kSelBins + 1) / 2 + 63) / 64;   // 33 words (66 bins) per lane
+constexpr int kWsWords = kWsPerLane * 64;
+static_assert(kWsWords * 2 >= kSelBins && (kWsPerLane & 1) == 1, "bins covered; odd stride = no bank conflicts");
+
+__global__ __launch_bounds__(kBlock) void ts_topk_wave_kernel(
+    const int32_t *__restrict__ lists, const int32_t *__restrict__ lists_n, int32_t ns, int32_t n_lists,
+    int32_t Q, int32_t cap, int32_t k, int32_t *__restrict__ topk, int32_t mode,
+    int32_t *__restrict__ totals, int32_t *__restrict__ flags) {
+    __shared__ uint32_t s_hist[kBlock / 64][kWsWords];
+    const int lane = threadIdx.x & 63;
+    const int q = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    if (q >= Q) return;                        // no block barrier below: waves are on their own
+    uint32_t *h = s_hist[threadIdx.x >> 6];
+    int n;                                     // entries to look at
+    int32_t total_row = 0;                     // mode 1: the shard's hit count (negated on overflow)
+    if (mode == 2) {
+        n = n_lists * (cap - 1);               // cap = k + 1 rows per gathered list, the last one = totals
+    } else {
+        const int32_t total = lists_n ? lists_n[(size_t)q * ns] : cap;
+        n = total > cap ? cap : (total < 0 ? 0 : total);
+        total_row = total > cap ? -total : total;
+    }
+    if (n > kWsMax) {                          // the block kernel's (the host passes flags whenever this can happen)
+        if (lane == 0) flags[q] = 1;
+        return;
+    }
+    uint64_t key[kWsE];
+    int32_t cnt[kWsE];
+    int bin[kWsE];
+#pragma unroll
+    for (int e = 0; e < kWsE; ++e) {
+        const int i = lane + 64 * e;
+        key[e] = ~0ULL;
+        cnt[e] = 0;
+        bin[e] = -1;                           // -1: no entry
+        if (i < n) {
+            const int32_t *src;
+            if (mode == 2) {
+                const int l = i / (cap - 1), j = i - l * (cap - 1);
+                src = lists + (((int64_t)l * Q + q) * cap + j) * 3;
+            } else {
+                src = lists + ((int64_t)q * cap + i) * 3;
+            }
+            const int32_t vid = src[0];
+            if (vid >= 0) {
+                key[e] = sort_key(vid, src[2]);
+                cnt[e] = src[1];
+                bin[e] = sel_bin(src[2]);
+            }
+        }
+    }
+#pragma unroll
+    for (int w = 0; w < kWsPerLane; ++w) h[lane + 64 * w] = 0;
+    wave_lds_fence();
+#pragma unroll
+    for (int e = 0; e < kWsE; ++e)
+        if (bin[e] >= 0) atomicAdd(&h[bin[e] >> 1], 1u << ((bin[e] & 1) * 16));
+    wave_lds_fence();
+    // lane l owns words 33 l .. 33 l + 32 (bins 66 l .. 66 l + 65)
+    uint32_t mine = 0;
+#pragma unroll
+    for (int w = 0; w < kWsPerLane; ++w) {
+        const uint32_t v = h[lane * kWsPerLane + w];
+        mine += (v & 0xffffu) + (v >> 16);
+    }
+    uint32_t incl = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = __shfl_up(incl, d);
+        if (lane >= d) incl += o;
+    }
+    const uint32_t tot = __shfl(incl, 63);
+    const uint32_t need = tot < (uint32_t)k ? tot : (uint32_t)k;
+    int n_cand = 0;
+    uint64_t mk = ~0ULL;
+    int32_t mc = 0;
+    bool fits = true;
+    if (tot) {
+        // threshold bin B: the first whose inclusive prefix reaches `need`; the owner lane walks its bins
+        const unsigned long long reach = __ballot(incl >= need);
+        const int owner = __ffsll((long long)reach) - 1;
+        // the owner's 33 words are re-read one per lane (lane j: word j of the owner), a scan over the
+        // lanes finds the bin (a serial walk by the owner alone was 500 of this kernel's 1,700 instructions)
+        const uint32_t before = __shfl(incl - mine, owner);          // entries in the bins of lower lanes
+        const uint32_t wv = lane < kWsPerLane ? h[owner * kWsPerLane + lane] : 0u;
+        const uint32_t c0 = wv & 0xffffu, c1 = wv >> 16;
+        uint32_t wincl = c0 + c1;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t o = __shfl_up(wincl, d);
+            if (lane >= d) wincl += o;
+        }
+        const unsigned long long wreach = __ballot(before + wincl >= need);
+        const int wl = __ffsll((long long)wreach) - 1;                // the word that holds bin B
+        const uint32_t below = before + wincl - (c0 + c1);            // entries before that word (lane wl's view)
+        const bool first = below + c0 >= need;                        // B is the word's low bin?
+        const int B = __shfl(2 * (owner * kWsPerLane + lane) + (first ? 0 : 1), wl);
+        const uint32_t upto = __shfl(below + c0 + (first ? 0u : c1), wl);
+        fits = upto <= 64u;
+        if (fits) {
+            wave_lds_fence();                  // the histogram is dead: its first words become the candidate list
+            uint64_t *ck = reinterpret_cast<uint64_t *>(h);          // [64] keys
+            int32_t *cc = reinterpret_cast<int32_t *>(h + 128);      // [64] counts
+            uint32_t base = 0;
+#pragma unroll
+            for (int e = 0; e < kWsE; ++e) {
+                const bool is = bin[e] >= 0 && bin[e] <= B;
+                const unsigned long long bal = __ballot(is);
+                const uint32_t ofs = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32),
+                                     __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+                if (is) { ck[base + ofs] = key[e]; cc[base + ofs] = cnt[e]; }
+                base += (uint32_t)__popcll(bal);
+            }
+            wave_lds_fence();
+            n_cand = (int)upto;
+            if (lane < n_cand) { mk = ck[lane]; mc = cc[lane]; }
+            // bitonic network over the 64 lanes, ascending by (key, count)
+#pragma unroll
+            for (int size = 2; size <= 64; size <<= 1) {
+#pragma unroll
+                for (int stride = size >> 1; stride > 0; stride >>= 1) {
+                    const uint64_t ok = __shfl_xor(mk, stride);
+                    const int32_t oc = __shfl_xor(mc, stride);
+                    const bool keep_min = ((lane & stride) == 0) == ((lane & size) == 0);
+                    const bool other_less = ok < mk || (ok == mk && oc < mc);
+                    const bool other_more = ok > mk || (ok == mk && oc > mc);
+                    if (keep_min ? other_less : other_more) { mk = ok; mc = oc; }
+                }
+            }
+        }
+    }
+    if (flags && lane == 0) flags[q] = 0;
+    if (!fits) {
+        // more than 64 entries up to the threshold bin (a big tie: e.g. hundreds of true duplicates
+        // with the same kth).  Rare, so simple: k rounds, each takes the minimum of what is left -
+        // per-lane minimum, DPP butterfly inside the 16-lane rows, the four rows through scalar
+        // registers - and removes exactly one copy of it.  Lane r keeps output row r.
+        mk = ~0ULL;
+        mc = 0;
+        for (int r = 0; r < k; ++r) {
+            uint64_t bk = key[0];
+            int32_t bc = cnt[0];
+#pragma unroll
+            for (int e = 1; e < kWsE; ++e)
+                if (key[e] < bk || (key[e] == bk && cnt[e] < bc)) { bk = key[e]; bc = cnt[e]; }
+            uint64_t wk = bk;
+            int32_t wc = bc;
+#define TVZ_MIN_STEP(CTRL)                                                               \
+            {                                                                              \
+                const uint64_t ok = dpp16_64<CTRL>(wk);                                    \
+                const int32_t oc = (int32_t)dpp16<CTRL>((uint32_t)wc);                     \
+                if (ok < wk || (ok == wk && oc < wc)) { wk = ok; wc = oc; }                \
+            }
+            TVZ_ROW16_BUTTERFLY(TVZ_MIN_STEP)
+#undef TVZ_MIN_STEP
+            uint64_t rk = ~0ULL;
+            int32_t rc = 0;
+#pragma unroll
+            for (int row = 0; row < 4; ++row) {
+                const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)wk, row * 16);
+                const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(wk >> 32), row * 16);
+                const int32_t oc = __builtin_amdgcn_readlane(wc, row * 16);
+                const uint64_t ok = ((uint64_t)hi << 32) | lo;
+                if (row == 0 || ok < rk || (ok == rk && oc < rc)) { rk = ok; rc = oc; }
+            }
+            if (rk == ~0ULL) break;            // nothing left: the remaining rows are padding
+            if (lane == r) { mk = rk; mc = rc; }
+            const unsigned long long holders = __ballot(bk == rk && bc == rc);
+            if (lane == __ffsll((long long)holders) - 1) {
+                bool gone = false;
+#pragma unroll
+                for (int e = 0; e < kWsE; ++e)
+                    if (!gone && key[e] == rk && cnt[e] == rc) { key[e] = ~0ULL; gone = true; }
+            }
+        }
+    }
+    const int orows = (mode == 1) ? k + 1 : k;
+    if (lane < k) {
+        int32_t *o = topk + ((int64_t)q * orows + lane) * 3;
+        if (mk == ~0ULL) {
+            o[0] = -1; o[1] = 0; o[2] = TVZ_KTH_NEVER;
+        } else {
+            o[0] = (int32_t)(uint32_t)mk;
+            o[1] = mc;
+            o[2] = (int32_t)(uint32_t)(mk >> 32) - 1;
+        }
+    }
+    if (mode == 1 && lane == 0) {
+        int32_t *o = topk + ((int64_t)q * orows + k) * 3;
+        o[0] = -1; o[1] = total_row; o[2] = TVZ_KTH_NEVER;
+    }
+    if (mode == 2 && totals) {
+        // every gathered list ends with (-1, n, NEVER): |n| summed, negated if any shard overflowed
+        long long sum = 0;
+        bool over = false;
+        for (int l = lane; l < n_lists; l += 64) {
+            const int32_t t = lists[(((int64_t)l * Q + q) * cap + (cap - 1)) * 3 + 1];
+            sum += t < 0 ? -(long long)t : t;
+            over = over || t < 0;
+        }
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) sum += __shfl_xor(sum, d);
+        over = __ballot(over) != 0ULL;
+        if (lane == 0) {
+            int32_t t = sum > 0x7fffffffLL ? 0x7fffffff : (int32_t)sum;
+            if (over) t = (t == 0) ? INT32_MIN : -t;
+            totals[q] = t;
         }
     }
 }

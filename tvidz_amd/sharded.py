@@ -115,6 +115,8 @@ def make_comm(device: int, group=None):
     """Create the libtvz RCCL communicator of this rank.  torch.distributed (any backend) is used
     ONLY to ship rank 0's 128-byte unique id; a non-Python host ships it by its own means."""
     from . import corpus as tc
+    if not dist.is_initialized():          # a single process: a one-rank communicator, same data path
+        return tc.Comm(tc.Comm.unique_id(), 1, 0, device)
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     box = [tc.Comm.unique_id() if rank == 0 else None]
     dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0,
