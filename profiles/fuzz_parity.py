@@ -2,8 +2,10 @@
 """Randomised differential soak: HIP path vs the oracle for N seconds (default 60).
    python profiles/fuzz_parity.py [seconds] [seed]
 Matcher: random corpora (sizes, row lengths, duplicates, special values), random batches, every
-min_match / exclusion / cap / kernel choice (tile, join, long-query).  Scene: random shapes, pitches,
-bit depths, chunkings.  Prints a summary line; exits non-zero at the first mismatch."""
+min_match / exclusion / cap / algorithm choice (index, Q1, tile, join, long-query), with random
+upserts between the upload and the match (replaced rows = stale postings + delta table, new rows,
+emptied rows, occasional explicit index rebuilds).  Scene: random shapes, pitches, bit depths,
+chunkings.  Prints a summary line; exits non-zero at the first mismatch."""
 import json, os, sys, time
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -17,7 +19,7 @@ lib = _lib.load()
 dev = torch.device("cuda:0")
 dc = tc.DeviceCorpus(0)
 special = np.array([0.0, -0.0, np.nan, np.inf, -np.inf, 5e-324, 1e300, 1.5, 0.1 + 0.2, 0.3])
-stats = {"match_cases": 0, "pairs": 0, "scene_cases": 0, "frames": 0}
+stats = {"match_cases": 0, "pairs": 0, "upserts": 0, "scene_cases": 0, "frames": 0}
 t_end = time.time() + SECONDS
 t_note = time.time() + 30
 
@@ -41,6 +43,24 @@ while time.time() < t_end:
         a, b = rng.integers(0, C, 2)
         rows[b] = (rows[b][0], list(rows[a][1]))
     dc.upload(rows)
+    # add_timestamps between the index build and the match (db.py:43-64: replaces the FIRST row of the video)
+    for _ in range(int(rng.choice([0, 0, 1, 5, 40]))):
+        kind = rng.random()
+        if kind < 0.5 and rows:
+            v = rows[int(rng.integers(0, len(rows)))][0]
+        else:
+            v = int(rng.integers(1, 10 * C + 50))
+        ts = [] if rng.random() < 0.1 else rand_keys(int(rng.choice([1, 3, 30, 300])), grid).tolist()
+        dc.upsert(v, ts)
+        first = next((i for i, (vv, _) in enumerate(rows) if vv == v), None)
+        if first is None:
+            rows.append((v, ts))
+        else:
+            rows[first] = (v, ts)
+        stats["upserts"] += 1
+    if rng.random() < 0.1:
+        dc.build_index()
+    C = len(rows)
     ids, offs, keys = tc.rows_to_csr(rows)
     Q = int(rng.choice([1, 2, 17, 70, 300]))
     queries = [rand_keys(int(rng.choice([0, 1, 5, 60, 250, 900])), grid) for _ in range(Q)]
@@ -49,7 +69,9 @@ while time.time() < t_end:
     mm = int(rng.choice([-1, 0, 1, 2, 2, 2, 3, 5, 6, 9]))
     excl = None if rng.random() < 0.5 else [int(rng.integers(1, 10 * C + 2)) for _ in range(Q)]
     cap = int(rng.choice([1, 5, max(C, 1)]))
-    mode = int(rng.choice([_lib.ALGO_AUTO, _lib.ALGO_Q1, _lib.ALGO_TILE, _lib.ALGO_JOIN]))   # per call
+    mode = int(rng.choice([_lib.ALGO_AUTO, _lib.ALGO_AUTO, _lib.ALGO_INDEX, _lib.ALGO_Q1, _lib.ALGO_TILE, _lib.ALGO_JOIN]))
+    if mode == _lib.ALGO_INDEX and not 1 <= mm <= 5:
+        mode = _lib.ALGO_AUTO                      # the index answers min_match 1..5 only (an error otherwise)
     d_q, d_off, ml = tc.pack_queries(queries, dev)
     d_ex = torch.tensor(excl, dtype=torch.int32, device=dev) if excl is not None else None
     hits, n = dc.match(d_q, d_off, ml, mm, cap, d_exclude_ids=d_ex, algo=mode)
