@@ -240,12 +240,20 @@ class Comm:
                       max_query_len: int, min_match: int, cap: int, k: int,
                       d_exclude_ids: Optional[torch.Tensor] = None,
                       workspace: Optional[torch.Tensor] = None,
-                      stream: Optional[torch.cuda.Stream] = None, algo: int = _lib.ALGO_AUTO):
-        """local sweep + top-k -> ncclAllGather -> merge, all enqueued on `stream` by ONE library
-        call; -> (merged int32 [Q,k,3], totals int32 [Q]), identical on every rank."""
+                      stream: Optional[torch.cuda.Stream] = None, algo: int = _lib.ALGO_AUTO,
+                      out: Optional[Tuple[torch.Tensor, torch.Tensor]] = None):
+        """local match + top-k -> ncclAllGather -> merge, all enqueued on `stream` by ONE library
+        call; -> (merged int32 [Q,k,3], totals int32 [Q]), identical on every rank.  `out` =
+        (merged, totals) buffers to write into (a caller streaming batches keeps its own)."""
         dev, Q = corpus._check_queries(d_queries, d_q_offsets)
-        merged = torch.empty((Q, k, 3), dtype=torch.int32, device=dev)
-        totals = torch.empty(Q, dtype=torch.int32, device=dev)
+        if out is not None:
+            merged, totals = out
+            if merged.shape != (Q, k, 3) or totals.shape != (Q,) or merged.dtype != torch.int32 \
+                    or totals.dtype != torch.int32 or not merged.is_contiguous():
+                raise RuntimeError("out must be (int32 [Q,k,3], int32 [Q])")
+        else:
+            merged = torch.empty((Q, k, 3), dtype=torch.int32, device=dev)
+            totals = torch.empty(Q, dtype=torch.int32, device=dev)
         s = stream if stream is not None else torch.cuda.current_stream(dev)
         ws = corpus._workspace(workspace, workspace_bytes(Q, max_query_len, cap, k, self.n_ranks), dev, s)
         _lib.check(self.lib.tvz_match_sharded(
