@@ -236,9 +236,6 @@ __global__ __launch_bounds__(kIxBlock) void ts_match_index_kernel(
         return;
     }
     const int n = (int)n64;
-#if defined(TVZ_IX_STOP) && TVZ_IX_STOP == 0
-    return;
-#endif
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (threadIdx.x == 0) { s_m = 0; s_total = 0; s_emitted = 0; s_nlist = 0; }
     for (int i = threadIdx.x; i < kIxWords; i += kIxBlock) { bm1[i] = 0; bm2[i] = 0; }
@@ -286,9 +283,6 @@ __global__ __launch_bounds__(kIxBlock) void ts_match_index_kernel(
         if (threadIdx.x == kIxBlock - 1) { s_total = pbase + incl; s_m = lbase + lincl; }
         __syncthreads();
     }
-#if defined(TVZ_IX_STOP) && TVZ_IX_STOP == 1
-    return;
-#endif
     const int m = (int)s_m;
     const uint32_t total = s_total;                    // <= 4095 lists x 32768 rows: fits 32 bits
     if (threadIdx.x == 0) s_pre[m] = total;
@@ -336,9 +330,6 @@ __global__ __launch_bounds__(kIxBlock) void ts_match_index_kernel(
             }
         }
     }
-#if defined(TVZ_IX_STOP) && TVZ_IX_STOP == 2
-    return;
-#endif
     __syncthreads();
     const uint32_t *cand = min_match >= 2 ? bm2 : bm1;
     // ---- rank: candidates before every bitmap word (512 words, one per thread) ----
@@ -360,9 +351,6 @@ __global__ __launch_bounds__(kIxBlock) void ts_match_index_kernel(
     }
     static_assert(kIxWords == kIxBlock, "one bitmap word per thread");
     static_assert(kIxSlots % kIxBlock == 0, "whole rounds of the block over the emit list");
-#if defined(TVZ_IX_STOP) && TVZ_IX_STOP == 3
-    return;
-#endif
     const uint32_t n_cand = s_base;
     const int32_t excl = exclude_ids ? exclude_ids[q] : exclude_one;
     const int64_t row0 = (int64_t)sub << kSubLog2;
@@ -401,9 +389,6 @@ __global__ __launch_bounds__(kIxBlock) void ts_match_index_kernel(
                 }
             }
         }
-#if defined(TVZ_IX_STOP) && TVZ_IX_STOP == 4
-        return;
-#endif
         __syncthreads();
         // emit, stage 1: thread <-> bitmap word; candidates of this part that reached min_match go to
         // an LDS list (row in the sub-index << kIxSlotBits | slot).  Looking their video ids up right here,
@@ -451,9 +436,6 @@ __global__ __launch_bounds__(kIxBlock) void ts_match_index_kernel(
             s_nlist = 0;
         }
         __syncthreads();
-#if defined(TVZ_IX_STOP) && TVZ_IX_STOP == 5
-        return;
-#endif
         uint32_t o = s_base + base + incl - mine;
         const int64_t room = HOSTOUT ? (int64_t)kSubRows : (int64_t)cap;
 #pragma unroll
