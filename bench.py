@@ -439,6 +439,9 @@ def main():
         cpu, cpu_sad = cpu_baseline_scene(res["frames"], args.cpu_frames, args.cpu_threads)
         gpu_sad = res["scorer"].sad[:len(cpu_sad)].cpu().numpy().view(np.uint64)
         cpu["agrees_with_gpu"] = bool((gpu_sad == cpu_sad).all())
+        # the restatement on ONE core as well as on all of them
+        one, _ = cpu_baseline_scene(res["frames"], min(args.cpu_frames, 256), 1, min_seconds=1.0)
+        cpu["single_core"] = {"value": one["value"], "unit": "frames/s", "cores": 1, "sample": one["sample"]}
         out["cpu_baseline"] = cpu
     else:
         out["cpu_baseline"] = None

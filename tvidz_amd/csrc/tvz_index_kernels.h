@@ -14,15 +14,16 @@
 //          sweep kernels read).
 //
 // One block per (query, sub-index).  A query of n elements whose keys have p postings in the
-// sub-index costs n directory probes + 2 p two-byte posting reads, whatever the corpus size
+// sub-index costs n directory probes + p two-byte posting reads, whatever the corpus size
 // (config 4: ~16,500 postings = 33 KB per query over 7 sub-indexes, against 160 MB for a sweep):
 //   pass A  every posting sets its row's bit in `seen1`, or in `seen2` if seen1 was set already:
 //           only rows in seen2 (seen1 for min_match 1) can reach min_match; the bitmaps cover the
 //           sub-index exactly (16,384 bits), so the candidates are known row by row;
 //   rank    prefix popcount of the candidate bitmap: candidate -> dense slot, no hashing;
-//   pass B  the postings are walked again; a candidate's (count, five smallest query positions)
-//           accumulate in its slot - 1,024 slots at a time if there are more candidates; the walk
-//           reads the (row, position) pairs pass A left in LDS, not the posting lists again;
+//   pass B  the postings are walked again - from the (row, position) pairs pass A left in LDS (the
+//           first 4,096; the lists themselves beyond that); a candidate's count and smallest query
+//           positions (two atomicMin words for min_match <= 2, five 12-bit positions in a CAS word
+//           for 3..5) accumulate in its slot - 1,024 slots at a time if there are more candidates;
 //   emit    candidates with count >= min_match, (video_id, count, kth) exactly as the sweeps emit
 //           them: one reservation per block in the query's hit list (or the block's own region of
 //           pinned host memory for tvz_find_duplicates).
