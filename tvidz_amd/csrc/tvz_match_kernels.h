@@ -1271,7 +1271,7 @@ __global__ __launch_bounds__(kBlock) void ts_topk_select_kernel(
 // (n_ranks x k entries) are a few hundred entries; a 256-thread block each, with ~30 block barriers,
 // spent 30 us + 15 us per 4096-query batch on them - a third of a sharded batch - and most of that
 // is the launch rate of 4096 blocks and barrier latency, not work.  Here a wave takes a query of up
-// to 1024 entries (16 per lane, in registers): a histogram of kth in the wave's own LDS (two 16-bit
+// to 1024 entries (4, 8 or 16 per lane, in registers): a histogram of kth in the wave's own LDS (two 16-bit
 // bins per word) gives the threshold bin; the entries up to that bin - k plus the ties of one bin,
 // normally a handful more than k - are compacted one per lane and sorted by a bitonic network over
 // the lanes (more than 64 of them: k rounds of wave-minimum instead).  Same order and output rows
@@ -1284,33 +1284,17 @@ constexpr int kWsPerLane = ((kSelBins + 1) / 2 + 63) / 64;   // 33 words (66 bin
 constexpr int kWsWords = kWsPerLane * 64;
 static_assert(kWsWords * 2 >= kSelBins && (kWsPerLane & 1) == 1, "bins covered; odd stride = no bank conflicts");
 
-__global__ __launch_bounds__(kBlock) void ts_topk_wave_kernel(
-    const int32_t *__restrict__ lists, const int32_t *__restrict__ lists_n, int32_t ns, int32_t n_lists,
-    int32_t Q, int32_t cap, int32_t k, int32_t *__restrict__ topk, int32_t mode,
-    int32_t *__restrict__ totals, int32_t *__restrict__ flags) {
-    __shared__ uint32_t s_hist[kBlock / 64][kWsWords];
-    const int lane = threadIdx.x & 63;
-    const int q = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
-    if (q >= Q) return;                        // no block barrier below: waves are on their own
-    uint32_t *h = s_hist[threadIdx.x >> 6];
-    int n;                                     // entries to look at
-    int32_t total_row = 0;                     // mode 1: the shard's hit count (negated on overflow)
-    if (mode == 2) {
-        n = n_lists * (cap - 1);               // cap = k + 1 rows per gathered list, the last one = totals
-    } else {
-        const int32_t total = lists_n ? lists_n[(size_t)q * ns] : cap;
-        n = total > cap ? cap : (total < 0 ? 0 : total);
-        total_row = total > cap ? -total : total;
-    }
-    if (n > kWsMax) {                          // the block kernel's (the host passes flags whenever this can happen)
-        if (lane == 0) flags[q] = 1;
-        return;
-    }
-    uint64_t key[kWsE];
-    int32_t cnt[kWsE];
-    int bin[kWsE];
+// the per-wave work for E entries per lane; a wave picks the smallest E that holds its list
+template <int E>
+__device__ __forceinline__ void wave_topk_body(
+    uint32_t *h, const int lane, const int q, const int n, const int32_t total_row,
+    const int32_t *__restrict__ lists, int32_t n_lists, int32_t Q, int32_t cap, int32_t k,
+    int32_t *__restrict__ topk, int32_t mode, int32_t *__restrict__ totals, int32_t *__restrict__ flags) {
+    uint64_t key[E];
+    int32_t cnt[E];
+    int bin[E];
 #pragma unroll
-    for (int e = 0; e < kWsE; ++e) {
+    for (int e = 0; e < E; ++e) {
         const int i = lane + 64 * e;
         key[e] = ~0ULL;
         cnt[e] = 0;
@@ -1335,7 +1319,7 @@ __global__ __launch_bounds__(kBlock) void ts_topk_wave_kernel(
     for (int w = 0; w < kWsPerLane; ++w) h[lane + 64 * w] = 0;
     wave_lds_fence();
 #pragma unroll
-    for (int e = 0; e < kWsE; ++e)
+    for (int e = 0; e < E; ++e)
         if (bin[e] >= 0) atomicAdd(&h[bin[e] >> 1], 1u << ((bin[e] & 1) * 16));
     wave_lds_fence();
     // lane l owns words 33 l .. 33 l + 32 (bins 66 l .. 66 l + 65)
@@ -1385,7 +1369,7 @@ __global__ __launch_bounds__(kBlock) void ts_topk_wave_kernel(
             int32_t *cc = reinterpret_cast<int32_t *>(h + 128);      // [64] counts
             uint32_t base = 0;
 #pragma unroll
-            for (int e = 0; e < kWsE; ++e) {
+            for (int e = 0; e < E; ++e) {
                 const bool is = bin[e] >= 0 && bin[e] <= B;
                 const unsigned long long bal = __ballot(is);
                 const uint32_t ofs = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32),
@@ -1423,7 +1407,7 @@ __global__ __launch_bounds__(kBlock) void ts_topk_wave_kernel(
             uint64_t bk = key[0];
             int32_t bc = cnt[0];
 #pragma unroll
-            for (int e = 1; e < kWsE; ++e)
+            for (int e = 1; e < E; ++e)
                 if (key[e] < bk || (key[e] == bk && cnt[e] < bc)) { bk = key[e]; bc = cnt[e]; }
             uint64_t wk = bk;
             int32_t wc = bc;
@@ -1451,7 +1435,7 @@ __global__ __launch_bounds__(kBlock) void ts_topk_wave_kernel(
             if (lane == __ffsll((long long)holders) - 1) {
                 bool gone = false;
 #pragma unroll
-                for (int e = 0; e < kWsE; ++e)
+                for (int e = 0; e < E; ++e)
                     if (!gone && key[e] == rk && cnt[e] == rc) { key[e] = ~0ULL; gone = true; }
             }
         }
@@ -1489,6 +1473,36 @@ __global__ __launch_bounds__(kBlock) void ts_topk_wave_kernel(
             totals[q] = t;
         }
     }
+}
+
+__global__ __launch_bounds__(kBlock) void ts_topk_wave_kernel(
+    const int32_t *__restrict__ lists, const int32_t *__restrict__ lists_n, int32_t ns, int32_t n_lists,
+    int32_t Q, int32_t cap, int32_t k, int32_t *__restrict__ topk, int32_t mode,
+    int32_t *__restrict__ totals, int32_t *__restrict__ flags) {
+    __shared__ uint32_t s_hist[kBlock / 64][kWsWords];
+    const int lane = threadIdx.x & 63;
+    const int q = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    if (q >= Q) return;                        // no block barrier below: waves are on their own
+    uint32_t *h = s_hist[threadIdx.x >> 6];
+    int n;                                     // entries to look at
+    int32_t total_row = 0;                     // mode 1: the shard's hit count (negated on overflow)
+    if (mode == 2) {
+        n = n_lists * (cap - 1);               // cap = k + 1 rows per gathered list, the last one = totals
+    } else {
+        const int32_t total = lists_n ? lists_n[(size_t)q * ns] : cap;
+        n = total > cap ? cap : (total < 0 ? 0 : total);
+        total_row = total > cap ? -total : total;
+    }
+    if (n > kWsMax) {                          // the block kernel's (the host passes flags whenever this can happen)
+        if (lane == 0) flags[q] = 1;
+        return;
+    }
+    if (n <= 64 * 4)
+        wave_topk_body<4>(h, lane, q, n, total_row, lists, n_lists, Q, cap, k, topk, mode, totals, flags);
+    else if (n <= 64 * 8)
+        wave_topk_body<8>(h, lane, q, n, total_row, lists, n_lists, Q, cap, k, topk, mode, totals, flags);
+    else
+        wave_topk_body<kWsE>(h, lane, q, n, total_row, lists, n_lists, Q, cap, k, topk, mode, totals, flags);
 }
 
 // ---- small helpers launched around the sweeps ------------------------------------------------
