@@ -184,9 +184,14 @@ __global__ void ts_row_write3_kernel(Row *dst, Row *delta_dst, int32_t *ivid_dea
 #ifndef TVZ_IX_CACHE
 #define TVZ_IX_CACHE 4096
 #endif
+#ifndef TVZ_IX_BLOCK
+#define TVZ_IX_BLOCK 512
+#endif
 constexpr int kIxWords = kSubRows / 32;              // words per bitmap
-constexpr int kIxBlock = kIxWords;                   // one bitmap word per thread
+constexpr int kIxBlock = TVZ_IX_BLOCK;
+constexpr int kIxWpt = kIxWords / kIxBlock;          // bitmap words per thread (rank, emit)
 constexpr int kIxWaves = kIxBlock / 64;
+static_assert(kIxWpt >= 1 && kIxWpt * kIxBlock == kIxWords, "whole bitmap words per thread");
 constexpr int kIxSlotBits = TVZ_IX_SLOT_BITS;
 constexpr int kIxSlots = 1 << kIxSlotBits;           // candidate slots per part (12 B each)
 constexpr int kIxCache = TVZ_IX_CACHE;               // (row, position) of postings kept in LDS between the passes
@@ -333,9 +338,11 @@ __global__ __launch_bounds__(kIxBlock) void ts_match_index_kernel(
     }
     __syncthreads();
     const uint32_t *cand = min_match >= 2 ? bm2 : bm1;
-    // ---- rank: candidates before every bitmap word (512 words, one per thread) ----
+    // ---- rank: candidates before every bitmap word (thread t owns words t*kIxWpt .. +kIxWpt-1) ----
     {
-        const uint32_t c = __popc(cand[threadIdx.x]);
+        uint32_t c = 0;
+#pragma unroll
+        for (int w = 0; w < kIxWpt; ++w) c += __popc(cand[threadIdx.x * kIxWpt + w]);
         uint32_t incl = c;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
@@ -346,11 +353,15 @@ __global__ __launch_bounds__(kIxBlock) void ts_match_index_kernel(
         __syncthreads();
         uint32_t base = 0;
         for (int w = 0; w < wave; ++w) base += s_wsum[w];
-        rank[threadIdx.x] = base + incl - c;
+        uint32_t run = base + incl - c;
+#pragma unroll
+        for (int w = 0; w < kIxWpt; ++w) {
+            rank[threadIdx.x * kIxWpt + w] = run;
+            run += __popc(cand[threadIdx.x * kIxWpt + w]);
+        }
         if (threadIdx.x == kIxBlock - 1) s_base = base + incl;         // candidates in all
         __syncthreads();
     }
-    static_assert(kIxWords == kIxBlock, "one bitmap word per thread");
     static_assert(kIxSlots % kIxBlock == 0, "whole rounds of the block over the emit list");
     const uint32_t n_cand = s_base;
     const int32_t excl = exclude_ids ? exclude_ids[q] : exclude_one;
@@ -394,14 +405,16 @@ __global__ __launch_bounds__(kIxBlock) void ts_match_index_kernel(
         // emit, stage 1: thread <-> bitmap word; candidates of this part that reached min_match go to
         // an LDS list (row in the sub-index << kIxSlotBits | slot).  Looking their video ids up right here,
         // bit after bit, was one dependent global load per bit and 60 % of the kernel.
-        {
-            const uint32_t w = cand[threadIdx.x];
-            const uint32_t rk = rank[threadIdx.x];
+#pragma unroll
+        for (int ww = 0; ww < kIxWpt; ++ww) {
+            const uint32_t wi = threadIdx.x * kIxWpt + ww;
+            const uint32_t w = cand[wi];
+            const uint32_t rk = rank[wi];
             for (uint32_t rest = w, i = 0; rest; rest &= rest - 1, ++i) {
                 const uint32_t idx = rk + i - lo;
                 if (idx >= (uint32_t)kIxSlots || (int32_t)tcnt[idx] < min_match) continue;
                 const uint32_t bit = (uint32_t)__ffs(rest) - 1u;
-                elist[atomicAdd(&s_nlist, 1u)] = ((threadIdx.x * 32u + bit) << kIxSlotBits) | idx;
+                elist[atomicAdd(&s_nlist, 1u)] = ((wi * 32u + bit) << kIxSlotBits) | idx;
             }
         }
         __syncthreads();
