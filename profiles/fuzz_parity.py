@@ -19,7 +19,7 @@ lib = _lib.load()
 dev = torch.device("cuda:0")
 dc = tc.DeviceCorpus(0)
 special = np.array([0.0, -0.0, np.nan, np.inf, -np.inf, 5e-324, 1e300, 1.5, 0.1 + 0.2, 0.3])
-stats = {"match_cases": 0, "pairs": 0, "upserts": 0, "scene_cases": 0, "frames": 0}
+stats = {"match_cases": 0, "pairs": 0, "upserts": 0, "topk_cases": 0, "scene_cases": 0, "frames": 0}
 t_end = time.time() + SECONDS
 t_note = time.time() + 30
 
@@ -86,6 +86,35 @@ while time.time() < t_end:
         if not ok:
             print("MATCH MISMATCH", dict(C=C, Q=Q, mm=mm, cap=cap, mode=mode, qi=qi, n=int(n[qi]), exp=len(exp)))
             sys.exit(1)
+    # ---- top-k of the hit lists (one-wave kernel, flagged block fallback) + merge of per-shard blocks
+    if mm >= 1 or rng.random() < 0.3:
+        k = int(rng.choice([1, 8, 16, 64, 100]))
+        capk = int(rng.choice([max(C, 1), 40, 2000]))
+        ws = torch.empty(tc.workspace_bytes(Q, ml, capk, k), dtype=torch.uint8, device=dev)
+        blk = dc.match_topk(d_q, d_off, ml, mm, capk, k, d_exclude_ids=d_ex, workspace=ws, algo=mode)
+        merged, totals = tc.topk_merge(torch.stack([blk, blk]).contiguous(), k)      # two identical "ranks"
+        torch.cuda.synchronize()
+        blk, merged, totals = blk.cpu().numpy(), merged.cpu().numpy(), totals.cpu().numpy()
+        for qi, q in enumerate(queries):
+            cnt, kth = oracle.match_kth_csr(np.asarray(q, dtype=np.float64), offs, keys, mm)
+            exp = [(int(ids[c]), int(cnt[c]), int(kth[c])) for c in range(C)
+                   if cnt[c] >= mm and (excl is None or ids[c] != excl[qi])]
+            tot = int(blk[qi, k, 1])
+            ok = tuple(blk[qi, k][[0, 2]]) == (-1, tc.KTH_NEVER)
+            if len(exp) <= capk:
+                srt = sorted(exp, key=lambda h: (h[2], h[0], h[1]))
+                want = srt[:k] + [(-1, 0, tc.KTH_NEVER)] * (k - min(k, len(srt)))
+                ok = ok and tot == len(exp) and [tuple(int(x) for x in r) for r in blk[qi, :k]] == want
+                dbl = sorted(exp + exp, key=lambda h: (h[2], h[0], h[1]))[:k]
+                dbl += [(-1, 0, tc.KTH_NEVER)] * (k - len(dbl))
+                ok = ok and [tuple(int(x) for x in r) for r in merged[qi]] == dbl and int(totals[qi]) == 2 * len(exp)
+            else:                                   # truncated list: signalled, entries are real hits
+                got = [tuple(int(x) for x in r) for r in blk[qi, :k] if r[0] >= 0]
+                ok = ok and tot == -len(exp) and set(got) <= set(exp) and int(totals[qi]) == -2 * len(exp)
+            if not ok:
+                print("TOPK MISMATCH", dict(C=C, Q=Q, mm=mm, k=k, cap=capk, mode=mode, qi=qi, n=len(exp)))
+                sys.exit(1)
+        stats["topk_cases"] += 1
     qi = int(rng.integers(0, Q))
     longq = rand_keys(int(rng.choice([10, 4500])), grid)
     for q in (queries[qi], longq):
