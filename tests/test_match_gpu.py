@@ -526,7 +526,8 @@ def test_match_topk_one_call_equals_match_then_topk(dc):
     assert len(exp_rows[1]) > 2500 and len({r[2] for r in exp_rows[1]}) == 1
     assert max(len(r) for r in exp_rows) > 1500          # long enough for the histogram path
     for algo in (_lib.ALGO_AUTO, _lib.ALGO_Q1, _lib.ALGO_TILE, _lib.ALGO_JOIN):
-        for k, cap in ((16, C), (1, C), (64, C), (16, 300), (256, C), (700, C)):   # k > 256: the wide select
+        for k, cap in ((16, C), (1, C), (64, C), (16, 300), (256, C), (700, C),   # k > 256: the wide select
+                       (16, 1024), (64, 1025), (16, 256), (8, 512)):         # list lengths at the one-wave kernel's limits
             ws = torch.empty(tc.workspace_bytes(Q, max_len, cap, k), dtype=torch.uint8, device=DEV)
             out = dc.match_topk(d_q, d_off, max_len, mm, cap, k, d_exclude_ids=excl, workspace=ws, algo=algo)
             torch.cuda.synchronize()
