@@ -134,8 +134,14 @@ static int tvz_match_sharded_impl(tvz_corpus *c, tvz_comm *comm, const double *d
     const int32_t *local = tvz_ws_local_block(d_workspace, Q, max_query_len, cap, k, comm->n_ranks);
     hipStream_t st = reinterpret_cast<hipStream_t>(hip_stream);
     const size_t count = (size_t)Q * (size_t)(k + 1) * 3;
-    if (int rc = g_api.AllGather(local, gathered, count, kNcclInt32, comm->comm, st))
-        return nccl_fail("ncclAllGather", rc);
+    // RCCL enqueues on the communicator's device: make it current for the call (a host that drives
+    // several GPUs from one thread may have another one selected)
+    int prev = -1;
+    (void)hipGetDevice(&prev);
+    if (prev != comm->device) TVZ_HIP(hipSetDevice(comm->device));
+    const int grc = g_api.AllGather(local, gathered, count, kNcclInt32, comm->comm, st);
+    if (prev >= 0 && prev != comm->device) (void)hipSetDevice(prev);
+    if (grc) return nccl_fail("ncclAllGather", grc);
     return tvz_topk_merge_ws(gathered, comm->n_ranks, Q, k, d_topk, d_totals, d_workspace, max_query_len, cap,
                              hip_stream);
 }
