@@ -169,7 +169,9 @@ int tvz_corpus_stats(tvz_corpus *c, int64_t *n_rows, int64_t *n_keys, int64_t *a
  * keys, independent of the corpus size) + a sweep of the delta table; results are identical to
  * a full sweep (every row is in exactly one of the two).
  * Built by tvz_corpus_upload, when a corpus grown by upserts reaches 4096 rows, when the delta
- * exceeds max(4096, indexed rows / 8), and by this call.  A build waits for matches in flight.
+ * exceeds max(4096, indexed rows / 8), and by this call.  A build waits for matches in flight;
+ * its buffers are sized with the corpus reservation (tvz_corpus_reserve / upload), so the rebuilds
+ * that upserts trigger allocate only when the corpus has outgrown it.
  * A corpus with >= 2^32 keys (per GPU) gets no index and is swept. */
 int tvz_corpus_build_index(tvz_corpus *c);
 /* indexed rows / rows in the delta table / postings / most distinct keys in one sub-index of 32768

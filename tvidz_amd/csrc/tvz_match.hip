@@ -258,14 +258,17 @@ int build_index(tvz_corpus *c) {
     if (n_rows == 0 || c->live_keys >= (int64_t)0xfffffff0LL) return TVZ_OK;
     hipStream_t st = c->mstream;
     if (!ix.info) TVZ_HIP(hipMalloc(&ix.info, sizeof(IxBuildInfo)));
-    if (int rc = ensure(ix.post, std::max<int64_t>(c->live_keys, 1), 0)) return rc;
+    // sized with the corpus RESERVATION (rows.cap / keys.cap double as the table grows), so the
+    // rebuilds that upserts trigger allocate nothing until the corpus outgrows it
+    if (int rc = ensure(ix.post, std::max<int64_t>(c->keys.cap, 1), 0)) return rc;
     if (int rc = ensure(ix.ivid, c->rows.cap, 0)) return rc;
-    if (int rc = ensure(ix.drows, delta_capacity(n_rows), 0)) return rc;
+    if (int rc = ensure(ix.drows, delta_capacity(c->rows.cap), 0)) return rc;
     // directories (one per sub-index, all the same size): sized for a guess of the distinct keys of a
     // sub-index - a fingerprint corpus repeats its keys many times over - and grown if too crowded
     const int n_sub = (int)tvz::ceil_div(n_rows, kSubRows);
     TVZ_REQUIRE(n_sub <= 65535, "too many rows for the index (%lld)", (long long)n_rows);
-    if (int rc = ensure(ix.sub_distinct, n_sub, 0)) return rc;
+    const int64_t n_sub_cap = std::max<int64_t>(n_sub, tvz::ceil_div(c->rows.cap, kSubRows));
+    if (int rc = ensure(ix.sub_distinct, n_sub_cap, 0)) return rc;
     const int64_t per_sub = tvz::ceil_div(c->live_keys, n_sub);
     int log2 = 10;
     while (((int64_t)1 << log2) < per_sub / 2) ++log2;
@@ -274,7 +277,7 @@ int build_index(tvz_corpus *c) {
     while (true) {
         TVZ_REQUIRE(log2 <= 28, "index directories would exceed 2^28 entries each");
         const int64_t dn = (int64_t)n_sub << log2;
-        if (int rc = ensure(ix.dir, dn, 0)) return rc;
+        if (int rc = ensure(ix.dir, std::max<int64_t>(dn, n_sub_cap << log2), 0)) return rc;
         hipLaunchKernelGGL(ix_clear_kernel, dim3(1024), dim3(kBlock), 0, st, ix.dir.p, (size_t)dn,
                            ix.sub_distinct.p, n_sub, ix.info);
         hipLaunchKernelGGL(ix_count_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, st, c->rows.p, n_rows,
@@ -934,7 +937,7 @@ static int tvz_corpus_upsert_impl(tvz_corpus *c, int32_t video_id, const double 
         auto ds = ix.delta_slot.find(r);
         if (ds != ix.delta_slot.end()) {
             slot = ds->second;
-        } else if (ix.n_delta < ix.drows.cap) {
+        } else if (ix.n_delta < std::min<int64_t>(ix.drows.cap, delta_capacity(ix.n_main))) {
             slot = (int32_t)ix.n_delta++;
             slot_new = true;
             ix.delta_slot.emplace(r, slot);
