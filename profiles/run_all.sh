@@ -12,8 +12,7 @@ echo "== scene kernel trace + FETCH/WRITE"; bash profiles/run_profile.sh $TAG > 
 echo "== matcher trace + counters";       bash profiles/pmc_match.sh $TAG index index1 join q1_100k q1_5k tile shard8 > $OUT/pmc_match.log 2>&1; echo rc=$?
 echo "== predicted scaling";              python profiles/predict_scaling.py 4096 2>/dev/null | tail -1 > $OUT/predicted_scaling.json; python profiles/predict_scaling.py 1024 2>/dev/null | tail -1 >> $OUT/predicted_scaling.json
 echo "== find_duplicates latency (C ABI, no Python)"
-gcc -O2 -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -Iinclude profiles/find_dup_latency.c -o /tmp/fdl -Ltvidz_amd -ltvz \
-    -L/opt/rocm/lib -lamdhip64 -lm -Wl,-rpath,$REPO/tvidz_amd -Wl,-rpath,/opt/rocm/lib && { /tmp/fdl 5000; /tmp/fdl 100000 1000; } > $OUT/find_dup_latency.txt
+bash profiles/fdl.sh > $OUT/find_dup_latency.txt
 echo "== driver, N concurrent uploads (1080p Y4M in RAM -> verdicts)"
 for a in "1 1024 1" "16 256 16" "32 256 16" "64 256 16" "16 512 16" "64 512 16"; do
   python profiles/e2e_service.py $a 256 64 2>/dev/null | tail -1
