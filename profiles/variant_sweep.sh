@@ -5,9 +5,8 @@
 W=$1; shift
 REPO=$(pwd)
 export TMPDIR=/tmp
-cp tvidz_amd/libtvz.so /tmp/libtvz_keep.so
 for v in "$@"; do
-  cp variants/libtvz_$v.so tvidz_amd/libtvz.so
+  export TVZ_LIB=$REPO/variants/libtvz_$v.so     # selected by tvidz_amd/_lib.py; the product library is never touched
   OUT=$REPO/gpurun_out/variant_$v
   mkdir -p $OUT
   echo "== variant $v"
@@ -28,4 +27,3 @@ for n, d in acc.items():
     print("  ", n, {k: round(sum(v) / len(v)) for k, v in d.items()}, "launches", len(next(iter(d.values()))))
 PY
 done
-cp /tmp/libtvz_keep.so tvidz_amd/libtvz.so

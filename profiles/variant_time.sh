@@ -1,10 +1,11 @@
 #!/bin/bash
-# Time one matcher workload with each prebuilt library variant under variants/ (experiments only).
-#   bash profiles/variant_time.sh <workload> <variant>...
-W=$1; shift
-cp tvidz_amd/libtvz.so /tmp/libtvz_keep.so
+# Time matcher workloads with prebuilt library variants under variants/ (experiments only).  The
+# variant is selected with TVZ_LIB (tvidz_amd/_lib.py): the product library is never touched.
+#   bash profiles/variant_time.sh "<workload> ..." <variant>...      (variant "product" = tvidz_amd/libtvz.so)
+WL=$1; shift
 for v in "$@"; do
-  cp variants/libtvz_$v.so tvidz_amd/libtvz.so
-  echo "== variant $v"; python3 profiles/match_workloads.py $W 2>/dev/null | cut -c1-110
+  for w in $WL; do
+    if [ "$v" = product ]; then L=""; else L=$(pwd)/variants/libtvz_$v.so; fi
+    echo -n "$v $w: "; TVZ_LIB=$L python3 profiles/match_workloads.py $w 14 2>/dev/null | tail -1 | cut -c1-120
+  done
 done
-cp /tmp/libtvz_keep.so tvidz_amd/libtvz.so

@@ -11,7 +11,9 @@ import os
 import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "libtvz.so")
+# TVZ_LIB selects another build of the same ABI (profiles/variant_*.sh time -D variants this way
+# instead of copying them over the product library)
+SO_PATH = os.environ.get("TVZ_LIB") or os.path.join(_HERE, "libtvz.so")
 
 KTH_NEVER = 0x7FFFFFFF
 VERSION = 200

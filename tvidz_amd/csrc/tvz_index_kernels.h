@@ -4,50 +4,54 @@
 // query elements are `in` the row.  The sweep kernels answer by reading every row; the index
 // answers from the other side: for every query element, which rows contain it.
 //
-// The indexed rows are cut into SUB-INDEXES of 2^14 rows.  Per sub-index:
-//   dir  : open-addressing directory of the distinct canonical keys of its rows, 16 B per entry
-//          {key, first posting, number of postings}, load <= 0.5 (all directories the same size)
-//   post : posting lists, one uint16 LOCAL row number per (row, key) pair, contiguous per key
-// and over all of them
+// Layout (round 3: ONE directory probe per query element, whatever the corpus size):
+//   dir  : ONE open-addressing directory over the distinct canonical keys of ALL indexed rows.
+//          An entry is a 16-byte head {key, first posting, postings in all} followed by `ks`
+//          uint16 counts - the key's postings in each SUB-INDEX of 2^14 rows (ks = sub-indexes
+//          rounded up to 8; ks = 0 for a corpus of one sub-index: the head's total is the count).
+//          One probe (head + counts share a cache line) tells a query element everything.
+//   post : posting lists, one uint16 LOCAL row number per (row, key) pair; the postings of a key
+//          are contiguous, ordered by sub-index - the pieces a block reads one sub-index after the
+//          other lie next to each other in memory
 //   ivid : video_id per indexed row; -1 once the row was replaced by an upsert (its postings are
 //          then stale and ignored; the row's current content lives in the delta table, which the
 //          sweep kernels read).
 //
-// One block per (query, sub-index).  A query of n elements whose keys have p postings in the
-// sub-index costs n directory probes + p two-byte posting reads, whatever the corpus size
-// (config 4: ~16,500 postings = 33 KB per query over 7 sub-indexes, against 160 MB for a sweep):
+// Lookup: one block per QUERY walks the query's sub-indexes one after the other (a lone query gets
+// one block per sub-index instead: latency).  The query's keys are probed once; per sub-index
 //   pass A  every posting sets its row's bit in `seen1`, or in `seen2` if seen1 was set already:
 //           only rows in seen2 (seen1 for min_match 1) can reach min_match; the bitmaps cover the
 //           sub-index exactly (16,384 bits), so the candidates are known row by row;
 //   rank    prefix popcount of the candidate bitmap: candidate -> dense slot, no hashing;
 //   pass B  the postings are walked again - from the (row, position) pairs pass A left in LDS (the
-//           first 4,096; the lists themselves beyond that); a candidate's count and smallest query
+//           first kIxCache; the lists themselves beyond that); a candidate's count and smallest query
 //           positions (two atomicMin words for min_match <= 2, five 12-bit positions in a CAS word
 //           for 3..5) accumulate in its slot - 1,024 slots at a time if there are more candidates;
 //   emit    candidates with count >= min_match, (video_id, count, kth) exactly as the sweeps emit
-//           them: one reservation per block in the query's hit list (or the block's own region of
-//           pinned host memory for tvz_find_duplicates).
+//           them.  A block that owns its query alone appends to the hit list with NO global atomic
+//           and stores the count once at the end.
 // The walks are laid out so that every wave owns a contiguous range of the flattened postings:
 // consecutive lanes read consecutive postings and a lane's list pointer only moves forward.
 //
-// Build (on the corpus' mutation stream, readers drained): count postings per key with
-// find-or-insert, hand out posting ranges with one atomic per wave, fill.  No sort.
+// Build (tvz_match.hip: into a SHADOW buffer set, readers keep using the old index meanwhile):
+// count postings per (key, sub-index) with find-or-insert, hand out posting ranges with a block
+// scan + one atomic per block, fill.  No sort.
 #pragma once
 #include "tvz_match_kernels.h"
 
 namespace {
 
-struct alignas(16) DirEnt {
+struct alignas(16) DirHead {
     int64_t key;       // kEmpty = free
-    uint32_t off;      // first posting
-    uint32_t len;      // postings
+    uint32_t base;     // first posting of the key
+    uint32_t total;    // postings of the key over all sub-indexes
 };
-static_assert(sizeof(DirEnt) == 16, "DirEnt must be 16 bytes");
+static_assert(sizeof(DirHead) == 16, "DirHead must be 16 bytes");
 
 struct IxBuildInfo {       // device-side build status, read back by the host
     uint32_t cursor;       // postings handed out
-    uint32_t max_distinct; // most directory entries in use in one sub-index
-    uint32_t failed;       // a probe sequence ran too long: directories too small, rebuild larger
+    uint32_t n_distinct;   // directory entries in use
+    uint32_t failed;       // a probe sequence ran too long: directory too small, rebuild larger
     uint32_t pad;
 };
 
@@ -58,38 +62,42 @@ constexpr int kIxMaxProbe = 4096;
 constexpr int kSubLog2 = TVZ_IX_SUB_LOG2;            // rows per sub-index (local row numbers are uint16)
 constexpr int kSubRows = 1 << kSubLog2;
 
+inline int ix_ks(int n_sub) { return n_sub <= 1 ? 0 : (n_sub + 7) & ~7; }   // uint16 counts per entry
+inline int ix_entry_bytes(int ks) { return 16 + 2 * ks; }
+
 __device__ __forceinline__ uint32_t ix_slot(int64_t k, int dir_log2) {
     return (q1_mix(k) * 0x9E3779B1u) >> (32 - dir_log2);
 }
 
-// directories = every key free; per-sub-index distinct counters = 0
-__global__ __launch_bounds__(kBlock) void ix_clear_kernel(DirEnt *__restrict__ dir, size_t n,
-                                                          uint32_t *__restrict__ sub_distinct, int n_sub,
+// every entry = {free, 0, 0, counts 0}; the fill cursors = 0
+__global__ __launch_bounds__(kBlock) void ix_clear_kernel(uint4 *__restrict__ dir16, size_t n16, int es16,
+                                                          uint4 *__restrict__ zero16, size_t nz16,
                                                           IxBuildInfo *info) {
     const size_t i0 = (size_t)blockIdx.x * kBlock + threadIdx.x, step = (size_t)gridDim.x * kBlock;
-    int4 e;
-    e.x = (int32_t)(uint32_t)(uint64_t)kEmpty;
-    e.y = (int32_t)(uint32_t)((uint64_t)kEmpty >> 32);
-    e.z = 0;
-    e.w = 0;
-    for (size_t i = i0; i < n; i += step) reinterpret_cast<int4 *>(dir)[i] = e;
-    for (size_t i = i0; i < (size_t)n_sub; i += step) sub_distinct[i] = 0;
-    if (i0 == 0) { info->cursor = 0; info->max_distinct = 0; info->failed = 0; info->pad = 0; }
+    uint4 head;
+    head.x = (uint32_t)(uint64_t)kEmpty;
+    head.y = (uint32_t)((uint64_t)kEmpty >> 32);
+    head.z = 0;
+    head.w = 0;
+    for (size_t i = i0; i < n16; i += step) dir16[i] = (i % (size_t)es16 == 0) ? head : make_uint4(0, 0, 0, 0);
+    for (size_t i = i0; i < nz16; i += step) zero16[i] = make_uint4(0, 0, 0, 0);
+    if (i0 == 0) { info->cursor = 0; info->n_distinct = 0; info->failed = 0; info->pad = 0; }
 }
 
 // find (or, with INSERT, claim) the directory entry of key k; returns the slot or -1
 template <bool INSERT>
-__device__ __forceinline__ int64_t ix_find(DirEnt *dir, int dir_log2, int64_t k, bool &is_new) {
+__device__ __forceinline__ int64_t ix_find(unsigned char *dir, int es, int dir_log2, int64_t k, bool &is_new) {
     const uint32_t mask = (1u << dir_log2) - 1u;
     uint32_t s = ix_slot(k, dir_log2);
     is_new = false;
     for (int probes = 0; probes < kIxMaxProbe; ++probes) {
+        int64_t *kp = reinterpret_cast<int64_t *>(dir + (size_t)s * es);
         // look first: keys only ever go from free to taken, a stale view is corrected by the CAS
-        const int64_t cur = INSERT ? *reinterpret_cast<volatile int64_t *>(&dir[s].key) : dir[s].key;
+        const int64_t cur = INSERT ? *reinterpret_cast<volatile int64_t *>(kp) : *kp;
         if (cur == k) return s;
         if (cur == kEmpty) {
             if (!INSERT) return -1;
-            const unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long *>(&dir[s].key),
+            const unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long *>(kp),
                                                      (unsigned long long)kEmpty, (unsigned long long)k);
             if (old == (unsigned long long)kEmpty) { is_new = true; return s; }
             if ((int64_t)old == k) return s;
@@ -99,67 +107,102 @@ __device__ __forceinline__ int64_t ix_find(DirEnt *dir, int dir_log2, int64_t k,
     return -1;
 }
 
-// one wave per row: count the postings of every key, remember the row's video id
+// one wave per row: count the postings of every (key, sub-index), remember the row's video id.
+// The uint16 counts are bumped through their 32-bit word (a count never exceeds the 2^14 rows of a
+// sub-index, so the low half cannot carry into the high half).
 __global__ __launch_bounds__(kBlock) void ix_count_kernel(const Row *__restrict__ rows, int64_t n_rows,
-                                                          const int64_t *__restrict__ keys, DirEnt *dir,
-                                                          int dir_log2, int32_t *__restrict__ ivid,
-                                                          uint32_t *__restrict__ sub_distinct,
+                                                          const int64_t *__restrict__ keys, unsigned char *dir,
+                                                          int es, int ks, int dir_log2, int32_t *__restrict__ ivid,
                                                           IxBuildInfo *info) {
     const int lane = threadIdx.x & 63;
     for (int64_t r = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6); r < n_rows;
          r += (int64_t)gridDim.x * (kBlock / 64)) {
         const Row row = load_row(rows + r);
         if (lane == 0) ivid[r] = row.vid;
-        DirEnt *d = dir + ((size_t)(r >> kSubLog2) << dir_log2);
+        const uint32_t sub = (uint32_t)(r >> kSubLog2);
         uint32_t mine = 0;
         for (int i = lane; i < row.len; i += 64) {
             bool is_new;
-            const int64_t s = ix_find<true>(d, dir_log2, keys[row.off + i], is_new);
+            const int64_t s = ix_find<true>(dir, es, dir_log2, keys[row.off + i], is_new);
             if (s < 0) { info->failed = 1; continue; }
-            atomicAdd(&d[s].len, 1u);
+            unsigned char *e = dir + (size_t)s * es;
+            if (ks) atomicAdd(reinterpret_cast<uint32_t *>(e + 16) + (sub >> 1), 1u << ((sub & 1u) * 16u));
+            else atomicAdd(&reinterpret_cast<DirHead *>(e)->total, 1u);
             mine += is_new ? 1u : 0u;
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o);
-        if (lane == 0 && mine) {
-            const uint32_t now = atomicAdd(&sub_distinct[r >> kSubLog2], mine) + mine;
-            atomicMax(&info->max_distinct, now);
-        }
+        if (lane == 0 && mine) atomicAdd(&info->n_distinct, mine);
     }
 }
 
-// hand out posting ranges: off = END of the range (the fill pass counts it down to the start)
-__global__ __launch_bounds__(kBlock) void ix_offsets_kernel(DirEnt *dir, size_t n, IxBuildInfo *info) {
+// hand out posting ranges: a thread per directory entry, block-wide exclusive scan of the entries'
+// totals, ONE atomic per block on the cursor (a wave per atomic was 229,376 waves queueing on one
+// address: 2.6 ms of a 5.2 ms build in round 2)
+__global__ __launch_bounds__(kBlock) void ix_offsets_kernel(unsigned char *dir, size_t n, int es, int ks,
+                                                            IxBuildInfo *info) {
+    __shared__ uint32_t s_w[kBlock / 64];
+    __shared__ uint32_t s_base;
     const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
-    const int lane = threadIdx.x & 63;
-    const uint32_t len = i < n ? dir[i].len : 0u;
-    uint32_t incl = len;                               // inclusive prefix over the wave
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t total = 0;
+    if (i < n) {
+        DirHead *h = reinterpret_cast<DirHead *>(dir + i * es);
+        if (ks) {
+            const uint4 *c = reinterpret_cast<const uint4 *>(dir + i * es + 16);
+            for (int j = 0; j < ks / 8; ++j) {
+                const uint4 v = c[j];
+                total += (v.x & 0xffffu) + (v.x >> 16) + (v.y & 0xffffu) + (v.y >> 16) + (v.z & 0xffffu) +
+                         (v.z >> 16) + (v.w & 0xffffu) + (v.w >> 16);
+            }
+            h->total = total;
+        } else {
+            total = h->total;
+        }
+    }
+    uint32_t incl = total;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
         const uint32_t o = __shfl_up(incl, d);
         if (lane >= d) incl += o;
     }
-    const uint32_t total = __shfl(incl, 63);
-    uint32_t base = 0;
-    if (lane == 0 && total) base = atomicAdd(&info->cursor, total);
-    base = __shfl(base, 0);
-    if (i < n && len) dir[i].off = base + incl;
+    if (lane == 63) s_w[wave] = incl;
+    __syncthreads();
+    uint32_t before = 0, all = 0;
+#pragma unroll
+    for (int w = 0; w < kBlock / 64; ++w) { if (w < wave) before += s_w[w]; all += s_w[w]; }
+    if (threadIdx.x == 0) s_base = all ? atomicAdd(&info->cursor, all) : 0u;
+    __syncthreads();
+    if (i < n && total) reinterpret_cast<DirHead *>(dir + i * es)->base = s_base + before + incl - total;
 }
 
+// one wave per row: every key takes the next free posting of its (key, sub-index) range.
+// fillc: one 32-bit word per two sub-indexes of an entry (ks = 0: one word per entry), zeroed.
 __global__ __launch_bounds__(kBlock) void ix_fill_kernel(const Row *__restrict__ rows, int64_t n_rows,
-                                                         const int64_t *__restrict__ keys, DirEnt *dir,
-                                                         int dir_log2, uint16_t *__restrict__ post) {
+                                                         const int64_t *__restrict__ keys, unsigned char *dir, int es,
+                                                         int ks, int dir_log2, uint32_t *__restrict__ fillc,
+                                                         uint16_t *__restrict__ post) {
     const int lane = threadIdx.x & 63;
+    const int fw = ks ? ks / 2 : 1;                    // fill-cursor words per entry
     for (int64_t r = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6); r < n_rows;
          r += (int64_t)gridDim.x * (kBlock / 64)) {
         const Row row = load_row(rows + r);
-        DirEnt *d = dir + ((size_t)(r >> kSubLog2) << dir_log2);
+        const uint32_t sub = (uint32_t)(r >> kSubLog2);
         for (int i = lane; i < row.len; i += 64) {
             bool is_new;
-            const int64_t s = ix_find<false>(d, dir_log2, keys[row.off + i], is_new);
+            const int64_t s = ix_find<false>(dir, es, dir_log2, keys[row.off + i], is_new);
             if (s < 0) continue;                       // cannot happen after a successful count pass
-            const uint32_t p = atomicSub(&d[s].off, 1u) - 1u;
-            post[p] = (uint16_t)(r & (kSubRows - 1));
+            const unsigned char *e = dir + (size_t)s * es;
+            uint32_t p = reinterpret_cast<const DirHead *>(e)->base;
+            uint32_t k;
+            if (ks) {
+                const uint16_t *cn = reinterpret_cast<const uint16_t *>(e + 16);
+                for (uint32_t t = 0; t < sub; ++t) p += cn[t];
+                k = (atomicAdd(&fillc[(size_t)s * fw + (sub >> 1)], 1u << ((sub & 1u) * 16u)) >> ((sub & 1u) * 16u)) & 0xffffu;
+            } else {
+                k = atomicAdd(&fillc[s], 1u);
+            }
+            post[p + k] = (uint16_t)(r & (kSubRows - 1));
         }
     }
 }
@@ -177,9 +220,17 @@ __global__ void ts_row_write3_kernel(Row *dst, Row *delta_dst, int32_t *ivid_dea
     if (ivid_dead) *ivid_dead = -1;
 }
 
-// ---- lookup: one block per (query, sub-index) -------------------------------------------------
+// after an index swap: the rows that were upserted while the new index was being built are dead in
+// it (their current entries were copied to the new delta table by the host)
+__global__ __launch_bounds__(kBlock) void ix_mark_dead_kernel(int32_t *__restrict__ ivid,
+                                                              const int32_t *__restrict__ rows_dead, int32_t n) {
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i < n) ivid[rows_dead[i]] = -1;
+}
+
+// ---- lookup: one block per query (and group of sub-indexes) ------------------------------------
 #ifndef TVZ_IX_SLOT_BITS
-#define TVZ_IX_SLOT_BITS 10
+#define TVZ_IX_SLOT_BITS 9
 #endif
 #ifndef TVZ_IX_CACHE
 #define TVZ_IX_CACHE 4096
@@ -193,199 +244,337 @@ constexpr int kIxWpt = kIxWords / kIxBlock;          // bitmap words per thread 
 constexpr int kIxWaves = kIxBlock / 64;
 static_assert(kIxWpt >= 1 && kIxWpt * kIxBlock == kIxWords, "whole bitmap words per thread");
 constexpr int kIxSlotBits = TVZ_IX_SLOT_BITS;
-constexpr int kIxSlots = 1 << kIxSlotBits;           // candidate slots per part (12 B each)
+constexpr int kIxSlots = 1 << kIxSlotBits;           // candidate slots per part (16 B each)
 constexpr int kIxCache = TVZ_IX_CACHE;               // (row, position) of postings kept in LDS between the passes
-static_assert(kSubLog2 <= 16 && kSubLog2 + 12 <= 32 && kSubLog2 + kIxSlotBits <= 32, "packed LDS entries");
+constexpr int kIxLWords = kIxCache / 32;             // list-start bitmap over the cached postings
+constexpr int kIxLPerLane = kIxLWords / 64;
+template <int N> struct IxN { static constexpr int value = N; };   // compile-time trip lengths
+static_assert(kIxLPerLane >= 1 && kIxLPerLane * 64 == kIxLWords, "list-start words split over one wave");
+static_assert(kSubLog2 <= 16 && kSubLog2 + 12 <= 32, "packed LDS entries");
 
-// dynamic LDS: [bm1][bm2][rank][tcnt][ttop][elist][cache][s_off[L]][s_pre[L + 1]][s_pos[L]] - 76 KiB + 10 L:
-// two 16-wave blocks (32 waves) per CU for queries of up to ~400 timestamps
-inline size_t ix_lds_bytes(int max_len) {
-    return (size_t)3 * kIxWords * 4 + (size_t)kIxSlots * 16 + (size_t)kIxCache * 4 +
-           (size_t)(2 * max_len + 2) * 4 + (size_t)(max_len + 2) * 2;
+// dynamic LDS: [bm1][bm2][tcnt][ttop][elist][cache][lst u64 x L][lbits][e_cur][s_pre (+2)][rank u16]
+// [e_len u16 x L x nsb] (nsb = sub-indexes this block walks, rounded up to even): 29.5 KiB + 32 B per
+// query position at 7..8 sub-indexes - FOUR blocks (32 waves) per CU for queries of up to ~330
+// timestamps.
+inline int ix_nsb_padded(int spb) { return (spb + 1) & ~1; }
+inline size_t ix_lds_bytes(int max_len, int spb) {
+    const size_t L = (size_t)(max_len > 0 ? max_len : 1);
+    return (size_t)2 * kIxWords * 4 + (size_t)kIxSlots * 16 + (size_t)kIxCache * 4 + L * 8 + (size_t)kIxLWords * 4 +
+           (2 * L + 2) * 4 + (size_t)kIxWords * 2 + L * 2 * (size_t)ix_nsb_padded(spb) + 16;
 }
 
 // TOP5 = false (min_match 1..2): a slot keeps the two smallest positions in two atomicMin words -
 // two plain LDS atomics per candidate posting instead of the 5 x 12-bit CAS loop (min_match 3..5).
+// grid = (Q, groups): block (q, g) walks sub-indexes [g * spb, min(n_sub, (g + 1) * spb)).
+//   HOSTOUT (tvz_find_duplicates): hits = pinned host memory [n_sub][kSubRows][3], hits_n[sub] = the
+//            sub-index's hit count (every sub-index has its own region: no atomics, any grouping).
+//   else   : hits = [Q][cap][3].  groups == 1: the block owns the query's list - it appends without
+//            atomics and STORES hits_n[q] at the end (the caller need not zero it).  groups > 1: the
+//            blocks of a query share the list through atomicAdd on hits_n[q] (zeroed by the caller).
+// A sub-index costs seven block barriers (one chunk of query positions, one part of candidates);
+// every LDS array is reset by the threads that used it last, inside the phases - no clearing pass.
 template <bool HOSTOUT, bool TOP5>
-__global__ __launch_bounds__(kIxBlock) void ts_match_index_kernel(
-    const DirEnt *__restrict__ dir_all, int dir_log2, const uint16_t *__restrict__ post,
-    const int32_t *__restrict__ ivid, int64_t n_indexed, const double *__restrict__ queries,
-    const int64_t *__restrict__ q_offsets, int32_t max_len, int32_t min_match,
-    const int32_t *__restrict__ exclude_ids, int32_t exclude_one, int32_t cap,
+__global__ __launch_bounds__(kIxBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) void ts_match_index_kernel(
+    const unsigned char *__restrict__ dir, int dir_log2, int ks, const uint16_t *__restrict__ post,
+    const int32_t *__restrict__ ivid, int64_t n_indexed, int32_t n_sub, int32_t spb,
+    const double *__restrict__ queries, const int64_t *__restrict__ q_offsets, int32_t max_len,
+    int32_t min_match, const int32_t *__restrict__ exclude_ids, int32_t exclude_one, int32_t cap,
     int32_t *__restrict__ hits, int32_t *__restrict__ hits_n, int32_t ns, const QByVal qv) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t *bm1 = reinterpret_cast<uint32_t *>(smem);
     uint32_t *bm2 = bm1 + kIxWords;
-    uint32_t *rank = bm2 + kIxWords;                                    // candidates before word j
-    uint32_t *tcnt = rank + kIxWords;
+    uint32_t *tcnt = bm2 + kIxWords;
     unsigned long long *ttop = reinterpret_cast<unsigned long long *>(tcnt + kIxSlots);
     uint32_t *m1 = reinterpret_cast<uint32_t *>(ttop), *m2 = m1 + kIxSlots;   // !TOP5: the same 8 B per slot
-    uint32_t *elist = reinterpret_cast<uint32_t *>(ttop + kIxSlots);    // emit list of one part
+    uint32_t *elist = reinterpret_cast<uint32_t *>(ttop + kIxSlots);    // row (in the sub-index) of slot k
     uint32_t *pcache = elist + kIxSlots;                                // first kIxCache postings: row | position << kSubLog2
-    uint32_t *s_off = reinterpret_cast<uint32_t *>(pcache + kIxCache);  // first posting of list j
-    uint32_t *s_pre = s_off + max_len;                                  // [m + 1] postings before list j
-    uint16_t *s_pos = reinterpret_cast<uint16_t *>(s_pre + max_len + 1);  // query position of list j
-    __shared__ uint32_t s_wsum[kIxWaves], s_lsum[kIxWaves];
-    __shared__ uint32_t s_base, s_m, s_total, s_nlist;
-    __shared__ int32_t s_emitted;
+    const int L = max_len > 0 ? max_len : 1;
+    uint2 *lst = reinterpret_cast<uint2 *>(pcache + kIxCache);          // [L] list j: {first posting - postings before it, position}
+    uint32_t *lbits = reinterpret_cast<uint32_t *>(lst + L);            // bit t: a posting list starts at flat posting t
+    uint32_t *e_cur = lbits + kIxLWords;                                // [L] first posting of position i in the CURRENT sub-index
+    uint32_t *s_pre = e_cur + L;                                        // [L + 1] postings before list j
+    uint16_t *rank = reinterpret_cast<uint16_t *>(s_pre + L + 2);       // candidates before bitmap word j
+    uint16_t *e_len = rank + kIxWords;                                  // [L][nsb] postings of position i per sub-index
+    __shared__ uint32_t s_wa[kIxWaves], s_la[kIxWaves], s_wb[kIxWaves], s_wc[kIxWaves];
+    __shared__ uint32_t s_bcast;
 
     const int q = blockIdx.x;
-    const int sub = blockIdx.y;
+    const int sub_lo = blockIdx.y * spb;
+    const int sub_hi = sub_lo + spb < n_sub ? sub_lo + spb : n_sub;
+    const int nsb = (spb + 1) & ~1;
+    const bool alone = gridDim.y == 1;                 // this block owns the query's hit list
     const bool byval = q_offsets == nullptr;
     const int64_t qo = byval ? 0 : q_offsets[q];
     const int64_t n64 = byval ? qv.n : q_offsets[q + 1] - qo;
-    // HOSTOUT: the block's own hit region [sub][kSubRows][3] and count in pinned host memory
-    int32_t *out_n = HOSTOUT ? hits_n + sub : hits_n + (size_t)q * ns;
-    int32_t *out_hits = HOSTOUT ? hits + (int64_t)sub * kSubRows * 3 : hits + (int64_t)q * cap * 3;
     if (n64 > max_len) {       // max_query_len was not an upper bound (the LDS arrays are sized from it)
-        if (threadIdx.x == 0) *out_n = INT32_MIN;
+        if (HOSTOUT) { for (int s = sub_lo + threadIdx.x; s < sub_hi; s += kIxBlock) hits_n[s] = INT32_MIN; }
+        else if (threadIdx.x == 0) hits_n[(size_t)q * ns] = INT32_MIN;
         return;
     }
     const int n = (int)n64;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (threadIdx.x == 0) { s_m = 0; s_total = 0; s_emitted = 0; s_nlist = 0; }
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // in an SGPR: scalar loop bounds
+    auto reset_slot = [&](uint32_t k) {
+        tcnt[k] = 0;
+        if (TOP5) ttop[k] = kTopNone; else { m1[k] = 0xffffffffu; m2[k] = 0xffffffffu; }
+    };
     for (int i = threadIdx.x; i < kIxWords; i += kIxBlock) { bm1[i] = 0; bm2[i] = 0; }
-    for (int i = threadIdx.x; i < kIxSlots; i += kIxBlock) {
-        tcnt[i] = 0;
-        if (TOP5) ttop[i] = kTopNone; else { m1[i] = 0xffffffffu; m2[i] = 0xffffffffu; }
-    }
-    __syncthreads();
+    for (int i = threadIdx.x; i < kIxLWords; i += kIxBlock) lbits[i] = 0;
+    for (int i = threadIdx.x; i < kIxSlots; i += kIxBlock) reset_slot((uint32_t)i);
 
-    // ---- directory: the NON-EMPTY posting lists of the query's positions, compacted ----
-    const DirEnt *dir = dir_all + ((size_t)sub << dir_log2);
+    // ---- directory: ONE probe per query position; the counts of this block's sub-indexes to LDS ----
     const uint32_t dmask = (1u << dir_log2) - 1u;
-    for (int i0 = 0; i0 < n; i0 += kIxBlock) {
-        const int i = i0 + threadIdx.x;
-        uint32_t off = 0, len = 0;
+    const int es = 16 + 2 * ks;
+    for (int i = threadIdx.x; i < n; i += kIxBlock) {
+        uint32_t base = 0, total = 0;
+        const unsigned char *ent = nullptr;
         int64_t k;
-        if (i < n && canon_key(byval ? qv.k[i] : queries[qo + i], k)) {   // NaN never matches
+        if (canon_key(byval ? qv.k[i] : queries[qo + i], k)) {           // NaN never matches
             uint32_t s = ix_slot(k, dir_log2);
             for (int probes = 0; probes < kIxMaxProbe; ++probes) {
-                const int4 e = *reinterpret_cast<const int4 *>(dir + s);
-                const int64_t ek = (int64_t)(((uint64_t)(uint32_t)e.y << 32) | (uint32_t)e.x);
-                if (ek == k) { off = (uint32_t)e.z; len = (uint32_t)e.w; break; }
+                const unsigned char *e = dir + (size_t)s * es;
+                const int4 h = *reinterpret_cast<const int4 *>(e);
+                const int64_t ek = (int64_t)(((uint64_t)(uint32_t)h.y << 32) | (uint32_t)h.x);
+                if (ek == k) { base = (uint32_t)h.z; total = (uint32_t)h.w; ent = e; break; }
                 if (ek == kEmpty) break;
                 s = (s + 1) & dmask;
             }
         }
-        // block-wide exclusive prefixes of (len, len != 0), continued from the previous chunk
-        uint32_t incl = len, lincl = len ? 1u : 0u;
+        uint16_t *el = e_len + (size_t)i * nsb;
+        if (ks == 0) {                                                   // one sub-index: the total is its count
+            el[0] = (uint16_t)total;
+            el[1] = 0;
+        } else {
+            for (int t = 0; t < nsb; ++t) el[t] = 0;
+            if (ent) {
+                const uint16_t *cn = reinterpret_cast<const uint16_t *>(ent + 16);
+                for (int c = 0; c * 8 < sub_hi; ++c) {                   // 16-byte pieces of the counts
+                    const uint4 v = *reinterpret_cast<const uint4 *>(cn + c * 8);
+                    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t o = __shfl_up(incl, d), lo = __shfl_up(lincl, d);
-            if (lane >= d) { incl += o; lincl += lo; }
-        }
-        if (lane == 63) { s_wsum[wave] = incl; s_lsum[wave] = lincl; }
-        __syncthreads();
-        uint32_t pbase = s_total, lbase = s_m;
-        for (int w = 0; w < wave; ++w) { pbase += s_wsum[w]; lbase += s_lsum[w]; }
-        if (len) {
-            const uint32_t j = lbase + lincl - 1u;
-            s_off[j] = off;
-            s_pre[j] = pbase + incl - len;
-            s_pos[j] = (uint16_t)i;
-        }
-        __syncthreads();
-        if (threadIdx.x == kIxBlock - 1) { s_total = pbase + incl; s_m = lbase + lincl; }
-        __syncthreads();
-    }
-    const int m = (int)s_m;
-    const uint32_t total = s_total;                    // <= 4095 lists x 32768 rows: fits 32 bits
-    if (threadIdx.x == 0) s_pre[m] = total;
-    __syncthreads();
-
-    // every wave owns a contiguous range of the flattened postings; a lane's list pointer only
-    // moves forward (by a bounded binary search when it has to skip short lists)
-    const uint32_t w_lo = (uint32_t)(((unsigned long long)total * wave) / kIxWaves);
-    const uint32_t w_hi = (uint32_t)(((unsigned long long)total * (wave + 1)) / kIxWaves);
-    auto seek = [&](int j, uint32_t t) -> int {        // largest j' >= j with s_pre[j'] <= t
-        if (s_pre[j + 1] > t) return j;
-        int lo = j + 1, hi = m;                        // s_pre[lo] <= t < s_pre[hi] = total
-        if (hi - lo > 64 && s_pre[lo + 64] > t) hi = lo + 64;
-        while (hi - lo > 1) {
-            const int mid = (lo + hi) >> 1;
-            if (s_pre[mid] <= t) lo = mid; else hi = mid;
-        }
-        return lo;
-    };
-    // ---- pass A: which rows are touched (twice); eight posting loads in flight per lane ----
-    {
-        int j = 0;
-        for (uint32_t t0 = w_lo; t0 < w_hi; t0 += 512u) {   // 8 x 64 postings
-            uint32_t r[8];
-            uint16_t pj[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                // unconditional (clamped) loads: a branch around a load makes the compiler wait for
-                // every load before it
-                const uint32_t t = t0 + (uint32_t)(u * 64 + lane);
-                const uint32_t tc = t < w_hi ? t : w_hi - 1u;
-                j = seek(j, tc);
-                const uint32_t v = post[s_off[j] + (tc - s_pre[j])];
-                r[u] = t < w_hi ? v : 0xffffffffu;
-                pj[u] = s_pos[j];
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                if (r[u] == 0xffffffffu) continue;
-                const uint32_t t = t0 + (uint32_t)(u * 64 + lane);
-                if (t < (uint32_t)kIxCache) pcache[t] = r[u] | ((uint32_t)pj[u] << kSubLog2);
-                const uint32_t bit = 1u << (r[u] & 31u);
-                const uint32_t old = atomicOr(&bm1[r[u] >> 5], bit);
-                if (min_match >= 2 && (old & bit)) atomicOr(&bm2[r[u] >> 5], bit);
-            }
-        }
-    }
-    __syncthreads();
-    const uint32_t *cand = min_match >= 2 ? bm2 : bm1;
-    // ---- rank: candidates before every bitmap word (thread t owns words t*kIxWpt .. +kIxWpt-1) ----
-    {
-        uint32_t c = 0;
-#pragma unroll
-        for (int w = 0; w < kIxWpt; ++w) c += __popc(cand[threadIdx.x * kIxWpt + w]);
-        uint32_t incl = c;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t o = __shfl_up(incl, d);
-            if (lane >= d) incl += o;
-        }
-        if (lane == 63) s_wsum[wave] = incl;
-        __syncthreads();
-        uint32_t base = 0;
-        for (int w = 0; w < wave; ++w) base += s_wsum[w];
-        uint32_t run = base + incl - c;
-#pragma unroll
-        for (int w = 0; w < kIxWpt; ++w) {
-            rank[threadIdx.x * kIxWpt + w] = run;
-            run += __popc(cand[threadIdx.x * kIxWpt + w]);
-        }
-        if (threadIdx.x == kIxBlock - 1) s_base = base + incl;         // candidates in all
-        __syncthreads();
-    }
-    static_assert(kIxSlots % kIxBlock == 0, "whole rounds of the block over the emit list");
-    const uint32_t n_cand = s_base;
-    const int32_t excl = exclude_ids ? exclude_ids[q] : exclude_one;
-    const int64_t row0 = (int64_t)sub << kSubLog2;
-
-    // ---- pass B + emit, kIxSlots candidates at a time ----
-    for (uint32_t lo = 0; lo < n_cand; lo += kIxSlots) {
-        {
-            int j = 0;
-            for (uint32_t t = w_lo + lane; t < w_hi; t += 64u) {
-                uint32_t r, pos;
-                if (t < (uint32_t)kIxCache) {
-                    const uint32_t e = pcache[t];
-                    r = e & (uint32_t)(kSubRows - 1);
-                    pos = e >> kSubLog2;
-                } else {                                                  // beyond the LDS copy: read it again
-                    j = seek(j, t);
-                    r = post[s_off[j] + (t - s_pre[j])];
-                    pos = s_pos[j];
+                    for (int h = 0; h < 8; ++h) {
+                        const int t = c * 8 + h;
+                        const uint32_t len = (w[h >> 1] >> ((h & 1) * 16)) & 0xffffu;
+                        if (t < sub_lo) base += len;
+                        else if (t < sub_hi) el[t - sub_lo] = (uint16_t)len;
+                    }
                 }
-                const uint32_t w = cand[r >> 5], bit = r & 31u;
-                if (!((w >> bit) & 1u)) continue;
-                const uint32_t idx = rank[r >> 5] + __popc(w & ((1u << bit) - 1u)) - lo;
-                if (idx >= (uint32_t)kIxSlots) continue;                 // another part's (wraps below lo)
+            }
+        }
+        e_cur[i] = base;
+    }
+    __syncthreads();
+#if defined(TVZ_IX_STOP) && TVZ_IX_STOP == 1
+    return;
+#endif
+
+    const int32_t excl = exclude_ids ? exclude_ids[q] : exclude_one;
+    uint32_t emitted = 0;                                  // hits so far (identical in every thread)
+    for (int sub = sub_lo; sub < sub_hi; ++sub) {
+        if (HOSTOUT) emitted = 0;                          // every sub-index has its own region and count
+        // ---- the NON-EMPTY posting lists of this sub-index, compacted (block-wide prefix sums) ----
+        uint32_t run_p = 0, run_l = 0;                     // postings / lists of the chunks so far
+        for (int i0 = 0; i0 < n; i0 += kIxBlock) {
+            const int i = i0 + threadIdx.x;
+            uint32_t off = 0, len = 0;
+            if (i < n) {
+                len = e_len[(size_t)i * nsb + (sub - sub_lo)];
+                off = e_cur[i];
+                e_cur[i] = off + len;                                    // the key's next piece follows
+            }
+            const uint32_t incl = wave_scan_incl(len), lincl = wave_scan_incl(len ? 1u : 0u);
+            if (lane == 63) { s_wa[wave] = incl; s_la[wave] = lincl; }
+            __syncthreads();
+            uint32_t pbase = run_p, lbase = run_l;
+#pragma unroll
+            for (int w = 0; w < kIxWaves; ++w) {
+                const uint32_t a = s_wa[w], b = s_la[w];
+                if (w < wave) { pbase += a; lbase += b; }
+                run_p += a;
+                run_l += b;
+            }
+            if (len) {
+                const uint32_t j = lbase + lincl - 1u, p = pbase + incl - len;
+                s_pre[j] = p;
+                lst[j] = make_uint2(off - p, (uint32_t)i);               // posting t of the sub-index = post[.x + t]
+                // where the list starts in the flattened postings (pass A counts the starts)
+                if (p < (uint32_t)kIxCache) atomicOr(&lbits[p >> 5], 1u << (p & 31u));
+            }
+            if (i0 + kIxBlock < n) __syncthreads();                      // the next chunk rewrites s_wa / s_la
+        }
+        const int m = __builtin_amdgcn_readfirstlane((int)run_l);
+        const uint32_t total = (uint32_t)__builtin_amdgcn_readfirstlane((int)run_p);   // <= 4095 lists x 16384 rows: fits 32 bits
+        // HOSTOUT: the sub-index's own hit region [sub][kSubRows][3] and count in pinned host memory
+        int32_t *out_n = HOSTOUT ? hits_n + sub : hits_n + (size_t)q * ns;
+        int32_t *out_hits = HOSTOUT ? hits + (int64_t)sub * kSubRows * 3 : hits + (int64_t)q * cap * 3;
+        if (total == 0) {                                  // nothing of this query in this sub-index (block-uniform)
+            if (HOSTOUT && threadIdx.x == 0) *out_n = 0;
+            __syncthreads();                               // s_wa / s_la are rewritten by the next sub-index
+            continue;
+        }
+        if (threadIdx.x == 0) s_pre[m] = total;
+        __syncthreads();
+#if defined(TVZ_IX_STOP) && TVZ_IX_STOP == 2
+        continue;
+#endif
+
+        // every wave owns a contiguous range of the flattened postings, starting at a multiple of 64
+        const uint32_t w_lo = wave == 0 ? 0u : (uint32_t)(((unsigned long long)total * wave) / kIxWaves) & ~63u;
+        const uint32_t w_hi = wave == kIxWaves - 1 ? total
+                                                   : (uint32_t)(((unsigned long long)total * (wave + 1)) / kIxWaves) & ~63u;
+        const uint32_t c_hi = w_hi < (uint32_t)kIxCache ? w_hi : (uint32_t)kIxCache;   // cached part ends here
+        // beyond the cached range (a query with > kIxCache postings in this sub-index): a lane's list
+        // pointer only moves forward, by a bounded binary search when it has to skip short lists
+        auto seek = [&](int j, uint32_t t) -> int {        // largest j' >= j with s_pre[j'] <= t
+            if (s_pre[j + 1] > t) return j;
+            int lo = j + 1, hi = m;                        // s_pre[lo] <= t < s_pre[hi] = total
+            if (hi - lo > 64 && s_pre[lo + 64] > t) hi = lo + 64;
+            while (hi - lo > 1) {
+                const int mid = (lo + hi) >> 1;
+                if (s_pre[mid] <= t) lo = mid; else hi = mid;
+            }
+            return lo;
+        };
+        auto touch = [&](uint32_t r) {                     // pass A's bookkeeping for one posting of row r
+            const uint32_t bit = 1u << (r & 31u);
+            const uint32_t old = atomicOr(&bm1[r >> 5], bit);
+            if (min_match >= 2 && (old & bit)) atomicOr(&bm2[r >> 5], bit);
+        };
+        // ---- pass A: which rows are touched (twice); eight posting loads in flight per lane ----
+        if (w_lo < c_hi) {
+            // the list of posting t = (list starts at or before t) - 1.  A step is 64 consecutive postings
+            // = two words of the start bitmap, read by the whole wave (one broadcast read); the starts
+            // before the step are carried in a scalar: no search, no per-posting table lookup
+            uint32_t before = 0;
+#pragma unroll
+            for (int w = 0; w < kIxLPerLane; ++w) {
+                const int wi = lane * kIxLPerLane + w;
+                before += wi < (int)(w_lo >> 5) ? __popc(lbits[wi]) : 0;
+            }
+            before = wave_total(wave_scan_incl(before));
+            // a trip = N steps with all N posting loads in flight; N is the exact number of steps left
+            // (up to 8): a wave has ~5 steps per sub-index, and eight-step trips with masked-off steps
+            // were 40 % of this loop's instructions
+            auto trip = [&](auto nc, const uint32_t t0) {
+                constexpr int N = decltype(nc)::value;
+                uint32_t r[N], ps[(N + 1) / 2];             // positions: two 16-bit halves per register
+#pragma unroll
+                for (int u = 0; u < N; ++u) {
+                    // unconditional (clamped) loads: a branch around a load makes the compiler wait for
+                    // every load before it
+                    const uint32_t tb = t0 + (uint32_t)(u * 64);
+                    const uint32_t wi = tb < c_hi ? tb >> 5 : 0u;
+                    const unsigned long long M = tb < c_hi ? ((unsigned long long)lbits[wi + 1] << 32) | lbits[wi] : 0ull;
+                    const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(M >> 32),
+                                           __builtin_amdgcn_mbcnt_lo((uint32_t)M, 0u));      // starts before this lane
+                    const uint32_t here = (uint32_t)((M >> lane) & 1ull);
+                    int j = (int)(before + below + here) - 1;
+                    before += (uint32_t)__popcll(M);
+                    const uint32_t t = tb + (uint32_t)lane;
+                    const bool valid = t < c_hi;
+                    j = valid ? j : 0;
+                    const uint2 e = lst[j];
+                    const uint32_t v = post[valid ? e.x + t : e.x + s_pre[j]];
+                    r[u] = valid ? v : 0xffffffffu;
+                    ps[u >> 1] = (u & 1) ? ps[u >> 1] | (e.y << 16) : e.y;
+                }
+#pragma unroll
+                for (int u = 0; u < N; ++u) {
+                    if (r[u] == 0xffffffffu) continue;
+                    pcache[t0 + (uint32_t)(u * 64 + lane)] = r[u] | (((ps[u >> 1] >> ((u & 1) * 16)) & 0xffffu) << kSubLog2);
+                    touch(r[u]);
+                }
+            };
+            for (uint32_t t0 = w_lo; t0 < c_hi; t0 += 512u) {
+                const uint32_t steps = (c_hi - t0 + 63u) >> 6;                // wave-uniform (scalar)
+                switch (steps >= 8u ? 8u : steps) {
+                    case 1: trip(IxN<1>{}, t0); break;
+                    case 2: trip(IxN<2>{}, t0); break;
+                    case 3: trip(IxN<3>{}, t0); break;
+                    case 4: trip(IxN<4>{}, t0); break;
+                    case 5: trip(IxN<5>{}, t0); break;
+                    case 6: trip(IxN<6>{}, t0); break;
+                    case 7: trip(IxN<7>{}, t0); break;
+                    default: trip(IxN<8>{}, t0); break;
+                }
+            }
+        }
+        if (w_hi > (uint32_t)kIxCache) {
+            int js = 0;
+            for (uint32_t t = (w_lo > (uint32_t)kIxCache ? w_lo : (uint32_t)kIxCache) + lane; t < w_hi; t += 64u) {
+                js = seek(js, t);
+                touch(post[lst[js].x + t]);
+            }
+        }
+        __syncthreads();
+#if defined(TVZ_IX_STOP) && TVZ_IX_STOP == 3
+        for (int i = threadIdx.x; i < kIxWords; i += kIxBlock) { bm1[i] = 0; bm2[i] = 0; }
+        for (int i = threadIdx.x; i < kIxLWords; i += kIxBlock) lbits[i] = 0;
+        __syncthreads();
+        continue;
+#endif
+        for (int i = threadIdx.x; i < kIxLWords; i += kIxBlock) lbits[i] = 0;    // done with: ready for the next sub-index
+        const uint32_t *cand = min_match >= 2 ? bm2 : bm1;
+        // ---- rank: candidates before every bitmap word (thread t owns words t*kIxWpt .. +kIxWpt-1) ----
+        uint32_t cw[kIxWpt], c = 0;
+#pragma unroll
+        for (int w = 0; w < kIxWpt; ++w) { cw[w] = cand[threadIdx.x * kIxWpt + w]; c += __popc(cw[w]); }
+        uint32_t rk0;                                      // candidates before this thread's first word
+        {
+            const uint32_t incl = wave_scan_incl(c);
+            if (lane == 63) s_wb[wave] = incl;
+            __syncthreads();
+            rk0 = incl - c;
+        }
+        uint32_t n_cand = 0;
+#pragma unroll
+        for (int w = 0; w < kIxWaves; ++w) {
+            const uint32_t a = s_wb[w];
+            if (w < wave) rk0 += a;
+            n_cand += a;
+        }
+        n_cand = (uint32_t)__builtin_amdgcn_readfirstlane((int)n_cand);
+        {
+            uint32_t run = rk0;
+#pragma unroll
+            for (int w = 0; w < kIxWpt; ++w) { rank[threadIdx.x * kIxWpt + w] = (uint16_t)run; run += __popc(cw[w]); }
+        }
+        static_assert(kIxSlots % kIxBlock == 0, "whole rounds of the block over the slots");
+        const int64_t row0 = (int64_t)sub << kSubLog2;
+
+        // ---- pass B + emit, kIxSlots candidates at a time ----
+        for (uint32_t lo = 0; lo < n_cand; lo += kIxSlots) {
+            // the rows of this part's slots (slot = rank of the candidate - lo): written by the owners of
+            // the bitmap words, no compaction, no atomics
+            {
+                uint32_t run = rk0;
+#pragma unroll
+                for (int ww = 0; ww < kIxWpt; ++ww) {
+                    const uint32_t wi = threadIdx.x * kIxWpt + ww;
+                    for (uint32_t rest = cw[ww], i = 0; rest; rest &= rest - 1, ++i) {
+                        const uint32_t idx = run + i - lo;
+                        if (idx < (uint32_t)kIxSlots) elist[idx] = wi * 32u + ((uint32_t)__ffs(rest) - 1u);
+                    }
+                    run += __popc(cw[ww]);
+                }
+            }
+            __syncthreads();                               // (first round: also publishes rank)
+            const uint32_t n_list = n_cand - lo < (uint32_t)kIxSlots ? n_cand - lo : (uint32_t)kIxSlots;
+            // the video ids of the slots' rows: loads issued now, used after pass B (which touches LDS only)
+            int32_t vid[kIxSlots / kIxBlock];
+#pragma unroll
+            for (int u = 0; u < kIxSlots / kIxBlock; ++u) {
+                const uint32_t k = (uint32_t)u * kIxBlock + threadIdx.x;
+                const int64_t row = row0 + (k < n_list ? elist[k] : 0u);
+                vid[u] = ivid[k < n_list && row < n_indexed ? row : row0];  // unconditional load
+                // replaced since the build (-1) / the query's own video: not a hit
+                if (k >= n_list || row >= n_indexed || vid[u] == excl) vid[u] = -1;
+            }
+            auto account = [&](uint32_t r, uint32_t pos, uint32_t w, uint32_t rkw) {
+                const uint32_t bit = r & 31u;
+                if (!((w >> bit) & 1u)) return;
+                const uint32_t idx = rkw + __popc(w & ((1u << bit) - 1u)) - lo;
+                if (idx >= (uint32_t)kIxSlots) return;                       // another part's (wraps below lo)
                 atomicAdd(&tcnt[idx], 1u);
                 if constexpr (TOP5) {
                     unsigned long long seen = ttop[idx];
@@ -396,84 +585,107 @@ __global__ __launch_bounds__(kIxBlock) void ts_match_index_kernel(
                         seen = old;
                     }
                 } else {
-                    const uint32_t o = atomicMin(&m1[idx], pos);         // positions of one row are distinct
-                    atomicMin(&m2[idx], o > pos ? o : pos);              // larger of two hits >= 2nd smallest
+                    const uint32_t o = atomicMin(&m1[idx], pos);             // positions of one row are distinct
+                    atomicMin(&m2[idx], o > pos ? o : pos);                  // larger of two hits >= 2nd smallest
+                }
+            };
+            // the cached postings, up to four per lane at a time: all reads of a stage before the next
+            // stage (one posting per trip was a chain of four dependent LDS round trips per posting)
+            auto tripb = [&](auto nc, const uint32_t t0) {
+                constexpr int N = decltype(nc)::value;
+                uint32_t e[N], w[N], rkw[N];
+#pragma unroll
+                for (int u = 0; u < N; ++u) {
+                    const uint32_t t = t0 + (uint32_t)(u * 64 + lane);
+                    e[u] = pcache[t < c_hi ? t : c_hi - 1u];
+                }
+#pragma unroll
+                for (int u = 0; u < N; ++u) {
+                    const uint32_t r = e[u] & (uint32_t)(kSubRows - 1);
+                    w[u] = cand[r >> 5];
+                    rkw[u] = rank[r >> 5];
+                }
+#pragma unroll
+                for (int u = 0; u < N; ++u) {
+                    if (t0 + (uint32_t)(u * 64 + lane) >= c_hi) continue;
+                    account(e[u] & (uint32_t)(kSubRows - 1), e[u] >> kSubLog2, w[u], rkw[u]);
+                }
+            };
+            for (uint32_t t0 = w_lo; t0 < c_hi; t0 += 256u) {
+                const uint32_t steps = (c_hi - t0 + 63u) >> 6;                // wave-uniform (scalar)
+                switch (steps >= 4u ? 4u : steps) {
+                    case 1: tripb(IxN<1>{}, t0); break;
+                    case 2: tripb(IxN<2>{}, t0); break;
+                    case 3: tripb(IxN<3>{}, t0); break;
+                    default: tripb(IxN<4>{}, t0); break;
                 }
             }
-        }
-        __syncthreads();
-        // emit, stage 1: thread <-> bitmap word; candidates of this part that reached min_match go to
-        // an LDS list (row in the sub-index << kIxSlotBits | slot).  Looking their video ids up right here,
-        // bit after bit, was one dependent global load per bit and 60 % of the kernel.
-#pragma unroll
-        for (int ww = 0; ww < kIxWpt; ++ww) {
-            const uint32_t wi = threadIdx.x * kIxWpt + ww;
-            const uint32_t w = cand[wi];
-            const uint32_t rk = rank[wi];
-            for (uint32_t rest = w, i = 0; rest; rest &= rest - 1, ++i) {
-                const uint32_t idx = rk + i - lo;
-                if (idx >= (uint32_t)kIxSlots || (int32_t)tcnt[idx] < min_match) continue;
-                const uint32_t bit = (uint32_t)__ffs(rest) - 1u;
-                elist[atomicAdd(&s_nlist, 1u)] = ((wi * 32u + bit) << kIxSlotBits) | idx;
+            if (w_hi > (uint32_t)kIxCache) {                                  // beyond the LDS copy: read them again
+                int js = 0;
+                for (uint32_t t = (w_lo > (uint32_t)kIxCache ? w_lo : (uint32_t)kIxCache) + lane; t < w_hi; t += 64u) {
+                    js = seek(js, t);
+                    const uint2 le = lst[js];
+                    const uint32_t r = post[le.x + t];
+                    account(r, le.y, cand[r >> 5], rank[r >> 5]);
+                }
             }
-        }
-        __syncthreads();
-        // stage 2: one list entry per thread and round (<= 2 rounds): video id, filters, one
-        // reservation per block, write
-        const uint32_t n_list = s_nlist;
-        uint32_t e[kIxSlots / kIxBlock];
-        int32_t vid[kIxSlots / kIxBlock];
-        uint32_t mine = 0;
+            __syncthreads();
+#if defined(TVZ_IX_STOP) && TVZ_IX_STOP == 4
+            for (int i = threadIdx.x; i < kIxSlots; i += kIxBlock) reset_slot((uint32_t)i);
+            break;
+#endif
+            // emit: one slot per thread and round; the slots that reached min_match and are live hits get
+            // a place by a block-wide scan - one reservation per block, none when the block owns the list
+            uint32_t mine = 0;
 #pragma unroll
-        for (int u = 0; u < kIxSlots / kIxBlock; ++u) {
-            const uint32_t k = (uint32_t)u * kIxBlock + threadIdx.x;
-            e[u] = k < n_list ? elist[k] : 0u;
-            const int64_t row = row0 + (e[u] >> kIxSlotBits);
-            vid[u] = ivid[k < n_list && row < n_indexed ? row : row0];  // unconditional load
-            // replaced since the build (-1) / the query's own video: not a hit
-            if (k >= n_list || row >= n_indexed || vid[u] < 0 || vid[u] == excl) vid[u] = -1;
-            mine += vid[u] >= 0 ? 1u : 0u;
-        }
-        uint32_t incl = mine;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t o = __shfl_up(incl, d);
-            if (lane >= d) incl += o;
-        }
-        if (lane == 63) s_wsum[wave] = incl;
-        __syncthreads();
-        uint32_t base = 0, all = 0;
-        for (int x = 0; x < kIxWaves; ++x) { if (x < wave) base += s_wsum[x]; all += s_wsum[x]; }
-        if (threadIdx.x == 0) {
-            s_base = (HOSTOUT || all == 0) ? (uint32_t)s_emitted : (uint32_t)atomicAdd(out_n, (int32_t)all);
-            s_emitted += (int32_t)all;
-            s_nlist = 0;
-        }
-        __syncthreads();
-        uint32_t o = s_base + base + incl - mine;
-        const int64_t room = HOSTOUT ? (int64_t)kSubRows : (int64_t)cap;
-#pragma unroll
-        for (int u = 0; u < kIxSlots / kIxBlock; ++u) {
-            if (vid[u] < 0) continue;
-            const uint32_t idx = e[u] & (uint32_t)(kIxSlots - 1);
-            if ((int64_t)o < room) {
-                int32_t *hp = out_hits + (int64_t)o * 3;
-                hp[0] = vid[u];
-                hp[1] = (int32_t)tcnt[idx];
-                hp[2] = TOP5 ? (int32_t)((uint32_t)(ttop[idx] >> (12 * (min_match - 1))) & 0xfffu)
-                             : (int32_t)(min_match == 1 ? m1[idx] : m2[idx]);
+            for (int u = 0; u < kIxSlots / kIxBlock; ++u) {
+                const uint32_t k = (uint32_t)u * kIxBlock + threadIdx.x;
+                if (vid[u] >= 0 && (int32_t)tcnt[k] < min_match) vid[u] = -1;
+                mine += vid[u] >= 0 ? 1u : 0u;
             }
-            ++o;
-        }
-        __syncthreads();
-        if (lo + kIxSlots < n_cand)
-            for (int i = threadIdx.x; i < kIxSlots; i += kIxBlock) {
-                tcnt[i] = 0;
-                if (TOP5) ttop[i] = kTopNone; else { m1[i] = 0xffffffffu; m2[i] = 0xffffffffu; }
+            const uint32_t incl = wave_scan_incl(mine);
+            if (lane == 63) s_wc[wave] = incl;
+            __syncthreads();
+            uint32_t base = 0, all = 0;
+#pragma unroll
+            for (int x = 0; x < kIxWaves; ++x) {
+                const uint32_t a = s_wc[x];
+                if (x < wave) base += a;
+                all += a;
             }
-        __syncthreads();
+            uint32_t start = emitted;
+            if (!HOSTOUT && !alone && all) {               // block-uniform: the blocks of a query share its list
+                if (threadIdx.x == 0) s_bcast = (uint32_t)atomicAdd(out_n, (int32_t)all);
+                __syncthreads();
+                start = s_bcast;
+            }
+            emitted += all;
+            uint32_t o = start + base + incl - mine;
+            const int64_t room = HOSTOUT ? (int64_t)kSubRows : (int64_t)cap;
+#pragma unroll
+            for (int u = 0; u < kIxSlots / kIxBlock; ++u) {
+                const uint32_t k = (uint32_t)u * kIxBlock + threadIdx.x;
+                if (vid[u] >= 0) {
+                    if ((int64_t)o < room) {
+                        int32_t *hp = out_hits + (int64_t)o * 3;
+                        hp[0] = vid[u];
+                        hp[1] = (int32_t)tcnt[k];
+                        hp[2] = TOP5 ? (int32_t)((uint32_t)(ttop[k] >> (12 * (min_match - 1))) & 0xfffu)
+                                     : (int32_t)(min_match == 1 ? m1[k] : m2[k]);
+                    }
+                    ++o;
+                }
+                if (k < n_list) reset_slot(k);             // this thread was the slot's last reader
+            }
+            if (lo + kIxSlots < n_cand) __syncthreads();   // the next part rewrites elist and refills the slots
+        }
+        // this thread's bitmap words: every reader (pass B of the last part) is behind a barrier
+#pragma unroll
+        for (int w = 0; w < kIxWpt; ++w) { bm1[threadIdx.x * kIxWpt + w] = 0; bm2[threadIdx.x * kIxWpt + w] = 0; }
+        if (HOSTOUT && threadIdx.x == 0) *out_n = (int32_t)emitted;
+        if (n_cand == 0) __syncthreads();                  // (no part ran: keep s_wb's readers ahead of its next writer)
     }
-    if (HOSTOUT && threadIdx.x == 0) *out_n = s_emitted;
+    if (!HOSTOUT && alone && threadIdx.x == 0) hits_n[(size_t)q * ns] = (int32_t)emitted;
 }
 
 }  // namespace

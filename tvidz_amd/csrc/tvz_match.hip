@@ -19,6 +19,7 @@
 // per-call argument and scratch is the caller's workspace.
 #include <algorithm>
 #include <atomic>
+#include <condition_variable>
 #include <mutex>
 #include <shared_mutex>
 #include <thread>
@@ -58,6 +59,7 @@ struct Staging {
     int32_t *d_smult = nullptr;
     int64_t sq_cap = 0;
     std::atomic<int> busy{0};        // a sweep of this staging is in flight (drain() waits for it)
+    int gen = 0;                     // index generation that sweep reads
 };
 
 
@@ -78,21 +80,43 @@ struct RingSlot {
 constexpr int64_t kIndexMinRows = 4096;           // a corpus grown by upserts gets its first index here
 constexpr int64_t kIndexMinDelta = 4096;          // rebuilt when the delta exceeds max(this, n_main / 8)
 
-struct Index {
-    DevBuf<DirEnt> dir;               // n_sub directories of 2^dir_log2 entries
+// One generation of the index's device image (tvz_index_kernels.h).  There are two: matches read
+// `cur`, a rebuild fills the other one (the SHADOW) while they keep running, and a swap under the
+// handle's lock makes it current - no reader ever waits for a rebuild.
+struct IndexBuf {
+    DevBuf<unsigned char> dir;        // 2^dir_log2 entries of 16 + 2 ks bytes
+    DevBuf<uint16_t> post;
+    DevBuf<int32_t> ivid;
+    DevBuf<Row> drows;                // the delta table that goes with this generation
     int dir_log2 = 0;
     int n_sub = 0;                    // sub-indexes of kSubRows rows
-    DevBuf<uint16_t> post;
-    DevBuf<uint32_t> sub_distinct;
-    DevBuf<int32_t> ivid;
-    DevBuf<Row> drows;
-    IxBuildInfo *info = nullptr;      // device
-    bool valid = false;
-    int64_t n_main = 0;
-    int64_t n_delta = 0;
+    int ks = 0;                       // uint16 counts per directory entry
+    int64_t n_main = 0;               // rows [0, n_main) are indexed
     int64_t n_post = 0, n_distinct = 0;
+};
+
+struct Index {
+    IndexBuf buf[2];
+    int cur = 0;                      // the generation matches read (valid only if `valid`)
+    bool valid = false;
+    int64_t n_delta = 0;
     int64_t builds = 0;
-    std::unordered_map<int64_t, int32_t> delta_slot;   // row index -> slot in drows
+    std::unordered_map<int64_t, int32_t> delta_slot;   // row index -> slot in buf[cur].drows
+    // build scratch (only the builder touches it)
+    IxBuildInfo *info = nullptr;      // device
+    DevBuf<uint32_t> fillc;           // per (entry, sub-index pair) fill cursors
+    DevBuf<Row> snap_rows;            // the row table as it was when a background build started
+    DevBuf<int32_t> dead_rows;        // rows upserted during that build (dead in the new generation)
+    hipStream_t bstream = nullptr;    // background builds run here, not on the mutation stream
+    hipEvent_t snap_ev = nullptr;
+    // a background build is running (its thread has released the handle's lock)
+    bool building = false;
+    std::vector<int64_t> since_snap;  // rows upserted since its snapshot
+    std::vector<Row> swap_entries;    // sources of the swap's two small copies: they live here until the
+    std::vector<int32_t> swap_dead;   // next swap, so the swap needs no synchronisation
+    std::condition_variable_any cv;   // signalled when it ends
+    IndexBuf &now() { return buf[cur]; }
+    const IndexBuf &now() const { return buf[cur]; }
 };
 
 }  // namespace
@@ -112,6 +136,7 @@ struct tvz_corpus {
     static constexpr int kEvents = 32;
     hipEvent_t events[kEvents] = {};
     bool ev_pending[kEvents] = {};
+    int ev_gen[kEvents] = {};    // index generation the match behind the event reads
     int ev_next = 0;
     // mutation stream: upsert payload copies + row swaps, in order
     hipStream_t mstream = nullptr;
@@ -203,6 +228,7 @@ int record(tvz_corpus *c, hipStream_t st) {
     if (c->ev_pending[i]) TVZ_HIP(hipEventSynchronize(c->events[i]));
     TVZ_HIP(hipEventRecord(c->events[i], st));
     c->ev_pending[i] = true;
+    c->ev_gen[i] = c->ix.cur;
     return TVZ_OK;
 }
 
@@ -239,71 +265,201 @@ int compact(tvz_corpus *c) {
     return upload_all(c, 0, 0);
 }
 
-// ---- inverted index: build (caller holds mu exclusively and has drained every reader) --------
+// ---- inverted index: build ---------------------------------------------------------------------
 void index_drop(tvz_corpus *c) {
     Index &ix = c->ix;
     ix.valid = false;
-    ix.n_main = ix.n_delta = ix.n_post = ix.n_distinct = 0;
-    ix.n_sub = 0;
+    ix.n_delta = 0;
     ix.delta_slot.clear();
 }
 
-int64_t delta_capacity(int64_t n_main) { return std::max<int64_t>(kIndexMinDelta, n_main / 8) + 64; }
+// The delta table holds delta_capacity() entries; a rebuild is started when it is HALF full, so
+// upserts keep landing in the old generation's table while the new one is being built.
+int64_t delta_trigger(int64_t n_main) { return std::max<int64_t>(kIndexMinDelta, n_main / 8); }
+int64_t delta_capacity(int64_t n_main) { return 2 * delta_trigger(n_main) + 64; }
 
+// Order `st` behind every match that has been enqueued so far: the event-tracked batched calls by
+// a device-side wait (no host stall), the single-query sweeps in flight - not event-tracked, their
+// callers are blocked in a stream synchronisation, ~20 us each - by waiting for them here.  Caller
+// holds mu exclusively, so no new match can be enqueued meanwhile.
+int stream_wait_readers(tvz_corpus *c, hipStream_t st) {
+    {
+        std::lock_guard<std::mutex> lk(c->ev_mu);
+        for (int i = 0; i < tvz_corpus::kEvents; ++i)
+            if (c->ev_pending[i]) TVZ_HIP(hipStreamWaitEvent(st, c->events[i], 0));
+    }
+    std::lock_guard<std::mutex> lk(c->stage_mu);
+    for (Staging *s : c->all_staging)
+        while (s->busy.load(std::memory_order_acquire)) std::this_thread::yield();
+    return TVZ_OK;
+}
+
+// Host-side wait for the matches that still read index generation `gen` (the shadow about to be
+// rebuilt: they were enqueued before the previous swap, i.e. thousands of upserts ago - this
+// returns at once in practice).  Caller holds mu exclusively.
+int wait_generation_idle(tvz_corpus *c, int gen) {
+    {
+        std::lock_guard<std::mutex> lk(c->ev_mu);
+        for (int i = 0; i < tvz_corpus::kEvents; ++i)
+            if (c->ev_pending[i] && c->ev_gen[i] == gen) {
+                TVZ_HIP(hipEventSynchronize(c->events[i]));
+                c->ev_pending[i] = false;
+            }
+    }
+    std::lock_guard<std::mutex> lk(c->stage_mu);
+    for (Staging *s : c->all_staging)
+        while (s->gen == gen && s->busy.load(std::memory_order_acquire)) std::this_thread::yield();
+    return TVZ_OK;
+}
+
+// Build the index of rows [0, n_rows) of the row table image `d_rows` (keys in c->keys) into
+// generation `b` on stream `st`, and wait for it.  `b` must have no reader; nothing of the handle's
+// published state is touched.  rows_cap / keys_cap: the corpus RESERVATION the buffers are sized
+// with, so the rebuilds that upserts trigger allocate nothing until the corpus outgrows it.
+int build_kernels(tvz_corpus *c, IndexBuf &b, const Row *d_rows, int64_t n_rows, int64_t live_keys,
+                  int64_t rows_cap, int64_t keys_cap, hipStream_t st) {
+    Index &ix = c->ix;
+    // posting offsets and counts are 32-bit: a larger shard is swept (shard it over more GPUs)
+    if (n_rows == 0 || live_keys >= (int64_t)0xfffffff0LL)
+        return tvz::fail(TVZ_ERR_UNSUPPORTED, "corpus of %lld rows / %lld keys gets no index", (long long)n_rows,
+                         (long long)live_keys);
+    if (!ix.info) TVZ_HIP(hipMalloc(&ix.info, sizeof(IxBuildInfo)));
+    const int n_sub = (int)tvz::ceil_div(n_rows, kSubRows);
+    TVZ_REQUIRE(n_sub <= 4096, "too many rows for the index (%lld)", (long long)n_rows);
+    const int ks = ix_ks(n_sub), es = ix_entry_bytes(ks);
+    if (int rc = ensure(b.post, std::max<int64_t>(keys_cap, live_keys + 1), 0)) return rc;
+    if (int rc = ensure(b.ivid, std::max<int64_t>(rows_cap, n_rows), 0)) return rc;
+    if (int rc = ensure(b.drows, delta_capacity(std::max<int64_t>(rows_cap, n_rows)), 0)) return rc;
+    // ONE directory over the distinct keys of all rows, load <= 0.5.  Sized from a guess - a
+    // fingerprint corpus repeats its keys many times over (cuts sit on frame grids) - and doubled
+    // while too crowded
+    int log2 = 10;
+    while (((int64_t)1 << log2) < live_keys / 8) ++log2;
+    if (b.dir_log2 > log2 && b.n_sub == n_sub) log2 = b.dir_log2;     // what this corpus needed last time
+    const int blocks = (int)std::min<int64_t>(tvz::ceil_div(n_rows, kBlock / 64), 256 * 8);
+    IxBuildInfo info{};
+    while (true) {
+        TVZ_REQUIRE(log2 <= 30, "index directory would exceed 2^30 entries");
+        const int64_t dn = (int64_t)1 << log2;
+        const int64_t fw = ks ? ks / 2 : 1;
+        if (int rc = ensure(b.dir, dn * es, 0)) return rc;
+        if (int rc = ensure(ix.fillc, tvz::round_up(dn * fw, 4), 0)) return rc;
+        hipLaunchKernelGGL(ix_clear_kernel, dim3(2048), dim3(kBlock), 0, st, reinterpret_cast<uint4 *>(b.dir.p),
+                           (size_t)(dn * es / 16), es / 16, reinterpret_cast<uint4 *>(ix.fillc.p),
+                           (size_t)(tvz::round_up(dn * fw, 4) / 4), ix.info);
+        hipLaunchKernelGGL(ix_count_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, st, d_rows, n_rows, c->keys.p,
+                           b.dir.p, es, ks, log2, b.ivid.p, ix.info);
+        TVZ_HIP(hipGetLastError());
+        TVZ_HIP(hipMemcpyAsync(&info, ix.info, sizeof(info), hipMemcpyDeviceToHost, st));
+        TVZ_HIP(hipStreamSynchronize(st));
+        if (!info.failed && (int64_t)info.n_distinct * 2 <= dn) break;
+        ++log2;                                       // too crowded: twice the directory
+    }
+    const int64_t dn = (int64_t)1 << log2;
+    hipLaunchKernelGGL(ix_offsets_kernel, dim3((unsigned)tvz::ceil_div(dn, kBlock)), dim3(kBlock), 0, st, b.dir.p,
+                       (size_t)dn, es, ks, ix.info);
+    hipLaunchKernelGGL(ix_fill_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, st, d_rows, n_rows, c->keys.p, b.dir.p,
+                       es, ks, log2, ix.fillc.p, b.post.p);
+    TVZ_HIP(hipGetLastError());
+    TVZ_HIP(hipMemcpyAsync(&info, ix.info, sizeof(info), hipMemcpyDeviceToHost, st));
+    TVZ_HIP(hipStreamSynchronize(st));
+    if ((int64_t)info.cursor != live_keys)
+        return tvz::fail(TVZ_ERR_INVALID, "internal: index holds %u postings for %lld keys", info.cursor,
+                         (long long)live_keys);
+    b.n_sub = n_sub;
+    b.ks = ks;
+    b.dir_log2 = log2;
+    b.n_main = n_rows;
+    b.n_post = info.cursor;
+    b.n_distinct = info.n_distinct;
+    return TVZ_OK;
+}
+
+// Synchronous build of the whole row table (upload, explicit rebuild, after a compaction).  Caller
+// holds mu exclusively, has drained every reader and no background build is running.
 int build_index(tvz_corpus *c) {
     Index &ix = c->ix;
     index_drop(c);
     const int64_t n_rows = (int64_t)c->h_rows.size();
-    // posting offsets and counts are 32-bit: a larger shard is swept (shard it over more GPUs)
     if (n_rows == 0 || c->live_keys >= (int64_t)0xfffffff0LL) return TVZ_OK;
-    hipStream_t st = c->mstream;
-    if (!ix.info) TVZ_HIP(hipMalloc(&ix.info, sizeof(IxBuildInfo)));
-    // sized with the corpus RESERVATION (rows.cap / keys.cap double as the table grows), so the
-    // rebuilds that upserts trigger allocate nothing until the corpus outgrows it
-    if (int rc = ensure(ix.post, std::max<int64_t>(c->keys.cap, 1), 0)) return rc;
-    if (int rc = ensure(ix.ivid, c->rows.cap, 0)) return rc;
-    if (int rc = ensure(ix.drows, delta_capacity(c->rows.cap), 0)) return rc;
-    // directories (one per sub-index, all the same size): sized for a guess of the distinct keys of a
-    // sub-index - a fingerprint corpus repeats its keys many times over - and grown if too crowded
-    const int n_sub = (int)tvz::ceil_div(n_rows, kSubRows);
-    TVZ_REQUIRE(n_sub <= 65535, "too many rows for the index (%lld)", (long long)n_rows);
-    const int64_t n_sub_cap = std::max<int64_t>(n_sub, tvz::ceil_div(c->rows.cap, kSubRows));
-    if (int rc = ensure(ix.sub_distinct, n_sub_cap, 0)) return rc;
-    const int64_t per_sub = tvz::ceil_div(c->live_keys, n_sub);
-    int log2 = 10;
-    while (((int64_t)1 << log2) < per_sub / 2) ++log2;
-    const int blocks = (int)std::min<int64_t>(tvz::ceil_div(n_rows, kBlock / 64), 256 * 8);
-    IxBuildInfo info{};
-    while (true) {
-        TVZ_REQUIRE(log2 <= 28, "index directories would exceed 2^28 entries each");
-        const int64_t dn = (int64_t)n_sub << log2;
-        if (int rc = ensure(ix.dir, std::max<int64_t>(dn, n_sub_cap << log2), 0)) return rc;
-        hipLaunchKernelGGL(ix_clear_kernel, dim3(1024), dim3(kBlock), 0, st, ix.dir.p, (size_t)dn,
-                           ix.sub_distinct.p, n_sub, ix.info);
-        hipLaunchKernelGGL(ix_count_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, st, c->rows.p, n_rows,
-                           c->keys.p, ix.dir.p, log2, ix.ivid.p, ix.sub_distinct.p, ix.info);
-        TVZ_HIP(hipGetLastError());
-        TVZ_HIP(hipMemcpyAsync(&info, ix.info, sizeof(info), hipMemcpyDeviceToHost, st));
-        TVZ_HIP(hipStreamSynchronize(st));
-        if (!info.failed && (int64_t)info.max_distinct * 2 <= ((int64_t)1 << log2)) break;
-        ++log2;                                       // too crowded: twice the directories
+    IndexBuf &b = ix.buf[ix.cur ^ 1];
+    if (int rc = build_kernels(c, b, c->rows.p, n_rows, c->live_keys, c->rows.cap, c->keys.cap, c->mstream))
+        return rc;
+    ix.cur ^= 1;
+    ix.valid = true;
+    ++ix.builds;
+    return TVZ_OK;
+}
+
+// No mutation that moves or frees the arena / row table / index buffers may run while a background
+// build reads them: wait for it (the lock is released while waiting).
+void wait_no_build(tvz_corpus *c, std::unique_lock<std::shared_mutex> &lk) {
+    while (c->ix.building) c->ix.cv.wait(lk);
+}
+
+// Background rebuild, run by the upserting thread that crossed the threshold.  The handle's lock is
+// RELEASED while the GPU builds: matches keep reading the current generation + its delta table,
+// upserts keep landing there (and are logged in since_snap).  The build reads a stream-ordered
+// snapshot of the row table and the append-only arena, fills the shadow generation on its own
+// stream, and the swap - a few host operations plus one small copy and one small kernel on the
+// mutation stream - publishes it.  Matches enqueued before the swap finish on the old generation,
+// whose buffers stay untouched until the NEXT rebuild (which first waits for them).
+int rebuild_in_background(tvz_corpus *c, std::unique_lock<std::shared_mutex> &lk) {
+    Index &ix = c->ix;
+    const int64_t n_snap = (int64_t)c->h_rows.size();
+    const int64_t live = c->live_keys, rows_cap = c->rows.cap, keys_cap = c->keys.cap;
+    const int shadow = ix.cur ^ 1;
+    if (!ix.bstream) TVZ_HIP(hipStreamCreateWithFlags(&ix.bstream, hipStreamNonBlocking));
+    if (!ix.snap_ev) TVZ_HIP(hipEventCreateWithFlags(&ix.snap_ev, hipEventDisableTiming));
+    if (int rc = wait_generation_idle(c, shadow)) return rc;
+    if (int rc = ensure(ix.snap_rows, std::max<int64_t>(rows_cap, n_snap), 0)) return rc;
+    // the snapshot is ordered on the mutation stream: behind every upsert that has returned, ahead
+    // of every later one
+    TVZ_HIP(hipMemcpyAsync(ix.snap_rows.p, c->rows.p, (size_t)n_snap * sizeof(Row), hipMemcpyDeviceToDevice,
+                           c->mstream));
+    TVZ_HIP(hipEventRecord(ix.snap_ev, c->mstream));
+    TVZ_HIP(hipStreamWaitEvent(ix.bstream, ix.snap_ev, 0));
+    ix.building = true;
+    ix.since_snap.clear();
+    lk.unlock();
+    int rc = build_kernels(c, ix.buf[shadow], ix.snap_rows.p, n_snap, live, rows_cap, keys_cap, ix.bstream);
+    char msg[512];
+    if (rc) snprintf(msg, sizeof msg, "%s", tvz::err_buf());
+    lk.lock();
+    struct Done { Index &ix; ~Done() { ix.building = false; ix.since_snap.clear(); ix.cv.notify_all(); } } done{ix};
+    if (rc) { snprintf(tvz::err_buf(), 512, "%s", msg); return rc; }
+    IndexBuf &nb = ix.buf[shadow];
+    // the new delta table: every row upserted since the snapshot, once, with its CURRENT entry
+    std::vector<int64_t> &rs = ix.since_snap;
+    std::sort(rs.begin(), rs.end());
+    rs.erase(std::unique(rs.begin(), rs.end()), rs.end());
+    const int64_t d = (int64_t)rs.size();
+    if (d > std::min<int64_t>(nb.drows.cap, delta_capacity(nb.n_main)))
+        return tvz::fail(TVZ_ERR_UNSUPPORTED, "%lld rows changed while the index was being rebuilt", (long long)d);
+    if (d) {
+        std::vector<Row> &entries = ix.swap_entries;
+        std::vector<int32_t> &dead = ix.swap_dead;
+        entries.resize((size_t)d);
+        dead.clear();
+        for (int64_t i = 0; i < d; ++i) {
+            entries[(size_t)i] = c->h_rows[(size_t)rs[(size_t)i]];
+            if (rs[(size_t)i] < nb.n_main) dead.push_back((int32_t)rs[(size_t)i]);
+        }
+        TVZ_HIP(hipMemcpyAsync(nb.drows.p, entries.data(), (size_t)d * sizeof(Row), hipMemcpyHostToDevice, c->mstream));
+        if (!dead.empty()) {
+            if (int rc2 = ensure(ix.dead_rows, (int64_t)dead.size(), 0)) return rc2;
+            TVZ_HIP(hipMemcpyAsync(ix.dead_rows.p, dead.data(), dead.size() * 4, hipMemcpyHostToDevice, c->mstream));
+            hipLaunchKernelGGL(ix_mark_dead_kernel, dim3((unsigned)tvz::ceil_div((int64_t)dead.size(), kBlock)),
+                               dim3(kBlock), 0, c->mstream, nb.ivid.p, ix.dead_rows.p, (int32_t)dead.size());
+            TVZ_HIP(hipGetLastError());
+        }
+        TVZ_HIP(hipEventRecord(c->mut_done, c->mstream));
+        c->mut_any = true;
     }
-    const int64_t dn = (int64_t)n_sub << log2;
-    hipLaunchKernelGGL(ix_offsets_kernel, dim3((unsigned)tvz::ceil_div(dn, kBlock)), dim3(kBlock), 0, st, ix.dir.p,
-                       (size_t)dn, ix.info);
-    hipLaunchKernelGGL(ix_fill_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, st, c->rows.p, n_rows, c->keys.p,
-                       ix.dir.p, log2, ix.post.p);
-    TVZ_HIP(hipGetLastError());
-    TVZ_HIP(hipMemcpyAsync(&info, ix.info, sizeof(info), hipMemcpyDeviceToHost, st));
-    TVZ_HIP(hipStreamSynchronize(st));
-    if ((int64_t)info.cursor != c->live_keys)
-        return tvz::fail(TVZ_ERR_INVALID, "internal: index holds %u postings for %lld keys", info.cursor,
-                         (long long)c->live_keys);
-    ix.n_sub = n_sub;
-    ix.dir_log2 = log2;
-    ix.n_main = n_rows;
-    ix.n_post = info.cursor;
-    ix.n_distinct = info.max_distinct;
+    ix.delta_slot.clear();
+    for (int64_t i = 0; i < d; ++i) ix.delta_slot.emplace(rs[(size_t)i], (int32_t)i);
+    ix.n_delta = d;
+    ix.cur = shadow;
     ix.valid = true;
     ++ix.builds;
     return TVZ_OK;
@@ -618,19 +774,37 @@ bool index_usable(const tvz_corpus *c, int32_t min_match) {
     return c->ix.valid && min_match >= 1 && min_match <= kTop;
 }
 
-// index lookup of Q queries, one block per (query, sub-index); the blocks ADD to the queries'
-// counters (zeroed by the caller) - or, HOSTOUT, each writes its own region and count
+constexpr int kIxMaxLds = 159 * 1024;               // gfx950: 160 KiB of LDS per workgroup, less the static part
+
+// How many sub-indexes one block walks.  A big batch gives every query ONE block (the query's keys
+// are probed once and the hit list needs no atomics); a small batch spreads a query over up to
+// n_sub blocks so that the chip is filled and a lone query's latency is one sub-index deep.
+int index_subs_per_block(int32_t Q, int n_sub, int32_t max_query_len, bool hostout) {
+    int groups = hostout ? n_sub : (int)std::min<int64_t>(n_sub, std::max<int64_t>(1, tvz::ceil_div(2048, std::max(Q, 1))));
+    int spb = (int)tvz::ceil_div(n_sub, std::max(groups, 1));
+    while (spb > 1 && ix_lds_bytes(max_query_len, spb) > (size_t)kIxMaxLds) --spb;
+    return std::max(spb, 1);
+}
+
+// index lookup of Q queries.  *alone_out = the kernel OWNS the hit counters (one block per query:
+// it stores them; nothing has to be zeroed before).  Otherwise the blocks ADD to the queries'
+// counters, which this zeroes first - or, HOSTOUT, every sub-index writes its own region and count.
 template <bool HOSTOUT>
 int launch_index(tvz_corpus *c, const double *d_queries, const int64_t *d_q_offsets, int32_t Q,
                  int32_t max_query_len, int32_t min_match, const int32_t *d_exclude_ids, int32_t exclude_one,
                  int32_t cap, int32_t *d_hits, int32_t *d_hits_n, int32_t ns, hipStream_t st,
                  const QByVal *byval = nullptr) {
     static const QByVal kNoQuery = {};
-    const Index &ix = c->ix;
+    const IndexBuf &ix = c->ix.now();
+    const int spb = index_subs_per_block(Q, ix.n_sub, max_query_len, HOSTOUT);
+    const int groups = (int)tvz::ceil_div(ix.n_sub, spb);
+    if (!HOSTOUT && groups > 1)
+        if (int rc = launch_prep(d_hits_n, ns, Q, nullptr, 0, nullptr, 0, st)) return rc;
+    const size_t lds = ix_lds_bytes(max_query_len, spb);
 #define TVZ_IX(TOP5)                                                                                        \
-    hipLaunchKernelGGL((ts_match_index_kernel<HOSTOUT, TOP5>), dim3((unsigned)Q, (unsigned)ix.n_sub),        \
-                       dim3(kIxBlock), ix_lds_bytes(max_query_len), st, ix.dir.p, ix.dir_log2, ix.post.p,    \
-                       ix.ivid.p, ix.n_main, d_queries, d_q_offsets, max_query_len, min_match, d_exclude_ids, \
+    hipLaunchKernelGGL((ts_match_index_kernel<HOSTOUT, TOP5>), dim3((unsigned)Q, (unsigned)groups),          \
+                       dim3(kIxBlock), lds, st, ix.dir.p, ix.dir_log2, ix.ks, ix.post.p, ix.ivid.p, ix.n_main, \
+                       ix.n_sub, spb, d_queries, d_q_offsets, max_query_len, min_match, d_exclude_ids,        \
                        exclude_one, cap, d_hits, d_hits_n, ns, byval ? *byval : kNoQuery)
     if (min_match <= 2) TVZ_IX(false); else TVZ_IX(true);
 #undef TVZ_IX
@@ -655,12 +829,11 @@ int launch_match(tvz_corpus *c, const double *d_queries, const int64_t *d_q_offs
     if ((algo == TVZ_ALGO_AUTO || algo == TVZ_ALGO_INDEX) && index_usable(c, min_match) && Q > 0) {
         // unchanged rows through the index, rows added or replaced since its build through a sweep
         // of the delta table - a row is in exactly one of the two
-        if (int rc = launch_prep(d_hits_n, ns, Q, nullptr, 0, nullptr, 0, st)) return rc;
         if (int rc = launch_index<false>(c, d_queries, d_q_offsets, Q, max_query_len, min_match, d_exclude_ids,
                                          -1, cap, d_hits, d_hits_n, ns, st))
             return rc;
         if (c->ix.n_delta == 0) return TVZ_OK;
-        span = RowSpan{c->ix.drows.p, c->ix.n_delta};
+        span = RowSpan{c->ix.now().drows.p, c->ix.n_delta};
         zero_counts = false;
         algo = TVZ_ALGO_AUTO;
     }
@@ -791,7 +964,7 @@ static int tvz_corpus_create_impl(tvz_corpus **out, int device) {
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)kJoinLds));
 #define TVZ_IX_ATTR(H, T)                                                                          \
     TVZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(ts_match_index_kernel<H, T>),           \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)ix_lds_bytes(kMaxQueryLen)))
+                                hipFuncAttributeMaxDynamicSharedMemorySize, kIxMaxLds))
     TVZ_IX_ATTR(false, false); TVZ_IX_ATTR(false, true); TVZ_IX_ATTR(true, false); TVZ_IX_ATTR(true, true);
 #undef TVZ_IX_ATTR
     const int q1max = (int)q1_lds_bytes(kQ1MaxLog2);
@@ -822,6 +995,7 @@ static int tvz_corpus_destroy_impl(tvz_corpus *c) {
     DeviceGuard dg(c->device);
     {
         std::unique_lock<std::shared_mutex> lk(c->mu);
+        wait_no_build(c, lk);
         if (c->mstream) (void)drain(c);
         for (Staging *s : c->all_staging) staging_free(s);
         c->all_staging.clear();
@@ -832,12 +1006,18 @@ static int tvz_corpus_destroy_impl(tvz_corpus *c) {
         }
         if (c->keys.p) (void)hipFree(c->keys.p);
         if (c->rows.p) (void)hipFree(c->rows.p);
-        if (c->ix.dir.p) (void)hipFree(c->ix.dir.p);
-        if (c->ix.post.p) (void)hipFree(c->ix.post.p);
-        if (c->ix.sub_distinct.p) (void)hipFree(c->ix.sub_distinct.p);
-        if (c->ix.ivid.p) (void)hipFree(c->ix.ivid.p);
-        if (c->ix.drows.p) (void)hipFree(c->ix.drows.p);
+        for (IndexBuf &b : c->ix.buf) {
+            if (b.dir.p) (void)hipFree(b.dir.p);
+            if (b.post.p) (void)hipFree(b.post.p);
+            if (b.ivid.p) (void)hipFree(b.ivid.p);
+            if (b.drows.p) (void)hipFree(b.drows.p);
+        }
+        if (c->ix.fillc.p) (void)hipFree(c->ix.fillc.p);
+        if (c->ix.snap_rows.p) (void)hipFree(c->ix.snap_rows.p);
+        if (c->ix.dead_rows.p) (void)hipFree(c->ix.dead_rows.p);
         if (c->ix.info) (void)hipFree(c->ix.info);
+        if (c->ix.snap_ev) (void)hipEventDestroy(c->ix.snap_ev);
+        if (c->ix.bstream) (void)hipStreamDestroy(c->ix.bstream);
         for (int i = 0; i < tvz_corpus::kEvents; ++i)
             if (c->events[i]) (void)hipEventDestroy(c->events[i]);
         if (c->mut_done) (void)hipEventDestroy(c->mut_done);
@@ -852,6 +1032,7 @@ static int tvz_corpus_reserve_impl(tvz_corpus *c, int64_t n_rows, int64_t n_keys
     TVZ_REQUIRE(n_rows >= 0 && n_keys >= 0, "negative size");
     DeviceGuard dg(c->device);
     std::unique_lock<std::shared_mutex> lk(c->mu);
+    wait_no_build(c, lk);
     return reserve_locked(c, n_rows, n_keys + n_rows /* padding to even row lengths */);
 }
 
@@ -874,6 +1055,7 @@ static int tvz_corpus_upload_impl(tvz_corpus *c, const int32_t *h_video_ids,
     }
     DeviceGuard dg(c->device);
     std::unique_lock<std::shared_mutex> lk(c->mu);
+    wait_no_build(c, lk);
     if (int rc = drain(c)) return rc;
     c->h_keys.clear();
     c->h_rows.clear();
@@ -910,12 +1092,34 @@ static int tvz_corpus_upsert_impl(tvz_corpus *c, int32_t video_id, const double 
     const int64_t len = canon_row(h_keys, n, tmp);
     const int64_t added = (int64_t)tmp.size();
     std::unique_lock<std::shared_mutex> lk(c->mu);
-    const int64_t off = (int64_t)c->h_keys.size();
-    const int64_t rows_before = (int64_t)c->h_rows.size();
-    auto it = c->first_row.find(video_id);
-    const bool is_new = it == c->first_row.end();
-    const int64_t r = is_new ? rows_before : it->second;
-    TVZ_REQUIRE(rows_before < INT32_MAX - 3, "too many rows");
+    Index &ix = c->ix;
+    int64_t off, rows_before, r;
+    bool is_new, gc, full;
+    while (true) {
+        off = (int64_t)c->h_keys.size();
+        rows_before = (int64_t)c->h_rows.size();
+        auto it = c->first_row.find(video_id);
+        is_new = it == c->first_row.end();
+        r = is_new ? rows_before : it->second;
+        TVZ_REQUIRE(rows_before < INT32_MAX - 3, "too many rows");
+        const int64_t rows_after = rows_before + (is_new ? 1 : 0);
+        const int64_t live_after = c->live_keys + len - (is_new ? 0 : c->h_rows[r].len);
+        // garbage-collect the arena when more than half of it is dead, or grow what is full: the only
+        // paths that wait for matches in flight (amortised: reservations double)
+        gc = off + added > 2 * (live_after + rows_after) + 4096;
+        full = off + added + 2 > c->keys.cap || rows_after + 1 > c->rows.cap;
+        const bool delta_full = ix.valid && ix.delta_slot.find(r) == ix.delta_slot.end() &&
+                                ix.n_delta >= std::min<int64_t>(ix.now().drows.cap, delta_capacity(ix.now().n_main));
+        if (!(gc || full || delta_full)) break;
+        if (ix.building) {            // gc / growth would move what the build reads; a full delta table
+            ix.cv.wait(lk);           // waits for the generation being built.  Then look again.
+            continue;
+        }
+        if (!delta_full) break;
+        // the delta table filled up before a rebuild could be started (it is started at half full):
+        // rebuild now - the lock is released meanwhile - and look again
+        if (rebuild_in_background(c, lk) != TVZ_OK) index_drop(c);      // no index: every match sweeps
+    }
     // host mirror first; every failure below leaves host and device consistent again through
     // the full re-upload of the slow path, or rolls the host mirror back
     const Row old_row = is_new ? Row{0, 0, 0} : c->h_rows[r];
@@ -930,23 +1134,18 @@ static int tvz_corpus_upsert_impl(tvz_corpus *c, int32_t video_id, const double 
     c->live_keys += len - (is_new ? 0 : old_row.len);
     // with an index: the row's current entry also goes to the delta table (which the sweeps read),
     // and an indexed row that changes for the first time has its stale postings marked dead
-    Index &ix = c->ix;
     int32_t slot = -1;
     bool slot_new = false;
     if (ix.valid) {
         auto ds = ix.delta_slot.find(r);
         if (ds != ix.delta_slot.end()) {
             slot = ds->second;
-        } else if (ix.n_delta < std::min<int64_t>(ix.drows.cap, delta_capacity(ix.n_main))) {
+        } else {                       // room was checked above
             slot = (int32_t)ix.n_delta++;
             slot_new = true;
             ix.delta_slot.emplace(r, slot);
         }
     }
-    // no room in the delta table (it is sized at max(4096, rows / 8)), or a corpus grown by upserts
-    // reached the size for its first index: rebuild after this write
-    const bool ix_rebuild = ix.valid ? slot < 0
-                                     : (int64_t)c->h_rows.size() >= std::max(kIndexMinRows, c->ix_next_try_rows);
     auto rollback = [&]() {
         c->h_keys.resize((size_t)off);
         c->live_keys -= len - (is_new ? 0 : old_row.len);
@@ -954,15 +1153,7 @@ static int tvz_corpus_upsert_impl(tvz_corpus *c, int32_t video_id, const double 
         else c->h_rows[r] = old_row;
         if (slot_new) { ix.delta_slot.erase(r); --ix.n_delta; }
     };
-    auto rebuild_index = [&]() {
-        c->ix_next_try_rows = 2 * (int64_t)c->h_rows.size();   // if this build fails: not at every upsert
-        (void)build_index(c);
-    };
-    // garbage-collect the arena when more than half of it is dead, or grow what is full: the only
-    // paths that wait for matches in flight (amortised: reservations double)
-    const bool gc = (int64_t)c->h_keys.size() > 2 * (c->live_keys + (int64_t)c->h_rows.size()) + 4096;
-    const bool full = (int64_t)c->h_keys.size() + 2 > c->keys.cap || (int64_t)c->h_rows.size() + 1 > c->rows.cap;
-    if (gc || full) {
+    if (gc || full) {                  // no background build is running (see above)
         int rc = drain(c);
         if (!rc) rc = gc ? compact(c) : TVZ_OK;
         if (!rc && !gc) rc = upload_all(c, 2 * (int64_t)c->h_rows.size() + 1024,
@@ -970,7 +1161,11 @@ static int tvz_corpus_upsert_impl(tvz_corpus *c, int32_t video_id, const double 
         if (!rc) rc = reserve_locked(c, 2 * (int64_t)c->h_rows.size() + 1024, 0);
         if (rc) { rollback(); index_drop(c); return rc; }
         // compaction moved every row's keys: the delta table's offsets are stale - start afresh
-        if (ix.valid || ix_rebuild) rebuild_index();
+        // (readers are drained anyway)
+        if (ix.valid || (int64_t)c->h_rows.size() >= std::max(kIndexMinRows, c->ix_next_try_rows)) {
+            c->ix_next_try_rows = 2 * (int64_t)c->h_rows.size();
+            (void)build_index(c);
+        }
         return rc;
     }
     // fast path: payload -> pinned ring slot -> async copy into FRESH arena space -> 16-byte row
@@ -1000,21 +1195,36 @@ static int tvz_corpus_upsert_impl(tvz_corpus *c, int32_t video_id, const double 
         }
         s.pending = true;
     }
-    if (slot >= 0)
-        hipLaunchKernelGGL(ts_row_write3_kernel, dim3(1), dim3(1), 0, c->mstream, c->rows.p + r, ix.drows.p + slot,
-                           (slot_new && r < ix.n_main) ? ix.ivid.p + r : nullptr, new_row);
-    else
+    hipError_t e = hipSuccess;
+    if (slot >= 0) {
+        const bool kills_postings = slot_new && r < ix.now().n_main;
+        // A match in flight captured the delta table's size when it was enqueued: it does not sweep
+        // this row's NEW delta entry, so it must still find the row through its postings.  Marking
+        // them dead therefore waits - on the device - for every match enqueued so far; those matches
+        // see the old row, every later one the new row, none neither (db.py:83 under Postgres MVCC
+        // cannot lose a row either).
+        if (kills_postings && stream_wait_readers(c, c->mstream) != TVZ_OK) e = hipErrorUnknown;
+        if (e == hipSuccess)
+            hipLaunchKernelGGL(ts_row_write3_kernel, dim3(1), dim3(1), 0, c->mstream, c->rows.p + r,
+                               ix.now().drows.p + slot, kills_postings ? ix.now().ivid.p + r : nullptr, new_row);
+    } else {
         hipLaunchKernelGGL(ts_row_write_kernel, dim3(1), dim3(1), 0, c->mstream, c->rows.p + r, new_row);
-    hipError_t e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipGetLastError();
     if (e == hipSuccess) e = hipEventRecord(c->mut_done, c->mstream);
     if (e != hipSuccess) {
         rollback();
         return tvz::fail(TVZ_ERR_HIP, "upsert row swap failed: %s", hipGetErrorString(e));
     }
     c->mut_any = true;
-    if (ix_rebuild) {
-        if (int rc = drain(c)) return rc;
-        rebuild_index();
+    if (ix.building) ix.since_snap.push_back(r);       // dead in the generation being built
+    // time for a (new) index?  Built in the background by this thread: the lock is released while
+    // the GPU builds, matches and other upserts go on
+    const bool want = ix.valid ? ix.n_delta >= delta_trigger(ix.now().n_main)
+                               : (int64_t)c->h_rows.size() >= std::max(kIndexMinRows, c->ix_next_try_rows);
+    if (want && !ix.building) {
+        c->ix_next_try_rows = 2 * (int64_t)c->h_rows.size();   // if this build fails: not at every upsert
+        (void)rebuild_in_background(c, lk);            // a failed build leaves the current state in force
     }
     return TVZ_OK;
 }
@@ -1023,7 +1233,12 @@ static int tvz_corpus_clear_impl(tvz_corpus *c) {
     TVZ_REQUIRE(c != nullptr, "corpus is NULL");
     DeviceGuard dg(c->device);
     std::unique_lock<std::shared_mutex> lk(c->mu);
-    // matches in flight keep sweeping the rows they were launched with (the memory stays valid)
+    wait_no_build(c, lk);
+    // Matches in flight keep sweeping the rows they were launched with: the memory stays valid, and
+    // it stays UNCHANGED - the arena is reused from offset 0 by the next upsert, whose copy runs on
+    // the mutation stream, so that stream is made to wait (on the device) for every match enqueued
+    // so far.  No host stall.
+    if (int rc = stream_wait_readers(c, c->mstream)) return rc;
     c->h_keys.clear();
     c->h_rows.clear();
     c->first_row.clear();
@@ -1047,6 +1262,7 @@ static int tvz_corpus_build_index_impl(tvz_corpus *c) {
     TVZ_REQUIRE(c != nullptr, "corpus is NULL");
     DeviceGuard dg(c->device);
     std::unique_lock<std::shared_mutex> lk(c->mu);
+    wait_no_build(c, lk);
     if (int rc = drain(c)) return rc;
     c->ix_next_try_rows = 2 * (int64_t)c->h_rows.size();
     return build_index(c);
@@ -1057,10 +1273,10 @@ static int tvz_corpus_index_stats_impl(tvz_corpus *c, int64_t *n_indexed, int64_
     TVZ_REQUIRE(c != nullptr, "corpus is NULL");
     std::shared_lock<std::shared_mutex> lk(c->mu);
     const Index &ix = c->ix;
-    if (n_indexed) *n_indexed = ix.valid ? ix.n_main : 0;
+    if (n_indexed) *n_indexed = ix.valid ? ix.now().n_main : 0;
     if (n_delta) *n_delta = ix.valid ? ix.n_delta : 0;
-    if (n_post) *n_post = ix.valid ? ix.n_post : 0;
-    if (n_distinct) *n_distinct = ix.valid ? ix.n_distinct : 0;
+    if (n_post) *n_post = ix.valid ? ix.now().n_post : 0;
+    if (n_distinct) *n_distinct = ix.valid ? ix.now().n_distinct : 0;
     if (n_builds) *n_builds = ix.builds;
     return TVZ_OK;
 }
@@ -1176,14 +1392,15 @@ static int tvz_find_duplicates_impl(tvz_corpus *c, const double *h_query, int64_
                     s->busy.store(1, std::memory_order_release);         // drain() waits for this sweep
                     if (attempt == 0 && index_usable(c, min_match)) {
                         used_index = true;
-                        n_sub = c->ix.n_sub;
+                        n_sub = c->ix.now().n_sub;
+                        s->gen = c->ix.cur;
                         if (int rc = launch_index<true>(c, dq, dqo, 1, (int32_t)n, min_match, nullptr, excl, 0,
                                                         s->dh_ix_hits, s->dh_counts + kQ1MaxBlocks, 1, s->stream,
                                                         by_value ? &qv : nullptr)) {
                             s->busy.store(0, std::memory_order_release);
                             return rc;
                         }
-                        span = RowSpan{c->ix.drows.p, c->ix.n_delta};
+                        span = RowSpan{c->ix.now().drows.p, c->ix.n_delta};
                     }
                     if (span.n) {
                         blocks = q1_blocks(span.n, 1);

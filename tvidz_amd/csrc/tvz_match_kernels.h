@@ -59,6 +59,28 @@ __device__ __forceinline__ void wave_lds_fence() {
     __builtin_amdgcn_wave_barrier();
 }
 
+// ---- wave64 inclusive prefix sum on the VALU (six DPP adds: row_shr 1/2/4/8 inside the 16-lane rows,
+// then row_bcast 15 and 31 across them).  A __shfl_up ladder is six ds_bpermute round trips through
+// the LDS crossbar (~100 cycles each, and LDS-pipe time): the index lookup runs five scans per
+// sub-index and was paying ~3,000 cycles of pure latency for them.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_add_u32(uint32_t v) {
+    // lanes whose DPP source is invalid or masked take `old` = 0
+    return v + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xf, false);
+}
+__device__ __forceinline__ uint32_t wave_scan_incl(uint32_t v) {
+    v = dpp_add_u32<0x111, 0xf>(v);  // row_shr:1
+    v = dpp_add_u32<0x112, 0xf>(v);  // row_shr:2
+    v = dpp_add_u32<0x114, 0xf>(v);  // row_shr:4
+    v = dpp_add_u32<0x118, 0xf>(v);  // row_shr:8   -> inclusive scan inside each row
+    v = dpp_add_u32<0x142, 0xa>(v);  // row_bcast:15 into rows 1,3
+    v = dpp_add_u32<0x143, 0xc>(v);  // row_bcast:31 into rows 2,3
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_total(uint32_t incl) {       // of an inclusive scan
+    return (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+}
+
 // ---- canonical key: integer-only so subnormals / signed zero never meet FP modes ----
 __host__ __device__ inline bool canon_key(double x, int64_t &k) {
     int64_t b;
