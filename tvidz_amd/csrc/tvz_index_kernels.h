@@ -246,21 +246,30 @@ static_assert(kIxWpt >= 1 && kIxWpt * kIxBlock == kIxWords, "whole bitmap words 
 constexpr int kIxSlotBits = TVZ_IX_SLOT_BITS;
 constexpr int kIxSlots = 1 << kIxSlotBits;           // candidate slots per part (16 B each)
 constexpr int kIxCache = TVZ_IX_CACHE;               // (row, position) of postings kept in LDS between the passes
-constexpr int kIxLWords = kIxCache / 32;             // list-start bitmap over the cached postings
-constexpr int kIxLPerLane = kIxLWords / 64;
-template <int N> struct IxN { static constexpr int value = N; };   // compile-time trip lengths
-static_assert(kIxLPerLane >= 1 && kIxLPerLane * 64 == kIxLWords, "list-start words split over one wave");
+constexpr int kIxPW = kIxCache / kIxWaves;           // ... per wave
+constexpr int kIxPWSteps = kIxPW / 64;               // steps (64 postings) of a wave's cached range
+constexpr int kIxLW = kIxPW / 32;                    // words of a wave's list-start bitmap
+static_assert(kIxPW % 64 == 0 && kIxPWSteps >= 1 && kIxPWSteps <= 8, "a wave's cached postings = one trip of <= 8 steps");
 static_assert(kSubLog2 <= 16 && kSubLog2 + 12 <= 32, "packed LDS entries");
+template <int N> struct IxN { static constexpr int value = N; };   // compile-time trip lengths
+#ifdef TVZ_IX_STAMP
+// diagnostic build only (profiles/ix_stamps.py): cycles wave 0 of every block spends per phase
+__device__ unsigned long long g_ix_stamps[16];
+#define TVZ_STAMP(i) do { if (threadIdx.x == 0) { const unsigned long long _t = __builtin_amdgcn_s_memtime(); \
+                          st_acc[i] += _t - st_last; st_last = _t; } } while (0)
+#else
+#define TVZ_STAMP(i) do { } while (0)
+#endif
 
-// dynamic LDS: [bm1][bm2][tcnt][ttop][elist][cache][lst u64 x L][lbits][e_cur][s_pre (+2)][rank u16]
-// [e_len u16 x L x nsb] (nsb = sub-indexes this block walks, rounded up to even): 29.5 KiB + 32 B per
-// query position at 7..8 sub-indexes - FOUR blocks (32 waves) per CU for queries of up to ~330
+// dynamic LDS: [bm1][bm2][tcnt][ttop][elist][cache][lst u64 x waves x 64][lbits][e_cur x L][rank u16]
+// [e_len u16 x L x nsb] (nsb = sub-indexes this block walks, rounded up to even): 33.5 KiB + 20 B per
+// query position at 7..8 sub-indexes - FOUR blocks (32 waves) per CU for queries of up to ~320
 // timestamps.
 inline int ix_nsb_padded(int spb) { return (spb + 1) & ~1; }
 inline size_t ix_lds_bytes(int max_len, int spb) {
     const size_t L = (size_t)(max_len > 0 ? max_len : 1);
-    return (size_t)2 * kIxWords * 4 + (size_t)kIxSlots * 16 + (size_t)kIxCache * 4 + L * 8 + (size_t)kIxLWords * 4 +
-           (2 * L + 2) * 4 + (size_t)kIxWords * 2 + L * 2 * (size_t)ix_nsb_padded(spb) + 16;
+    return (size_t)2 * kIxWords * 4 + (size_t)kIxSlots * 16 + (size_t)kIxCache * 4 + (size_t)kIxWaves * 64 * 8 +
+           (size_t)kIxWaves * kIxLW * 4 + (L + 1) * 4 + (size_t)kIxWords * 2 + L * 2 * (size_t)ix_nsb_padded(spb) + 16;
 }
 
 // TOP5 = false (min_match 1..2): a slot keeps the two smallest positions in two atomicMin words -
@@ -271,8 +280,14 @@ inline size_t ix_lds_bytes(int max_len, int spb) {
 //   else   : hits = [Q][cap][3].  groups == 1: the block owns the query's list - it appends without
 //            atomics and STORES hits_n[q] at the end (the caller need not zero it).  groups > 1: the
 //            blocks of a query share the list through atomicAdd on hits_n[q] (zeroed by the caller).
-// A sub-index costs seven block barriers (one chunk of query positions, one part of candidates);
-// every LDS array is reset by the threads that used it last, inside the phases - no clearing pass.
+//
+// Who does what.  Query position i belongs to wave (i mod waves), lane (i / waves): a wave owns the
+// posting lists of ITS positions and walks them on its own - compaction, list-start masks, pass A
+// and pass B need no block barrier and no cross-wave prefix; only the row bitmaps and the candidate
+// slots are shared.  A sub-index costs five block barriers (pass A done, rank, slot rows, pass B
+// done, emit scan); every LDS array is reset inside the phases by the threads that used it last.
+// (Profiled with s_memtime stamps, profiles/ix_stamps.py: with block-wide compaction 55 % of a
+// block's cycles were barrier waits.)
 template <bool HOSTOUT, bool TOP5>
 __global__ __launch_bounds__(kIxBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) void ts_match_index_kernel(
     const unsigned char *__restrict__ dir, int dir_log2, int ks, const uint16_t *__restrict__ post,
@@ -287,15 +302,14 @@ __global__ __launch_bounds__(kIxBlock) __attribute__((amdgpu_waves_per_eu(8, 8))
     unsigned long long *ttop = reinterpret_cast<unsigned long long *>(tcnt + kIxSlots);
     uint32_t *m1 = reinterpret_cast<uint32_t *>(ttop), *m2 = m1 + kIxSlots;   // !TOP5: the same 8 B per slot
     uint32_t *elist = reinterpret_cast<uint32_t *>(ttop + kIxSlots);    // row (in the sub-index) of slot k
-    uint32_t *pcache = elist + kIxSlots;                                // first kIxCache postings: row | position << kSubLog2
+    uint32_t *pcache_all = elist + kIxSlots;                            // cached postings: row | position << kSubLog2
     const int L = max_len > 0 ? max_len : 1;
-    uint2 *lst = reinterpret_cast<uint2 *>(pcache + kIxCache);          // [L] list j: {first posting - postings before it, position}
-    uint32_t *lbits = reinterpret_cast<uint32_t *>(lst + L);            // bit t: a posting list starts at flat posting t
-    uint32_t *e_cur = lbits + kIxLWords;                                // [L] first posting of position i in the CURRENT sub-index
-    uint32_t *s_pre = e_cur + L;                                        // [L + 1] postings before list j
-    uint16_t *rank = reinterpret_cast<uint16_t *>(s_pre + L + 2);       // candidates before bitmap word j
+    uint2 *lst_all = reinterpret_cast<uint2 *>(pcache_all + kIxCache);  // per wave: non-empty list j = {first posting - local start, position}
+    uint32_t *lbits_all = reinterpret_cast<uint32_t *>(lst_all + kIxWaves * 64);   // per wave: bit t = a list starts at local posting t
+    uint32_t *e_cur = lbits_all + kIxWaves * kIxLW;                     // [L] first posting of position i in the CURRENT sub-index
+    uint16_t *rank = reinterpret_cast<uint16_t *>(e_cur + L + 1);       // candidates before bitmap word j
     uint16_t *e_len = rank + kIxWords;                                  // [L][nsb] postings of position i per sub-index
-    __shared__ uint32_t s_wa[kIxWaves], s_la[kIxWaves], s_wb[kIxWaves], s_wc[kIxWaves];
+    __shared__ uint32_t s_wb[kIxWaves], s_wc[kIxWaves];
     __shared__ uint32_t s_bcast;
 
     const int q = blockIdx.x;
@@ -312,14 +326,21 @@ __global__ __launch_bounds__(kIxBlock) __attribute__((amdgpu_waves_per_eu(8, 8))
         return;
     }
     const int n = (int)n64;
+#ifdef TVZ_IX_STAMP
+    unsigned long long st_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long st_last = __builtin_amdgcn_s_memtime();
+#endif
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // in an SGPR: scalar loop bounds
+    uint32_t *pcache = pcache_all + wave * kIxPW;
+    uint2 *lst = lst_all + wave * 64;
+    uint32_t *lbits = lbits_all + wave * kIxLW;
     auto reset_slot = [&](uint32_t k) {
         tcnt[k] = 0;
         if (TOP5) ttop[k] = kTopNone; else { m1[k] = 0xffffffffu; m2[k] = 0xffffffffu; }
     };
     for (int i = threadIdx.x; i < kIxWords; i += kIxBlock) { bm1[i] = 0; bm2[i] = 0; }
-    for (int i = threadIdx.x; i < kIxLWords; i += kIxBlock) lbits[i] = 0;
+    for (int i = threadIdx.x; i < kIxWaves * kIxLW; i += kIxBlock) lbits_all[i] = 0;
     for (int i = threadIdx.x; i < kIxSlots; i += kIxBlock) reset_slot((uint32_t)i);
 
     // ---- directory: ONE probe per query position; the counts of this block's sub-indexes to LDS ----
@@ -364,156 +385,140 @@ __global__ __launch_bounds__(kIxBlock) __attribute__((amdgpu_waves_per_eu(8, 8))
         e_cur[i] = base;
     }
     __syncthreads();
+    TVZ_STAMP(0);
 #if defined(TVZ_IX_STOP) && TVZ_IX_STOP == 1
     return;
 #endif
 
     const int32_t excl = exclude_ids ? exclude_ids[q] : exclude_one;
+    const int n_chunks = (n + kIxBlock - 1) / kIxBlock;    // query positions come in chunks of one per thread
     uint32_t emitted = 0;                                  // hits so far (identical in every thread)
     for (int sub = sub_lo; sub < sub_hi; ++sub) {
         if (HOSTOUT) emitted = 0;                          // every sub-index has its own region and count
-        // ---- the NON-EMPTY posting lists of this sub-index, compacted (block-wide prefix sums) ----
-        uint32_t run_p = 0, run_l = 0;                     // postings / lists of the chunks so far
-        for (int i0 = 0; i0 < n; i0 += kIxBlock) {
-            const int i = i0 + threadIdx.x;
-            uint32_t off = 0, len = 0;
-            if (i < n) {
-                len = e_len[(size_t)i * nsb + (sub - sub_lo)];
-                off = e_cur[i];
-                e_cur[i] = off + len;                                    // the key's next piece follows
-            }
-            const uint32_t incl = wave_scan_incl(len), lincl = wave_scan_incl(len ? 1u : 0u);
-            if (lane == 63) { s_wa[wave] = incl; s_la[wave] = lincl; }
-            __syncthreads();
-            uint32_t pbase = run_p, lbase = run_l;
-#pragma unroll
-            for (int w = 0; w < kIxWaves; ++w) {
-                const uint32_t a = s_wa[w], b = s_la[w];
-                if (w < wave) { pbase += a; lbase += b; }
-                run_p += a;
-                run_l += b;
-            }
-            if (len) {
-                const uint32_t j = lbase + lincl - 1u, p = pbase + incl - len;
-                s_pre[j] = p;
-                lst[j] = make_uint2(off - p, (uint32_t)i);               // posting t of the sub-index = post[.x + t]
-                // where the list starts in the flattened postings (pass A counts the starts)
-                if (p < (uint32_t)kIxCache) atomicOr(&lbits[p >> 5], 1u << (p & 31u));
-            }
-            if (i0 + kIxBlock < n) __syncthreads();                      // the next chunk rewrites s_wa / s_la
-        }
-        const int m = __builtin_amdgcn_readfirstlane((int)run_l);
-        const uint32_t total = (uint32_t)__builtin_amdgcn_readfirstlane((int)run_p);   // <= 4095 lists x 16384 rows: fits 32 bits
         // HOSTOUT: the sub-index's own hit region [sub][kSubRows][3] and count in pinned host memory
         int32_t *out_n = HOSTOUT ? hits_n + sub : hits_n + (size_t)q * ns;
         int32_t *out_hits = HOSTOUT ? hits + (int64_t)sub * kSubRows * 3 : hits + (int64_t)q * cap * 3;
-        if (total == 0) {                                  // nothing of this query in this sub-index (block-uniform)
-            if (HOSTOUT && threadIdx.x == 0) *out_n = 0;
-            __syncthreads();                               // s_wa / s_la are rewritten by the next sub-index
-            continue;
-        }
-        if (threadIdx.x == 0) s_pre[m] = total;
-        __syncthreads();
-#if defined(TVZ_IX_STOP) && TVZ_IX_STOP == 2
-        continue;
-#endif
-
-        // every wave owns a contiguous range of the flattened postings, starting at a multiple of 64
-        const uint32_t w_lo = wave == 0 ? 0u : (uint32_t)(((unsigned long long)total * wave) / kIxWaves) & ~63u;
-        const uint32_t w_hi = wave == kIxWaves - 1 ? total
-                                                   : (uint32_t)(((unsigned long long)total * (wave + 1)) / kIxWaves) & ~63u;
-        const uint32_t c_hi = w_hi < (uint32_t)kIxCache ? w_hi : (uint32_t)kIxCache;   // cached part ends here
-        // beyond the cached range (a query with > kIxCache postings in this sub-index): a lane's list
-        // pointer only moves forward, by a bounded binary search when it has to skip short lists
-        auto seek = [&](int j, uint32_t t) -> int {        // largest j' >= j with s_pre[j'] <= t
-            if (s_pre[j + 1] > t) return j;
-            int lo = j + 1, hi = m;                        // s_pre[lo] <= t < s_pre[hi] = total
-            if (hi - lo > 64 && s_pre[lo + 64] > t) hi = lo + 64;
-            while (hi - lo > 1) {
-                const int mid = (lo + hi) >> 1;
-                if (s_pre[mid] <= t) lo = mid; else hi = mid;
-            }
-            return lo;
-        };
         auto touch = [&](uint32_t r) {                     // pass A's bookkeeping for one posting of row r
             const uint32_t bit = 1u << (r & 31u);
             const uint32_t old = atomicOr(&bm1[r >> 5], bit);
             if (min_match >= 2 && (old & bit)) atomicOr(&bm2[r >> 5], bit);
         };
-        // ---- pass A: which rows are touched (twice); eight posting loads in flight per lane ----
-        if (w_lo < c_hi) {
-            // the list of posting t = (list starts at or before t) - 1.  A step is 64 consecutive postings
-            // = two words of the start bitmap, read by the whole wave (one broadcast read); the starts
-            // before the step are carried in a scalar: no search, no per-posting table lookup
-            uint32_t before = 0;
-#pragma unroll
-            for (int w = 0; w < kIxLPerLane; ++w) {
-                const int wi = lane * kIxLPerLane + w;
-                before += wi < (int)(w_lo >> 5) ? __popc(lbits[wi]) : 0;
+        // ---- this wave's posting lists (position i = chunk * block + lane * waves + wave) ----
+        // chunk 0 - every position of a query of up to 512 timestamps - is laid out in the wave's LOCAL
+        // flat posting space: non-empty lists compacted by a ballot, their starts marked in a bitmap
+        uint32_t off0 = 0, len0 = 0, p0 = 0;               // this lane's chunk-0 list: first posting, length, local start
+        uint32_t tw;                                       // postings of the wave's chunk-0 lists
+        {
+            const int i = lane * kIxWaves + wave;
+            if (i < n) {
+                len0 = e_len[(size_t)i * nsb + (sub - sub_lo)];
+                off0 = e_cur[i];
+                e_cur[i] = off0 + len0;                                  // the key's next piece follows
             }
-            before = wave_total(wave_scan_incl(before));
-            // a trip = N steps with all N posting loads in flight; N is the exact number of steps left
-            // (up to 8): a wave has ~5 steps per sub-index, and eight-step trips with masked-off steps
-            // were 40 % of this loop's instructions
-            auto trip = [&](auto nc, const uint32_t t0) {
+            const uint32_t incl = wave_scan_incl(len0);
+            tw = wave_total(incl);
+            p0 = incl - len0;
+            const unsigned long long some = __ballot(len0 != 0u);
+            if (len0) {
+                const uint32_t j = __builtin_amdgcn_mbcnt_hi((uint32_t)(some >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)some, 0u));
+                lst[j] = make_uint2(off0 - p0, (uint32_t)i);             // local posting t of the wave = post[.x + t]
+                if (p0 < (uint32_t)kIxPW) atomicOr(&lbits[p0 >> 5], 1u << (p0 & 31u));
+            }
+            wave_lds_fence();
+        }
+        const uint32_t c_hi = tw < (uint32_t)kIxPW ? tw : (uint32_t)kIxPW;   // cached part of the local space
+        TVZ_STAMP(1);
+        // ---- pass A: which rows are touched (twice) ----
+        if (c_hi) {
+            // the list of local posting t = (list starts at or before t) - 1.  A step is 64 consecutive
+            // postings = two words of the start bitmap, read by the whole wave (one broadcast read); the
+            // starts before the step are carried in a scalar: no search, no per-posting table lookup.
+            // A trip = N steps with all N posting loads in flight, N = the exact number of steps
+            // (eight-step trips with masked-off steps were 40 % of this loop's instructions).
+            auto trip = [&](auto nc) {
                 constexpr int N = decltype(nc)::value;
-                uint32_t r[N], ps[(N + 1) / 2];             // positions: two 16-bit halves per register
+                // stage by stage, so that the N steps' LDS round trips overlap: start masks -> list
+                // entries -> posting loads.  Lanes past the end of the postings (last step only) read up
+                // to 63 postings beyond the wave's last list: the posting buffer is padded for that, and
+                // the value is discarded.
+                unsigned long long M[N];
+#pragma unroll
+                for (int u = 0; u < N; ++u) M[u] = *reinterpret_cast<const unsigned long long *>(lbits + 2 * u);
+                uint2 e[N];
+                uint32_t before = 0;
 #pragma unroll
                 for (int u = 0; u < N; ++u) {
-                    // unconditional (clamped) loads: a branch around a load makes the compiler wait for
-                    // every load before it
-                    const uint32_t tb = t0 + (uint32_t)(u * 64);
-                    const uint32_t wi = tb < c_hi ? tb >> 5 : 0u;
-                    const unsigned long long M = tb < c_hi ? ((unsigned long long)lbits[wi + 1] << 32) | lbits[wi] : 0ull;
-                    const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(M >> 32),
-                                           __builtin_amdgcn_mbcnt_lo((uint32_t)M, 0u));      // starts before this lane
-                    const uint32_t here = (uint32_t)((M >> lane) & 1ull);
-                    int j = (int)(before + below + here) - 1;
-                    before += (uint32_t)__popcll(M);
-                    const uint32_t t = tb + (uint32_t)lane;
-                    const bool valid = t < c_hi;
-                    j = valid ? j : 0;
-                    const uint2 e = lst[j];
-                    const uint32_t v = post[valid ? e.x + t : e.x + s_pre[j]];
-                    r[u] = valid ? v : 0xffffffffu;
-                    ps[u >> 1] = (u & 1) ? ps[u >> 1] | (e.y << 16) : e.y;
+                    const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(M[u] >> 32),
+                                           __builtin_amdgcn_mbcnt_lo((uint32_t)M[u], 0u));   // starts before this lane
+                    const uint32_t here = (uint32_t)((M[u] >> lane) & 1ull);
+                    e[u] = lst[before + below + here - 1u];
+                    before += (uint32_t)__popcll(M[u]);
                 }
+                uint32_t r[N];
+#pragma unroll
+                for (int u = 0; u < N; ++u) r[u] = post[e[u].x + (uint32_t)(u * 64 + lane)];
+#pragma unroll
+                for (int u = 0; u < N; ++u) lbits[2 * u + (lane & 1)] = 0;      // done with: ready for the next sub-index
 #pragma unroll
                 for (int u = 0; u < N; ++u) {
-                    if (r[u] == 0xffffffffu) continue;
-                    pcache[t0 + (uint32_t)(u * 64 + lane)] = r[u] | (((ps[u >> 1] >> ((u & 1) * 16)) & 0xffffu) << kSubLog2);
+                    const uint32_t t = (uint32_t)(u * 64 + lane);
+                    if (t >= c_hi) continue;
+                    pcache[t] = r[u] | (e[u].y << kSubLog2);
                     touch(r[u]);
                 }
             };
-            for (uint32_t t0 = w_lo; t0 < c_hi; t0 += 512u) {
-                const uint32_t steps = (c_hi - t0 + 63u) >> 6;                // wave-uniform (scalar)
-                switch (steps >= 8u ? 8u : steps) {
-                    case 1: trip(IxN<1>{}, t0); break;
-                    case 2: trip(IxN<2>{}, t0); break;
-                    case 3: trip(IxN<3>{}, t0); break;
-                    case 4: trip(IxN<4>{}, t0); break;
-                    case 5: trip(IxN<5>{}, t0); break;
-                    case 6: trip(IxN<6>{}, t0); break;
-                    case 7: trip(IxN<7>{}, t0); break;
-                    default: trip(IxN<8>{}, t0); break;
-                }
+            switch ((c_hi + 63u) >> 6) {                   // wave-uniform (scalar)
+                case 1: trip(IxN<1>{}); break;
+                case 2: trip(IxN<2>{}); break;
+                case 3: trip(IxN<3>{}); break;
+                case 4: trip(IxN<4>{}); break;
+                case 5: trip(IxN<5>{}); break;
+                case 6: trip(IxN<6>{}); break;
+                case 7: trip(IxN<7>{}); break;
+                default: trip(IxN<8>{}); break;
             }
         }
-        if (w_hi > (uint32_t)kIxCache) {
-            int js = 0;
-            for (uint32_t t = (w_lo > (uint32_t)kIxCache ? w_lo : (uint32_t)kIxCache) + lane; t < w_hi; t += 64u) {
-                js = seek(js, t);
-                touch(post[lst[js].x + t]);
+        // postings outside the cached range - the tail of a wave with more than kIxPW postings in this
+        // sub-index (5 % of the waves on the config-4 corpus, 1 % of the postings), and every later chunk
+        // of a query of more than 512 timestamps.  The WAVE walks those lists one after the other, 64
+        // postings at a time (a lane walking its own list alone was a chain of dependent loads).
+        // `each_uncached(f)` calls f(row, position) for all of them; pass B uses it again.
+        auto walk_lists = [&](unsigned long long todo, uint32_t off, uint32_t len, uint32_t first, uint32_t posn, auto f) {
+            while (todo) {                                 // wave-uniform
+                const int src = __builtin_amdgcn_readfirstlane(__ffsll((long long)todo) - 1);
+                todo &= todo - 1;
+                const uint32_t o = (uint32_t)__builtin_amdgcn_readlane((int)off, src);
+                const uint32_t l = (uint32_t)__builtin_amdgcn_readlane((int)len, src);
+                const uint32_t k0 = (uint32_t)__builtin_amdgcn_readlane((int)first, src);
+                const uint32_t ps = (uint32_t)__builtin_amdgcn_readlane((int)posn, src);
+                for (uint32_t k = k0 + (uint32_t)lane; k < l; k += 64u) f((uint32_t)post[o + k], ps);
             }
+        };
+        auto each_uncached = [&](auto f) {
+            if (tw > (uint32_t)kIxPW) {
+                const uint32_t first = p0 < (uint32_t)kIxPW ? (uint32_t)kIxPW - p0 : 0u;
+                walk_lists(__ballot(first < len0), off0, len0, first, (uint32_t)(lane * kIxWaves + wave), f);
+            }
+            for (int c = 1; c < n_chunks; ++c) {
+                const int i = c * kIxBlock + lane * kIxWaves + wave;
+                const uint32_t len = i < n ? e_len[(size_t)i * nsb + (sub - sub_lo)] : 0u;
+                const uint32_t off = i < n ? e_cur[i] - len : 0u;         // (e_cur was advanced below)
+                walk_lists(__ballot(len != 0u), off, len, 0u, (uint32_t)i, f);
+            }
+        };
+        for (int c = 1; c < n_chunks; ++c) {               // advance the later chunks' cursors (once per sub-index)
+            const int i = c * kIxBlock + lane * kIxWaves + wave;
+            if (i < n) e_cur[i] += e_len[(size_t)i * nsb + (sub - sub_lo)];
         }
+        if (tw > (uint32_t)kIxPW || n_chunks > 1) each_uncached([&](uint32_t r, uint32_t) { touch(r); });
+        TVZ_STAMP(2);
         __syncthreads();
+        TVZ_STAMP(3);
 #if defined(TVZ_IX_STOP) && TVZ_IX_STOP == 3
         for (int i = threadIdx.x; i < kIxWords; i += kIxBlock) { bm1[i] = 0; bm2[i] = 0; }
-        for (int i = threadIdx.x; i < kIxLWords; i += kIxBlock) lbits[i] = 0;
         __syncthreads();
         continue;
 #endif
-        for (int i = threadIdx.x; i < kIxLWords; i += kIxBlock) lbits[i] = 0;    // done with: ready for the next sub-index
         const uint32_t *cand = min_match >= 2 ? bm2 : bm1;
         // ---- rank: candidates before every bitmap word (thread t owns words t*kIxWpt .. +kIxWpt-1) ----
         uint32_t cw[kIxWpt], c = 0;
@@ -558,7 +563,9 @@ __global__ __launch_bounds__(kIxBlock) __attribute__((amdgpu_waves_per_eu(8, 8))
                     run += __popc(cw[ww]);
                 }
             }
+            TVZ_STAMP(4);
             __syncthreads();                               // (first round: also publishes rank)
+            TVZ_STAMP(5);
             const uint32_t n_list = n_cand - lo < (uint32_t)kIxSlots ? n_cand - lo : (uint32_t)kIxSlots;
             // the video ids of the slots' rows: loads issued now, used after pass B (which touches LDS only)
             int32_t vid[kIxSlots / kIxBlock];
@@ -566,7 +573,11 @@ __global__ __launch_bounds__(kIxBlock) __attribute__((amdgpu_waves_per_eu(8, 8))
             for (int u = 0; u < kIxSlots / kIxBlock; ++u) {
                 const uint32_t k = (uint32_t)u * kIxBlock + threadIdx.x;
                 const int64_t row = row0 + (k < n_list ? elist[k] : 0u);
+#ifdef TVZ_IX_NOIVID
+                vid[u] = (int32_t)row;
+#else
                 vid[u] = ivid[k < n_list && row < n_indexed ? row : row0];  // unconditional load
+#endif
                 // replaced since the build (-1) / the query's own video: not a hit
                 if (k >= n_list || row >= n_indexed || vid[u] == excl) vid[u] = -1;
             }
@@ -589,8 +600,8 @@ __global__ __launch_bounds__(kIxBlock) __attribute__((amdgpu_waves_per_eu(8, 8))
                     atomicMin(&m2[idx], o > pos ? o : pos);                  // larger of two hits >= 2nd smallest
                 }
             };
-            // the cached postings, up to four per lane at a time: all reads of a stage before the next
-            // stage (one posting per trip was a chain of four dependent LDS round trips per posting)
+            // the wave's cached postings, up to four per lane at a time: all reads of a stage before the
+            // next stage (one posting per trip was a chain of four dependent LDS round trips per posting)
             auto tripb = [&](auto nc, const uint32_t t0) {
                 constexpr int N = decltype(nc)::value;
                 uint32_t e[N], w[N], rkw[N];
@@ -611,7 +622,7 @@ __global__ __launch_bounds__(kIxBlock) __attribute__((amdgpu_waves_per_eu(8, 8))
                     account(e[u] & (uint32_t)(kSubRows - 1), e[u] >> kSubLog2, w[u], rkw[u]);
                 }
             };
-            for (uint32_t t0 = w_lo; t0 < c_hi; t0 += 256u) {
+            for (uint32_t t0 = 0; t0 < c_hi; t0 += 256u) {
                 const uint32_t steps = (c_hi - t0 + 63u) >> 6;                // wave-uniform (scalar)
                 switch (steps >= 4u ? 4u : steps) {
                     case 1: tripb(IxN<1>{}, t0); break;
@@ -620,16 +631,11 @@ __global__ __launch_bounds__(kIxBlock) __attribute__((amdgpu_waves_per_eu(8, 8))
                     default: tripb(IxN<4>{}, t0); break;
                 }
             }
-            if (w_hi > (uint32_t)kIxCache) {                                  // beyond the LDS copy: read them again
-                int js = 0;
-                for (uint32_t t = (w_lo > (uint32_t)kIxCache ? w_lo : (uint32_t)kIxCache) + lane; t < w_hi; t += 64u) {
-                    js = seek(js, t);
-                    const uint2 le = lst[js];
-                    const uint32_t r = post[le.x + t];
-                    account(r, le.y, cand[r >> 5], rank[r >> 5]);
-                }
-            }
+            if (tw > (uint32_t)kIxPW || n_chunks > 1)
+                each_uncached([&](uint32_t r, uint32_t pos) { account(r, pos, cand[r >> 5], rank[r >> 5]); });
+            TVZ_STAMP(6);
             __syncthreads();
+            TVZ_STAMP(7);
 #if defined(TVZ_IX_STOP) && TVZ_IX_STOP == 4
             for (int i = threadIdx.x; i < kIxSlots; i += kIxBlock) reset_slot((uint32_t)i);
             break;
@@ -646,6 +652,7 @@ __global__ __launch_bounds__(kIxBlock) __attribute__((amdgpu_waves_per_eu(8, 8))
             const uint32_t incl = wave_scan_incl(mine);
             if (lane == 63) s_wc[wave] = incl;
             __syncthreads();
+            TVZ_STAMP(8);
             uint32_t base = 0, all = 0;
 #pragma unroll
             for (int x = 0; x < kIxWaves; ++x) {
@@ -666,7 +673,11 @@ __global__ __launch_bounds__(kIxBlock) __attribute__((amdgpu_waves_per_eu(8, 8))
             for (int u = 0; u < kIxSlots / kIxBlock; ++u) {
                 const uint32_t k = (uint32_t)u * kIxBlock + threadIdx.x;
                 if (vid[u] >= 0) {
+#ifdef TVZ_IX_NOSTORE
+                    if ((int64_t)o < room && tcnt[k] == 0x7fffffffu) {
+#else
                     if ((int64_t)o < room) {
+#endif
                         int32_t *hp = out_hits + (int64_t)o * 3;
                         hp[0] = vid[u];
                         hp[1] = (int32_t)tcnt[k];
@@ -684,8 +695,15 @@ __global__ __launch_bounds__(kIxBlock) __attribute__((amdgpu_waves_per_eu(8, 8))
         for (int w = 0; w < kIxWpt; ++w) { bm1[threadIdx.x * kIxWpt + w] = 0; bm2[threadIdx.x * kIxWpt + w] = 0; }
         if (HOSTOUT && threadIdx.x == 0) *out_n = (int32_t)emitted;
         if (n_cand == 0) __syncthreads();                  // (no part ran: keep s_wb's readers ahead of its next writer)
+        TVZ_STAMP(9);
     }
     if (!HOSTOUT && alone && threadIdx.x == 0) hits_n[(size_t)q * ns] = (int32_t)emitted;
+#ifdef TVZ_IX_STAMP
+    if (threadIdx.x == 0) {
+        for (int i = 0; i < 10; ++i) atomicAdd(&g_ix_stamps[i], st_acc[i]);
+        atomicAdd(&g_ix_stamps[15], 1ull);
+    }
+#endif
 }
 
 }  // namespace

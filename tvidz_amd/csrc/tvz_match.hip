@@ -327,7 +327,8 @@ int build_kernels(tvz_corpus *c, IndexBuf &b, const Row *d_rows, int64_t n_rows,
     const int n_sub = (int)tvz::ceil_div(n_rows, kSubRows);
     TVZ_REQUIRE(n_sub <= 4096, "too many rows for the index (%lld)", (long long)n_rows);
     const int ks = ix_ks(n_sub), es = ix_entry_bytes(ks);
-    if (int rc = ensure(b.post, std::max<int64_t>(keys_cap, live_keys + 1), 0)) return rc;
+    // (+64: the lookup's last step reads up to 63 postings past the last list and discards them)
+    if (int rc = ensure(b.post, std::max<int64_t>(keys_cap, live_keys) + 64, 0)) return rc;
     if (int rc = ensure(b.ivid, std::max<int64_t>(rows_cap, n_rows), 0)) return rc;
     if (int rc = ensure(b.drows, delta_capacity(std::max<int64_t>(rows_cap, n_rows)), 0)) return rc;
     // ONE directory over the distinct keys of all rows, load <= 0.5.  Sized from a guess - a
@@ -1614,6 +1615,17 @@ static int tvz_align_impl(tvz_corpus *c, const double *d_query, int32_t n, doubl
     TVZ_HIP(hipGetLastError());
     return record(c, st);
 }
+
+#ifdef TVZ_IX_STAMP
+// diagnostic build only: read (and clear) the per-phase cycle totals of ts_match_index_kernel
+TVZ_EXPORT int tvz_debug_ix_stamps(unsigned long long *out16) {
+    TVZ_HIP(hipDeviceSynchronize());
+    TVZ_HIP(hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_ix_stamps), 16 * 8));
+    unsigned long long z[16] = {};
+    TVZ_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_ix_stamps), z, 16 * 8));
+    return TVZ_OK;
+}
+#endif
 
 TVZ_EXPORT size_t tvz_match_workspace_bytes(int32_t Q, int32_t max_query_len, int32_t cap, int32_t k,
                                             int32_t n_ranks) {
