@@ -21,3 +21,26 @@ def test_plain_c_consumer(tmp_path):
     out = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120)
     assert out.returncode == 0, out.stderr
     assert "c_abi_smoke OK" in out.stdout
+
+
+def test_rebuilds_do_not_stall_lookups(tmp_path):
+    """db.py:83: a reader never waits for a writer.  100k rows, 40k upserts (several background
+    rebuilds of the index), a thread timing every tvz_find_duplicates call from C (no GIL in the
+    picture): every result is right and no call waits for a rebuild (~2 ms of GPU work each at this
+    size; a drained reader used to wait 5 ms at 100k rows)."""
+    import json
+    from tvidz_amd import build
+    build.build()
+    exe = str(tmp_path / "rebuild_latency")
+    cmd = ["gcc", "-O1", "-pthread", f"-I{ROOT}/include", f"{ROOT}/tests/rebuild_latency.c", "-o", exe,
+           f"-L{ROOT}/tvidz_amd", "-ltvz", "-lm", f"-Wl,-rpath,{ROOT}/tvidz_amd", "-Wl,-rpath,/opt/rocm/lib"]
+    subprocess.check_call(cmd)
+    out = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr + out.stdout
+    res = json.loads(out.stdout.strip().splitlines()[-1])
+    print(res)
+    assert res["wrong_results"] == 0
+    assert res["rebuilds"] >= 2 and res["indexed_rows"] > 100000, res
+    assert res["lookups_during_upserts"] > 1000, res
+    assert res["max_us"] < 1000.0, res          # no lookup waited for a rebuild
+    assert res["p99_us"] < 300.0, res

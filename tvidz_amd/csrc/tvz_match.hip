@@ -336,8 +336,14 @@ int build_kernels(tvz_corpus *c, IndexBuf &b, const Row *d_rows, int64_t n_rows,
     // while too crowded
     int log2 = 10;
     while (((int64_t)1 << log2) < live_keys / 8) ++log2;
-    if (b.dir_log2 > log2 && b.n_sub == n_sub) log2 = b.dir_log2;     // what this corpus needed last time
-    const int blocks = (int)std::min<int64_t>(tvz::ceil_div(n_rows, kBlock / 64), 256 * 8);
+    if (ix.valid && ix.now().n_post > 0) {
+        // the current generation knows how often this corpus repeats its keys: one count pass, no retry
+        const double guess = (double)ix.now().n_distinct * (double)live_keys / (double)ix.now().n_post * 1.25;
+        while ((double)((int64_t)1 << log2) < 2.0 * guess && log2 < 30) ++log2;
+    }
+    // one row per wave and SHORT-LIVED blocks (no grid-stride loop): a background build shares the GPU
+    // with lookups, whose few blocks get a CU as soon as any of these retires
+    const int64_t blocks = tvz::ceil_div(n_rows, kBlock / 64);
     IxBuildInfo info{};
     while (true) {
         TVZ_REQUIRE(log2 <= 30, "index directory would exceed 2^30 entries");
@@ -389,6 +395,18 @@ int build_index(tvz_corpus *c) {
     ix.cur ^= 1;
     ix.valid = true;
     ++ix.builds;
+    // size the OTHER generation and the snapshot buffer now, while nobody is waiting: a background
+    // rebuild then allocates nothing (hipMalloc / hipFree synchronise the whole device - a lookup in
+    // flight would wait for them)
+    IndexBuf &o = ix.buf[ix.cur ^ 1];
+    const IndexBuf &n = ix.buf[ix.cur];
+    (void)ensure(o.dir, 2 * n.dir.cap, 0);         // room for the directory to double once
+    (void)ensure(ix.fillc, 2 * ix.fillc.cap, 0);
+    (void)ensure(o.post, n.post.cap, 0);
+    (void)ensure(o.ivid, n.ivid.cap, 0);
+    (void)ensure(o.drows, n.drows.cap, 0);
+    (void)ensure(ix.snap_rows, c->rows.cap, 0);
+    (void)ensure(ix.dead_rows, n.drows.cap, 0);
     return TVZ_OK;
 }
 
@@ -410,8 +428,6 @@ int rebuild_in_background(tvz_corpus *c, std::unique_lock<std::shared_mutex> &lk
     const int64_t n_snap = (int64_t)c->h_rows.size();
     const int64_t live = c->live_keys, rows_cap = c->rows.cap, keys_cap = c->keys.cap;
     const int shadow = ix.cur ^ 1;
-    if (!ix.bstream) TVZ_HIP(hipStreamCreateWithFlags(&ix.bstream, hipStreamNonBlocking));
-    if (!ix.snap_ev) TVZ_HIP(hipEventCreateWithFlags(&ix.snap_ev, hipEventDisableTiming));
     if (int rc = wait_generation_idle(c, shadow)) return rc;
     if (int rc = ensure(ix.snap_rows, std::max<int64_t>(rows_cap, n_snap), 0)) return rc;
     // the snapshot is ordered on the mutation stream: behind every upsert that has returned, ahead
@@ -509,7 +525,11 @@ int staging_size(Staging *s, int64_t rows) {
 int staging_new(tvz_corpus *c, Staging **out) {
     Staging *s = new Staging();
     struct Guard { Staging *s; ~Guard() { if (s) staging_free(s); } } g{s};
-    TVZ_HIP(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+    {                                    // single-query lookups: ahead of background index builds
+        int least = 0, greatest = 0;
+        TVZ_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        TVZ_HIP(hipStreamCreateWithPriority(&s->stream, hipStreamNonBlocking, greatest));
+    }
     TVZ_HIP(hipHostMalloc(&s->h_query, (size_t)(kQueryStageKeys + 2) * 8, hipHostMallocDefault));
     TVZ_HIP(hipMalloc(&s->d_query, (size_t)(kQueryStageKeys + 2) * 8));
     TVZ_HIP(hipMalloc(&s->d_hits_n, sizeof(int32_t)));
@@ -547,6 +567,16 @@ int reserve_locked(tvz_corpus *c, int64_t n_rows, int64_t n_keys) {
         if (int rc = ensure(c->keys, n_keys + 2, (int64_t)c->h_keys.size())) return rc;
         if (int rc = ensure(c->rows, n_rows + 1, (int64_t)c->h_rows.size())) return rc;
     }
+    // the host mirrors and maps follow the device reservation: inside it an upsert never reallocates
+    // a vector or rehashes a map under the exclusive lock (growing the 32 MB key mirror of a 100k-row
+    // corpus was a 9 ms stall for every lookup waiting for the lock)
+    c->h_keys.reserve((size_t)c->keys.cap);
+    c->h_rows.reserve((size_t)c->rows.cap);
+    c->first_row.reserve((size_t)c->rows.cap);
+    c->ix.delta_slot.reserve((size_t)delta_capacity(c->rows.cap));
+    c->ix.since_snap.reserve((size_t)delta_capacity(c->rows.cap));
+    c->ix.swap_entries.reserve((size_t)delta_capacity(c->rows.cap));
+    c->ix.swap_dead.reserve((size_t)delta_capacity(c->rows.cap));
     if (n_rows > c->stage_rows) {
         std::lock_guard<std::mutex> lk(c->stage_mu);
         c->stage_rows = n_rows;
@@ -953,6 +983,15 @@ static int tvz_corpus_create_impl(tvz_corpus **out, int device) {
         TVZ_HIP(hipEventCreateWithFlags(&c->events[i], hipEventDisableTiming));
     TVZ_HIP(hipStreamCreateWithFlags(&c->mstream, hipStreamNonBlocking));
     TVZ_HIP(hipEventCreateWithFlags(&c->mut_done, hipEventDisableTiming));
+    {   // background index builds: their own stream, lowest priority (lookups and upserts go first).
+        // Created here, not at the first rebuild: creating a stream takes milliseconds and holds
+        // runtime locks a lookup in flight would wait for
+        int least = 0, greatest = 0;
+        TVZ_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        TVZ_HIP(hipStreamCreateWithPriority(&c->ix.bstream, hipStreamNonBlocking, least));
+        TVZ_HIP(hipEventCreateWithFlags(&c->ix.snap_ev, hipEventDisableTiming));
+        TVZ_HIP(hipMalloc(&c->ix.info, sizeof(IxBuildInfo)));
+    }
     for (RingSlot &s : c->ring) {
         TVZ_HIP(hipHostMalloc(&s.h, (size_t)kRingSlotKeys * 8, hipHostMallocDefault));
         TVZ_HIP(hipEventCreateWithFlags(&s.ev, hipEventDisableTiming));
