@@ -87,6 +87,8 @@ int main(void) {
     const int n_quiet = n_lat;
     /* upserts far from the probe's keys (> 2500 s): none of them can become a hit */
     double row[LEN], max_upsert_us = 0;
+    double win0[64], win1[64];            /* the upsert calls that rebuilt the index: [start, end] since t_start */
+    int n_win = 0;
     for (int v = 0; v < NEW_ROWS; ++v) {
         for (int j = 0; j < LEN; ++j) row[j] = 2500.0 + (double)(rnd() % 100000) / 7.0;
         const double t0 = now_us();
@@ -101,6 +103,7 @@ int main(void) {
         nanosleep(&gap, NULL);
         int64_t b = 0;
         CHECK(tvz_corpus_index_stats(corpus, NULL, NULL, NULL, NULL, &b));
+        if (b != builds_now && n_win < 64) { win0[n_win] = t0 - t_start; win1[n_win] = t0 - t_start + dt; n_win++; }
         builds_now = b;
     }
     stop_flag = 1;
@@ -108,6 +111,19 @@ int main(void) {
     int64_t n_ix = 0, n_delta = 0, b1 = 0;
     CHECK(tvz_corpus_index_stats(corpus, &n_ix, &n_delta, NULL, NULL, &b1));
     const int n_busy = n_lat - n_quiet;
+    /* lookups that STARTED AND FINISHED while a rebuild was running: none if readers waited for rebuilds,
+     * dozens if they do not (robust against the occasional multi-millisecond hiccup of a shared host,
+     * which hits lookups and upserts alike whether or not a rebuild is running) */
+    int inside = 0, min_inside = 1 << 30;
+    double rebuild_us = 0;
+    for (int w = 0; w < n_win; ++w) {
+        int k = 0;
+        for (int i = n_quiet; i < n_lat; ++i)
+            if (lat_at[i] - lat[i] >= win0[w] && lat_at[i] <= win1[w]) k++;
+        inside += k;
+        if (k < min_inside) min_inside = k;
+        rebuild_us += win1[w] - win0[w];
+    }
     for (int i = n_quiet; i < n_lat; ++i)
         if (lat[i] > 500.f) fprintf(stderr, "slow lookup: %.0f us, returned at %.0f us (builds then: %lld)\n", lat[i], lat_at[i], (long long)lat_builds[i]);
     float *q = malloc(n_quiet * sizeof *q), *w = malloc((n_busy > 0 ? n_busy : 1) * sizeof *w);
@@ -118,10 +134,12 @@ int main(void) {
     printf("{\"rows\": %d, \"upserts\": %d, \"rebuilds\": %lld, \"indexed_rows\": %lld, \"delta_rows\": %lld, "
            "\"lookups_quiet\": %d, \"quiet_median_us\": %.1f, \"quiet_max_us\": %.1f, "
            "\"lookups_during_upserts\": %d, \"median_us\": %.1f, \"p99_us\": %.1f, \"p999_us\": %.1f, \"max_us\": %.1f, "
-           "\"max_upsert_us\": %.1f, \"wrong_results\": %d}\n",
+           "\"max_upsert_us\": %.1f, \"rebuild_calls_us_mean\": %.1f, \"lookups_completed_inside_rebuilds\": %d, "
+           "\"min_lookups_inside_one_rebuild\": %d, \"wrong_results\": %d}\n",
            ROWS, NEW_ROWS, (long long)(b1 - b0), (long long)n_ix, (long long)n_delta, n_quiet, q[n_quiet / 2],
            q[n_quiet - 1], n_busy, n_busy ? w[n_busy / 2] : 0.f, n_busy ? w[(int)(n_busy * 0.99)] : 0.f,
-           n_busy ? w[(int)(n_busy * 0.999)] : 0.f, n_busy ? w[n_busy - 1] : 0.f, max_upsert_us, wrong);
+           n_busy ? w[(int)(n_busy * 0.999)] : 0.f, n_busy ? w[n_busy - 1] : 0.f, max_upsert_us,
+           n_win ? rebuild_us / n_win : 0.0, inside, n_win ? min_inside : 0, wrong);
     CHECK(tvz_corpus_destroy(corpus));
     return wrong ? 1 : 0;
 }

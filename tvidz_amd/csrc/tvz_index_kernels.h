@@ -289,12 +289,13 @@ inline size_t ix_lds_bytes(int max_len, int spb) {
 // (Profiled with s_memtime stamps, profiles/ix_stamps.py: with block-wide compaction 55 % of a
 // block's cycles were barrier waits.)
 template <bool HOSTOUT, bool TOP5>
-__global__ __launch_bounds__(kIxBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) void ts_match_index_kernel(
+__device__ __forceinline__ void ix_lookup_body(
     const unsigned char *__restrict__ dir, int dir_log2, int ks, const uint16_t *__restrict__ post,
     const int32_t *__restrict__ ivid, int64_t n_indexed, int32_t n_sub, int32_t spb,
     const double *__restrict__ queries, const int64_t *__restrict__ q_offsets, int32_t max_len,
     int32_t min_match, const int32_t *__restrict__ exclude_ids, int32_t exclude_one, int32_t cap,
-    int32_t *__restrict__ hits, int32_t *__restrict__ hits_n, int32_t ns, const QByVal qv) {
+    int32_t *__restrict__ hits, int32_t *__restrict__ hits_n, int32_t ns, const QByVal &qv, const int q,
+    const int group, const int n_groups) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t *bm1 = reinterpret_cast<uint32_t *>(smem);
     uint32_t *bm2 = bm1 + kIxWords;
@@ -312,11 +313,10 @@ __global__ __launch_bounds__(kIxBlock) __attribute__((amdgpu_waves_per_eu(8, 8))
     __shared__ uint32_t s_wb[kIxWaves], s_wc[kIxWaves];
     __shared__ uint32_t s_bcast;
 
-    const int q = blockIdx.x;
-    const int sub_lo = blockIdx.y * spb;
+    const int sub_lo = group * spb;
     const int sub_hi = sub_lo + spb < n_sub ? sub_lo + spb : n_sub;
     const int nsb = (spb + 1) & ~1;
-    const bool alone = gridDim.y == 1;                 // this block owns the query's hit list
+    const bool alone = n_groups == 1;                  // this block owns the query's hit list
     const bool byval = q_offsets == nullptr;
     const int64_t qo = byval ? 0 : q_offsets[q];
     const int64_t n64 = byval ? qv.n : q_offsets[q + 1] - qo;
@@ -704,6 +704,42 @@ __global__ __launch_bounds__(kIxBlock) __attribute__((amdgpu_waves_per_eu(8, 8))
         atomicAdd(&g_ix_stamps[15], 1ull);
     }
 #endif
+}
+
+template <bool HOSTOUT, bool TOP5>
+__global__ __launch_bounds__(kIxBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) void ts_match_index_kernel(
+    const unsigned char *__restrict__ dir, int dir_log2, int ks, const uint16_t *__restrict__ post,
+    const int32_t *__restrict__ ivid, int64_t n_indexed, int32_t n_sub, int32_t spb,
+    const double *__restrict__ queries, const int64_t *__restrict__ q_offsets, int32_t max_len,
+    int32_t min_match, const int32_t *__restrict__ exclude_ids, int32_t exclude_one, int32_t cap,
+    int32_t *__restrict__ hits, int32_t *__restrict__ hits_n, int32_t ns, const QByVal qv) {
+    ix_lookup_body<HOSTOUT, TOP5>(dir, dir_log2, ks, post, ivid, n_indexed, n_sub, spb, queries, q_offsets, max_len,
+                                  min_match, exclude_ids, exclude_one, cap, hits, hits_n, ns, qv, (int)blockIdx.x,
+                                  (int)blockIdx.y, (int)gridDim.y);
+}
+
+// tvz_find_duplicates on an indexed corpus with rows in the delta table - the streaming driver's call:
+// the upload's own row was upserted a moment ago - in ONE launch: blocks [0, n_groups) look the query
+// up in the index (one sub-index group each), the others sweep the delta table with the single-query
+// sweep's body.  Both write to pinned host memory (every block its own region and count), so they
+// share nothing; two launches on one stream cost ~8 us more.
+template <bool TOP5>
+__global__ __launch_bounds__(kIxBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) void ts_find_fused_kernel(
+    const unsigned char *__restrict__ dir, int dir_log2, int ks, const uint16_t *__restrict__ post,
+    const int32_t *__restrict__ ivid, int64_t n_indexed, int32_t n_sub, int32_t spb, int32_t n_groups,
+    const double *__restrict__ queries, const int64_t *__restrict__ q_offsets, int32_t max_len,
+    int32_t min_match, int32_t exclude_one, int32_t *__restrict__ ix_hits, int32_t *__restrict__ ix_hits_n,
+    const Row *__restrict__ delta_rows, int64_t n_delta, const int64_t *__restrict__ keys, int32_t s_log2,
+    HostOut ho, const QByVal qv) {
+    if ((int)blockIdx.x < n_groups)
+        ix_lookup_body<true, TOP5>(dir, dir_log2, ks, post, ivid, n_indexed, n_sub, spb, queries, q_offsets, max_len,
+                                   min_match, nullptr, exclude_one, 0, ix_hits, ix_hits_n, 1, qv, 0, (int)blockIdx.x,
+                                   n_groups);
+    else
+        q1_body<TOP5 ? kQ1ModeTop5 : kQ1ModeM2, true, kIxBlock>(delta_rows, n_delta, keys, queries, q_offsets, min_match,
+                                                               nullptr, exclude_one, 0, nullptr, nullptr, 1, s_log2, ho,
+                                                               qv, (int)blockIdx.x - n_groups,
+                                                               (int)gridDim.x - n_groups, 0);
 }
 
 }  // namespace

@@ -18,6 +18,8 @@
 // Kernels: tvz_match_kernels.h.  No process-global mutable state: the sweep algorithm is a
 // per-call argument and scratch is the caller's workspace.
 #include <algorithm>
+#include <cstdlib>
+#include <ctime>
 #include <atomic>
 #include <condition_variable>
 #include <mutex>
@@ -64,6 +66,8 @@ struct Staging {
 
 
 constexpr int kQ1MaxBlocks = 2048;
+constexpr int kStageGroups = kIxBlock / kGroup;   // row groups of the widest sweep block (the fused lookup's): every
+                                                  // block's hit region rounds up to whole row groups
 constexpr int64_t kQueryStageKeys = kMaxQueryLen + 1;
 constexpr int kRingSlots = 16;                    // pinned upsert payload ring
 constexpr int64_t kRingSlotKeys = 8192;           // 64 KiB each
@@ -109,11 +113,16 @@ struct Index {
     DevBuf<int32_t> dead_rows;        // rows upserted during that build (dead in the new generation)
     hipStream_t bstream = nullptr;    // background builds run here, not on the mutation stream
     hipEvent_t snap_ev = nullptr;
+    hipEvent_t build_ev = nullptr;    // polled by the builder (wait_stream_polling)
     // a background build is running (its thread has released the handle's lock)
     bool building = false;
     std::vector<int64_t> since_snap;  // rows upserted since its snapshot
-    std::vector<Row> swap_entries;    // sources of the swap's two small copies: they live here until the
-    std::vector<int32_t> swap_dead;   // next swap, so the swap needs no synchronisation
+    // PINNED host buffers: a copy to or from pageable memory makes the runtime wait for the stream
+    // while it holds internal locks - a lookup issued meanwhile waited for the whole count pass
+    IxBuildInfo *h_info = nullptr;    // read-back of `info`
+    Row *h_swap_rows = nullptr;       // sources of the swap's two small copies: they stay untouched until
+    int32_t *h_swap_dead = nullptr;   // the next swap, so the swap needs no synchronisation
+    int64_t h_swap_cap = 0;
     std::condition_variable_any cv;   // signalled when it ends
     IndexBuf &now() { return buf[cur]; }
     const IndexBuf &now() const { return buf[cur]; }
@@ -183,9 +192,11 @@ int ensure(DevBuf<T> &b, int64_t need, int64_t keep) {
     int64_t cap = std::max<int64_t>(need, b.cap * 2);
     cap = std::max<int64_t>(cap, 1024);
     T *np = nullptr;
-    if (hipMalloc(&np, (size_t)cap * sizeof(T)) != hipSuccess)
+    if (hipMalloc(&np, (size_t)cap * sizeof(T)) != hipSuccess) {
+        (void)hipGetLastError();                  // not sticky: the next launch check must not report it
         return tvz::fail(TVZ_ERR_NOMEM, "hipMalloc of %lld bytes failed",
                          (long long)(cap * (int64_t)sizeof(T)));
+    }
     if (b.p && keep > 0) {
         const hipError_t e = hipMemcpy(np, b.p, (size_t)keep * sizeof(T), hipMemcpyDeviceToDevice);
         if (e != hipSuccess) {
@@ -312,6 +323,21 @@ int wait_generation_idle(tvz_corpus *c, int gen) {
     return TVZ_OK;
 }
 
+// Wait for `st` without blocking inside the runtime: record an event and poll it.  A thread parked
+// in hipStreamSynchronize for the length of a count pass (~1 ms) held up a lookup that called
+// hipStreamSynchronize on ITS stream meanwhile (tests/rebuild_latency.c: one lookup per rebuild
+// returned right when the builder's wait ended); a query of an event takes no such turn.
+int wait_stream_polling(hipStream_t st, hipEvent_t ev) {
+    TVZ_HIP(hipEventRecord(ev, st));
+    while (true) {
+        const hipError_t e = hipEventQuery(ev);
+        if (e == hipSuccess) return TVZ_OK;
+        if (e != hipErrorNotReady) return tvz::fail(TVZ_ERR_HIP, "index build failed: %s", hipGetErrorString(e));
+        timespec nap = {0, 20 * 1000};
+        nanosleep(&nap, nullptr);
+    }
+}
+
 // Build the index of rows [0, n_rows) of the row table image `d_rows` (keys in c->keys) into
 // generation `b` on stream `st`, and wait for it.  `b` must have no reader; nothing of the handle's
 // published state is touched.  rows_cap / keys_cap: the corpus RESERVATION the buffers are sized
@@ -323,7 +349,6 @@ int build_kernels(tvz_corpus *c, IndexBuf &b, const Row *d_rows, int64_t n_rows,
     if (n_rows == 0 || live_keys >= (int64_t)0xfffffff0LL)
         return tvz::fail(TVZ_ERR_UNSUPPORTED, "corpus of %lld rows / %lld keys gets no index", (long long)n_rows,
                          (long long)live_keys);
-    if (!ix.info) TVZ_HIP(hipMalloc(&ix.info, sizeof(IxBuildInfo)));
     const int n_sub = (int)tvz::ceil_div(n_rows, kSubRows);
     TVZ_REQUIRE(n_sub <= 4096, "too many rows for the index (%lld)", (long long)n_rows);
     const int ks = ix_ks(n_sub), es = ix_entry_bytes(ks);
@@ -357,8 +382,9 @@ int build_kernels(tvz_corpus *c, IndexBuf &b, const Row *d_rows, int64_t n_rows,
         hipLaunchKernelGGL(ix_count_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, st, d_rows, n_rows, c->keys.p,
                            b.dir.p, es, ks, log2, b.ivid.p, ix.info);
         TVZ_HIP(hipGetLastError());
-        TVZ_HIP(hipMemcpyAsync(&info, ix.info, sizeof(info), hipMemcpyDeviceToHost, st));
-        TVZ_HIP(hipStreamSynchronize(st));
+        TVZ_HIP(hipMemcpyAsync(ix.h_info, ix.info, sizeof(info), hipMemcpyDeviceToHost, st));
+        if (int rc = wait_stream_polling(st, ix.build_ev)) return rc;
+        info = *ix.h_info;
         if (!info.failed && (int64_t)info.n_distinct * 2 <= dn) break;
         ++log2;                                       // too crowded: twice the directory
     }
@@ -368,8 +394,9 @@ int build_kernels(tvz_corpus *c, IndexBuf &b, const Row *d_rows, int64_t n_rows,
     hipLaunchKernelGGL(ix_fill_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, st, d_rows, n_rows, c->keys.p, b.dir.p,
                        es, ks, log2, ix.fillc.p, b.post.p);
     TVZ_HIP(hipGetLastError());
-    TVZ_HIP(hipMemcpyAsync(&info, ix.info, sizeof(info), hipMemcpyDeviceToHost, st));
-    TVZ_HIP(hipStreamSynchronize(st));
+    TVZ_HIP(hipMemcpyAsync(ix.h_info, ix.info, sizeof(info), hipMemcpyDeviceToHost, st));
+    if (int rc = wait_stream_polling(st, ix.build_ev)) return rc;
+    info = *ix.h_info;
     if ((int64_t)info.cursor != live_keys)
         return tvz::fail(TVZ_ERR_INVALID, "internal: index holds %u postings for %lld keys", info.cursor,
                          (long long)live_keys);
@@ -400,8 +427,9 @@ int build_index(tvz_corpus *c) {
     // flight would wait for them)
     IndexBuf &o = ix.buf[ix.cur ^ 1];
     const IndexBuf &n = ix.buf[ix.cur];
-    (void)ensure(o.dir, 2 * n.dir.cap, 0);         // room for the directory to double once
-    (void)ensure(ix.fillc, 2 * ix.fillc.cap, 0);
+    const int64_t dir_bytes = ((int64_t)1 << n.dir_log2) * ix_entry_bytes(n.ks);
+    (void)ensure(o.dir, 2 * dir_bytes, 0);         // room for the directory to double once
+    (void)ensure(ix.fillc, 2 * (((int64_t)1 << n.dir_log2) * (n.ks ? n.ks / 2 : 1)), 0);
     (void)ensure(o.post, n.post.cap, 0);
     (void)ensure(o.ivid, n.ivid.cap, 0);
     (void)ensure(o.drows, n.drows.cap, 0);
@@ -423,8 +451,16 @@ void wait_no_build(tvz_corpus *c, std::unique_lock<std::shared_mutex> &lk) {
 // stream, and the swap - a few host operations plus one small copy and one small kernel on the
 // mutation stream - publishes it.  Matches enqueued before the swap finish on the old generation,
 // whose buffers stay untouched until the NEXT rebuild (which first waits for them).
+static bool tvz_debug() { static const bool on = getenv("TVZ_DEBUG") != nullptr; return on; }
+static double tvz_now_us() {
+    timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return ts.tv_sec * 1e6 + ts.tv_nsec * 1e-3;
+}
+
 int rebuild_in_background(tvz_corpus *c, std::unique_lock<std::shared_mutex> &lk) {
     Index &ix = c->ix;
+    const double t_dbg0 = tvz_debug() ? tvz_now_us() : 0.0;
     const int64_t n_snap = (int64_t)c->h_rows.size();
     const int64_t live = c->live_keys, rows_cap = c->rows.cap, keys_cap = c->keys.cap;
     const int shadow = ix.cur ^ 1;
@@ -439,10 +475,16 @@ int rebuild_in_background(tvz_corpus *c, std::unique_lock<std::shared_mutex> &lk
     ix.building = true;
     ix.since_snap.clear();
     lk.unlock();
+    const double t_dbg1 = tvz_debug() ? tvz_now_us() : 0.0;
     int rc = build_kernels(c, ix.buf[shadow], ix.snap_rows.p, n_snap, live, rows_cap, keys_cap, ix.bstream);
     char msg[512];
     if (rc) snprintf(msg, sizeof msg, "%s", tvz::err_buf());
+    const double t_dbg2 = tvz_debug() ? tvz_now_us() : 0.0;
     lk.lock();
+    if (tvz_debug())
+        fprintf(stderr, "[tvz] rebuild: %lld rows, %lld keys, rc %d: locked prologue %.0f us, build (unlocked) %.0f us, "
+                        "relock %.0f us, delta so far %lld\n", (long long)n_snap, (long long)live, rc, t_dbg1 - t_dbg0,
+                t_dbg2 - t_dbg1, tvz_now_us() - t_dbg2, (long long)ix.since_snap.size());
     struct Done { Index &ix; ~Done() { ix.building = false; ix.since_snap.clear(); ix.cv.notify_all(); } } done{ix};
     if (rc) { snprintf(tvz::err_buf(), 512, "%s", msg); return rc; }
     IndexBuf &nb = ix.buf[shadow];
@@ -451,23 +493,20 @@ int rebuild_in_background(tvz_corpus *c, std::unique_lock<std::shared_mutex> &lk
     std::sort(rs.begin(), rs.end());
     rs.erase(std::unique(rs.begin(), rs.end()), rs.end());
     const int64_t d = (int64_t)rs.size();
-    if (d > std::min<int64_t>(nb.drows.cap, delta_capacity(nb.n_main)))
+    if (d > std::min<int64_t>(std::min(nb.drows.cap, ix.h_swap_cap), delta_capacity(nb.n_main)))
         return tvz::fail(TVZ_ERR_UNSUPPORTED, "%lld rows changed while the index was being rebuilt", (long long)d);
     if (d) {
-        std::vector<Row> &entries = ix.swap_entries;
-        std::vector<int32_t> &dead = ix.swap_dead;
-        entries.resize((size_t)d);
-        dead.clear();
+        int64_t n_dead = 0;
         for (int64_t i = 0; i < d; ++i) {
-            entries[(size_t)i] = c->h_rows[(size_t)rs[(size_t)i]];
-            if (rs[(size_t)i] < nb.n_main) dead.push_back((int32_t)rs[(size_t)i]);
+            ix.h_swap_rows[i] = c->h_rows[(size_t)rs[(size_t)i]];
+            if (rs[(size_t)i] < nb.n_main) ix.h_swap_dead[n_dead++] = (int32_t)rs[(size_t)i];
         }
-        TVZ_HIP(hipMemcpyAsync(nb.drows.p, entries.data(), (size_t)d * sizeof(Row), hipMemcpyHostToDevice, c->mstream));
-        if (!dead.empty()) {
-            if (int rc2 = ensure(ix.dead_rows, (int64_t)dead.size(), 0)) return rc2;
-            TVZ_HIP(hipMemcpyAsync(ix.dead_rows.p, dead.data(), dead.size() * 4, hipMemcpyHostToDevice, c->mstream));
-            hipLaunchKernelGGL(ix_mark_dead_kernel, dim3((unsigned)tvz::ceil_div((int64_t)dead.size(), kBlock)),
-                               dim3(kBlock), 0, c->mstream, nb.ivid.p, ix.dead_rows.p, (int32_t)dead.size());
+        TVZ_HIP(hipMemcpyAsync(nb.drows.p, ix.h_swap_rows, (size_t)d * sizeof(Row), hipMemcpyHostToDevice, c->mstream));
+        if (n_dead) {
+            if (int rc2 = ensure(ix.dead_rows, n_dead, 0)) return rc2;
+            TVZ_HIP(hipMemcpyAsync(ix.dead_rows.p, ix.h_swap_dead, (size_t)n_dead * 4, hipMemcpyHostToDevice, c->mstream));
+            hipLaunchKernelGGL(ix_mark_dead_kernel, dim3((unsigned)tvz::ceil_div(n_dead, kBlock)),
+                               dim3(kBlock), 0, c->mstream, nb.ivid.p, ix.dead_rows.p, (int32_t)n_dead);
             TVZ_HIP(hipGetLastError());
         }
         TVZ_HIP(hipEventRecord(c->mut_done, c->mstream));
@@ -499,7 +538,7 @@ void staging_free(Staging *s) {
 
 // room for the hits of `rows` corpus rows (every block's region rounds up to whole row groups)
 int staging_size(Staging *s, int64_t rows) {
-    const int64_t slots = rows + (int64_t)kQ1MaxBlocks * kQ1Groups;
+    const int64_t slots = rows + (int64_t)kQ1MaxBlocks * kStageGroups;
     if (slots <= s->hit_slots) return TVZ_OK;
     if (s->h_hits) (void)hipHostFree(s->h_hits);
     s->h_hits = nullptr;
@@ -575,8 +614,16 @@ int reserve_locked(tvz_corpus *c, int64_t n_rows, int64_t n_keys) {
     c->first_row.reserve((size_t)c->rows.cap);
     c->ix.delta_slot.reserve((size_t)delta_capacity(c->rows.cap));
     c->ix.since_snap.reserve((size_t)delta_capacity(c->rows.cap));
-    c->ix.swap_entries.reserve((size_t)delta_capacity(c->rows.cap));
-    c->ix.swap_dead.reserve((size_t)delta_capacity(c->rows.cap));
+    if (delta_capacity(c->rows.cap) > c->ix.h_swap_cap) {
+        Index &ix = c->ix;
+        if (ix.h_swap_rows) (void)hipHostFree(ix.h_swap_rows);
+        if (ix.h_swap_dead) (void)hipHostFree(ix.h_swap_dead);
+        ix.h_swap_rows = nullptr; ix.h_swap_dead = nullptr; ix.h_swap_cap = 0;
+        const int64_t cap = delta_capacity(c->rows.cap);
+        TVZ_HIP(hipHostMalloc(&ix.h_swap_rows, (size_t)cap * sizeof(Row), hipHostMallocDefault));
+        TVZ_HIP(hipHostMalloc(&ix.h_swap_dead, (size_t)cap * 4, hipHostMallocDefault));
+        ix.h_swap_cap = cap;
+    }
     if (n_rows > c->stage_rows) {
         std::lock_guard<std::mutex> lk(c->stage_mu);
         c->stage_rows = n_rows;
@@ -990,7 +1037,9 @@ static int tvz_corpus_create_impl(tvz_corpus **out, int device) {
         TVZ_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
         TVZ_HIP(hipStreamCreateWithPriority(&c->ix.bstream, hipStreamNonBlocking, least));
         TVZ_HIP(hipEventCreateWithFlags(&c->ix.snap_ev, hipEventDisableTiming));
+        TVZ_HIP(hipEventCreateWithFlags(&c->ix.build_ev, hipEventDisableTiming));
         TVZ_HIP(hipMalloc(&c->ix.info, sizeof(IxBuildInfo)));
+        TVZ_HIP(hipHostMalloc(&c->ix.h_info, sizeof(IxBuildInfo), hipHostMallocDefault));
     }
     for (RingSlot &s : c->ring) {
         TVZ_HIP(hipHostMalloc(&s.h, (size_t)kRingSlotKeys * 8, hipHostMallocDefault));
@@ -1007,6 +1056,10 @@ static int tvz_corpus_create_impl(tvz_corpus **out, int device) {
                                 hipFuncAttributeMaxDynamicSharedMemorySize, kIxMaxLds))
     TVZ_IX_ATTR(false, false); TVZ_IX_ATTR(false, true); TVZ_IX_ATTR(true, false); TVZ_IX_ATTR(true, true);
 #undef TVZ_IX_ATTR
+    TVZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(ts_find_fused_kernel<false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, kIxMaxLds));
+    TVZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(ts_find_fused_kernel<true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, kIxMaxLds));
     const int q1max = (int)q1_lds_bytes(kQ1MaxLog2);
 #define TVZ_Q1_ATTR(M, H)                                                                     \
     TVZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(ts_match_q1_kernel<M, H>),       \
@@ -1020,6 +1073,7 @@ static int tvz_corpus_create_impl(tvz_corpus **out, int device) {
     c->stage_rows = 1 << 16;
     if (int rc = ensure(c->keys, (int64_t)1 << 21, 0)) return rc;
     if (int rc = ensure(c->rows, (int64_t)1 << 16, 0)) return rc;
+    if (int rc = reserve_locked(c, ((int64_t)1 << 16) - 1, ((int64_t)1 << 21) - 2)) return rc;   // host mirrors, pinned buffers
     for (int i = 0; i < 2; ++i) {
         Staging *s = nullptr;
         if (int rc = staging_new(c, &s)) return rc;
@@ -1056,7 +1110,11 @@ static int tvz_corpus_destroy_impl(tvz_corpus *c) {
         if (c->ix.snap_rows.p) (void)hipFree(c->ix.snap_rows.p);
         if (c->ix.dead_rows.p) (void)hipFree(c->ix.dead_rows.p);
         if (c->ix.info) (void)hipFree(c->ix.info);
+        if (c->ix.h_info) (void)hipHostFree(c->ix.h_info);
+        if (c->ix.h_swap_rows) (void)hipHostFree(c->ix.h_swap_rows);
+        if (c->ix.h_swap_dead) (void)hipHostFree(c->ix.h_swap_dead);
         if (c->ix.snap_ev) (void)hipEventDestroy(c->ix.snap_ev);
+        if (c->ix.build_ev) (void)hipEventDestroy(c->ix.build_ev);
         if (c->ix.bstream) (void)hipStreamDestroy(c->ix.bstream);
         for (int i = 0; i < tvz_corpus::kEvents; ++i)
             if (c->events[i]) (void)hipEventDestroy(c->events[i]);
@@ -1194,6 +1252,8 @@ static int tvz_corpus_upsert_impl(tvz_corpus *c, int32_t video_id, const double 
         if (slot_new) { ix.delta_slot.erase(r); --ix.n_delta; }
     };
     if (gc || full) {                  // no background build is running (see above)
+        if (tvz_debug()) fprintf(stderr, "[tvz] upsert slow path: gc %d full %d (arena %lld, live %lld, rows %lld)\n", (int)gc,
+                                 (int)full, (long long)c->h_keys.size(), (long long)c->live_keys, (long long)c->h_rows.size());
         int rc = drain(c);
         if (!rc) rc = gc ? compact(c) : TVZ_OK;
         if (!rc && !gc) rc = upload_all(c, 2 * (int64_t)c->h_rows.size() + 1024,
@@ -1419,7 +1479,7 @@ static int tvz_find_duplicates_impl(tvz_corpus *c, const double *h_query, int64_
                 std::shared_lock<std::shared_mutex> lk(c->mu);
                 const int64_t n_rows = (int64_t)c->h_rows.size();
                 if (n_rows) {
-                    if (n_rows > c->stage_rows || n_rows + (int64_t)kQ1MaxBlocks * kQ1Groups > s->hit_slots ||
+                    if (n_rows > c->stage_rows || n_rows + (int64_t)kQ1MaxBlocks * kStageGroups > s->hit_slots ||
                         n_rows > s->ix_slots) {
                         // the corpus outgrew its reservation (see tvz_corpus_reserve): grow this staging
                         if (int rc = staging_size(s, std::max<int64_t>(2 * n_rows, c->stage_rows))) return rc;
@@ -1430,19 +1490,43 @@ static int tvz_find_duplicates_impl(tvz_corpus *c, const double *h_query, int64_
                     const int64_t *dqo = by_value ? nullptr : s->d_query;
                     RowSpan span{c->rows.p, n_rows};
                     s->busy.store(1, std::memory_order_release);         // drain() waits for this sweep
+                    bool fused = false;
                     if (attempt == 0 && index_usable(c, min_match)) {
                         used_index = true;
-                        n_sub = c->ix.now().n_sub;
+                        const IndexBuf &ib = c->ix.now();
+                        n_sub = ib.n_sub;
                         s->gen = c->ix.cur;
-                        if (int rc = launch_index<true>(c, dq, dqo, 1, (int32_t)n, min_match, nullptr, excl, 0,
-                                                        s->dh_ix_hits, s->dh_counts + kQ1MaxBlocks, 1, s->stream,
-                                                        by_value ? &qv : nullptr)) {
+                        span = RowSpan{ib.drows.p, c->ix.n_delta};
+                        const int s_log2 = q1_slots_log2((int32_t)n);
+                        const size_t lds = std::max(ix_lds_bytes((int32_t)n, 1), q1_lds_bytes(s_log2));
+                        if (span.n && lds <= (size_t)kIxMaxLds) {
+                            // lookup + delta sweep in ONE launch (the streaming driver's call: its own row is
+                            // always in the delta table)
+                            fused = true;
+                            constexpr int kFG = kIxBlock / kGroup;                // row groups per sweep block
+                            blocks = (int)std::max<int64_t>(1, std::min<int64_t>(tvz::ceil_div(span.n, kFG), kQ1MaxBlocks));
+                            region = (int)(tvz::ceil_div(span.n, (int64_t)blocks * kFG) * kFG);
+                            const HostOut ho{s->dh_hits, s->dh_counts, region};
+                            static const QByVal kNoQuery = {};
+#define TVZ_FUSED(TOP5)                                                                                               \
+    hipLaunchKernelGGL((ts_find_fused_kernel<TOP5>), dim3((unsigned)(n_sub + blocks)), dim3(kIxBlock), lds, s->stream, \
+                       ib.dir.p, ib.dir_log2, ib.ks, ib.post.p, ib.ivid.p, ib.n_main, ib.n_sub, 1, n_sub, dq, dqo,       \
+                       (int32_t)n, min_match, excl, s->dh_ix_hits, s->dh_counts + kQ1MaxBlocks, span.p, span.n,         \
+                       c->keys.p, s_log2, ho, by_value ? qv : kNoQuery)
+                            if (min_match <= 2) TVZ_FUSED(false); else TVZ_FUSED(true);
+#undef TVZ_FUSED
+                            if (hipGetLastError() != hipSuccess) {
+                                s->busy.store(0, std::memory_order_release);
+                                return tvz::fail(TVZ_ERR_HIP, "fused lookup launch failed");
+                            }
+                        } else if (int rc = launch_index<true>(c, dq, dqo, 1, (int32_t)n, min_match, nullptr, excl, 0,
+                                                               s->dh_ix_hits, s->dh_counts + kQ1MaxBlocks, 1, s->stream,
+                                                               by_value ? &qv : nullptr)) {
                             s->busy.store(0, std::memory_order_release);
                             return rc;
                         }
-                        span = RowSpan{c->ix.now().drows.p, c->ix.n_delta};
                     }
-                    if (span.n) {
+                    if (span.n && !fused) {
                         blocks = q1_blocks(span.n, 1);
                         region = (int)(tvz::ceil_div(span.n, (int64_t)blocks * kQ1Groups) * kQ1Groups);
                         const HostOut ho{s->dh_hits, s->dh_counts, region};
