@@ -252,3 +252,89 @@ def test_write_behind_coalesces_and_flushes(store):
     assert store.find_duplicates([7.5, 8.5], 2) == [(ext_id, 2)]
     store.clear()
     assert store.sync_if_stale() is False and store.find_duplicates([7.5], 1) == []
+
+
+def _sql_rows(store):
+    s = store.SessionLocal()
+    try:
+        return {r.video_id: r.timestamps for r in s.query(tdb.VideoTimestamps).all()}
+    finally:
+        s.close()
+
+
+def test_write_behind_failure_is_retried_then_raised_once_to_its_owner(store):
+    """A transient SQL error must cost nothing; a persistent one fails only the upload that owns
+    the row (db.py:52-62 commits per call: one failing request, not every later one), exactly once,
+    and the mirror is reloaded from SQL afterwards."""
+    a, b = store.add_video("a.mp4"), store.add_video("b.mp4")
+    real = store._write_timestamps_sql
+    fails = {"n": 1}
+
+    def flaky(session, vid, ts):
+        if fails["n"] > 0:
+            fails["n"] -= 1
+            raise RuntimeError("connection reset")
+        return real(session, vid, ts)
+    store._write_timestamps_sql = flaky
+    store.add_timestamps_async(a.id, [1.0, 2.0])
+    store.flush(a.id)                                   # retried behind the scenes: no error
+    assert _sql_rows(store) == {a.id: [1.0, 2.0]}
+    # three failures in a row = the writer gives up on this batch
+    fails["n"] = store._wb_retries
+    store.add_timestamps_async(b.id, [5.0, 6.0])
+    with pytest.raises(RuntimeError, match="connection reset"):
+        store.flush(b.id)
+    store.flush(b.id)                                   # raised once; not sticky
+    store.flush()
+    assert store._dirty and b.id not in _sql_rows(store)
+    assert (b.id, [5.0, 6.0]) in store.corpus.rows      # the mirror is ahead of SQL ...
+    store.add_timestamps_async(a.id, [1.0, 2.0, 3.0])   # ... and other uploads go on unharmed
+    store.flush(a.id)
+    assert store.sync_if_stale() is True                # ... until the next sync reloads it from SQL
+    assert store.corpus.rows == [(a.id, [1.0, 2.0, 3.0])]
+    # the owner learns about a failed write at its next call too (before the device row is touched)
+    fails["n"] = store._wb_retries
+    store.add_timestamps_async(b.id, [5.0])
+    deadline = time.time() + 10
+    while time.time() < deadline and b.id not in store._wb_errors:
+        time.sleep(0.01)
+    rows_before = list(store.corpus.rows)
+    with pytest.raises(RuntimeError, match="connection reset"):
+        store.add_timestamps_async(b.id, [5.0, 6.0])
+    assert store.corpus.rows == rows_before
+    store.add_timestamps_async(b.id, [5.0, 6.0])
+    store.flush(b.id)
+    assert _sql_rows(store)[b.id] == [5.0, 6.0]
+
+
+def test_upload_error_record_when_sync_fails(store):
+    """sync_if_stale runs inside analyze_file's try: a failure there is the upload's
+    `status: error` record (app.py:303-315), not a worker that died without one."""
+    ins = insp.Inspector(store, device="cuda:0", frame_source=lambda *a: (_ for _ in ()).throw(RuntimeError("no source")))
+
+    def boom(min_interval=0.0):
+        raise RuntimeError("census failed")
+    store.sync_if_stale = boom
+    res = ins.analyze_file("videos", "1700000000-x.mp4")
+    assert res["status"] == "error" and "census failed" in res["error"]
+    assert ins.result_for("x.mp4") is None and any(r["status"] == "error" for r in ins.analysis_results.values())
+    ins.close()
+
+
+def test_sync_replays_rows_of_uploads_that_raced_the_reload(store):
+    """An add_timestamps_async between flush() and reload_corpus() has its HBM row upserted and
+    its SQL write queued; the reload reads a table that does not hold the row yet.  The queued and
+    in-flight rows are replayed into the mirror after the reload."""
+    a = store.add_video("a.mp4")
+    store.add_timestamps(a.id, [1.0, 2.0])
+    b = store.add_video("b.mp4")
+    store.flush = lambda video_id=None: None            # the race: the writer has not committed b yet
+    with store._wb_cv:
+        store._pending[b.id] = [8.0, 9.0]               # queued ...
+        store._inflight = {777: [3.0]}                   # ... and one batch being committed
+    store._dirty = True
+    assert store.sync_if_stale() is True
+    assert sorted(store.corpus.rows) == sorted([(a.id, [1.0, 2.0]), (b.id, [8.0, 9.0]), (777, [3.0])])
+    with store._wb_cv:
+        store._pending.clear()
+        store._inflight = {}

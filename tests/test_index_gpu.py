@@ -309,3 +309,84 @@ def test_index_through_compaction_growth_long_rows_and_duplicate_ids(dc):
     dc.build_index()
     _check(dc, rows, [q, q3], 2)
     _check_single(dc, rows, q3, 2, excl=7)
+
+
+def test_replacing_an_indexed_row_that_is_a_hit_never_hides_it(dc):
+    """add_timestamps (db.py:54-62) on a row that a concurrent find_duplicates is matching: the reader
+    sees the old or the new list (both hold the probe's cuts here), never neither.  The first
+    replacement of an INDEXED row marks its postings dead and gives it a new delta entry; a match in
+    flight captured the old delta size, so it must still find the row through the postings - the dead
+    mark therefore waits (on the device) for the matches enqueued before it."""
+    import threading
+    rng = np.random.default_rng(51)
+    grid = np.arange(1, 20_001) / 10.0
+    probe = rng.choice(grid, size=30, replace=False)
+    rows = [(v, rng.choice(grid, size=12, replace=False).tolist()) for v in range(1, 6001)]
+    X = 4321
+    variants = [probe[:14].tolist() + rows[X - 1][1][:5], probe[:12].tolist() + [5000.5, 5001.5]]
+    rows[X - 1] = (X, variants[0])
+    dc.upload(rows)
+    stop = threading.Event()
+    errs = []
+    seen = {"find": 0, "batch": 0}
+
+    def finder():
+        try:
+            while not stop.is_set():
+                got = dc.find_duplicates(probe, 5)
+                assert [h for h in got if h[0] == X] in ([(X, 14)], [(X, 12)]), got
+                seen["find"] += 1
+        except Exception as e:                                            # pragma: no cover
+            errs.append(e)
+
+    def batcher():
+        try:
+            d_q, d_off, max_len = tc.pack_queries([probe] * 16, DEV)
+            while not stop.is_set():
+                hits, n = dc.match(d_q, d_off, max_len, 5, 64)
+                torch.cuda.synchronize()
+                h, nn = hits.cpu().numpy(), n.cpu().numpy()
+                for qi in range(16):
+                    mine = [tuple(int(x) for x in r[:2]) for r in h[qi, :nn[qi]] if r[0] == X]
+                    assert mine in ([(X, 14)], [(X, 12)]), (qi, mine)
+                seen["batch"] += 1
+        except Exception as e:                                            # pragma: no cover
+            errs.append(e)
+    th = [threading.Thread(target=finder) for _ in range(2)] + [threading.Thread(target=batcher)]
+    [t.start() for t in th]
+    try:
+        for it in range(300):
+            dc.upsert(X, variants[(it + 1) % 2])          # (first one after a build: kills the row's postings)
+            if it % 3 == 2:
+                dc.build_index()                          # the row is indexed again
+    finally:
+        stop.set()
+        [t.join(60) for t in th]
+    assert not errs, errs[:1]
+    assert seen["find"] > 50 and seen["batch"] > 10, seen
+
+
+def test_clear_does_not_disturb_matches_already_queued(dc):
+    """/admin/clear-db (app.py:325-333) while matches are queued: they keep sweeping the rows they
+    were launched with.  The arena is reused from offset 0 by the next add_timestamps, so that copy
+    is ordered (on the device) behind every match enqueued before the clear."""
+    ids, offs, keys = synth.synth_timestamp_corpus(20000, seed=77, mean_len=200)
+    dc.upload_csr(ids, offs, keys)
+    queries = [keys[offs[c]:offs[c + 1]].copy() for c in (0, 1, 2, 3)] * 64     # rows 0..3 are hits of their queries
+    d_q, d_off, max_len = tc.pack_queries(queries, DEV)
+    st = torch.cuda.Stream(DEV)
+    outs = []
+    for _ in range(6):                                    # ~ms of corpus sweeps queued on one stream, not waited for
+        outs.append(dc.match(d_q, d_off, max_len, 5, 64, stream=st, algo=_lib.ALGO_TILE))
+    dc.clear()
+    dc.upsert(999_999, (np.arange(4000) * 0.5 + 9000.0).tolist())               # lands at arena offset 0
+    st.synchronize()
+    torch.cuda.synchronize()
+    for hits, n in outs:
+        h, nn = hits.cpu().numpy(), n.cpu().numpy()
+        for qi in range(len(queries)):
+            c = qi % 4
+            got = sorted(tuple(int(x) for x in r) for r in h[qi, :nn[qi]])
+            assert (int(ids[c]), int(offs[c + 1] - offs[c]), 4) in got, (qi, got[:3])
+    assert dc.find_duplicates(queries[0], 2) == []
+    assert dc.find_duplicates([9000.0, 9000.5, 9001.0], 3) == [(999_999, 3)]

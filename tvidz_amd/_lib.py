@@ -113,6 +113,12 @@ def load() -> C.CDLL:
                 fn = getattr(lib, name)
                 fn.restype = res
                 fn.argtypes = args
+            # A stale library behind a newer binding (or the reverse) shifts arguments silently: round
+            # 2's only host crash (SIGSEGV inside tvz_find_duplicates, gpurun_out/r2_t2.log) was a run
+            # of the ABI-v2 binding against a library built from the half-converted sources.  Refuse.
+            if lib.tvz_version() != VERSION:
+                raise RuntimeError(f"{SO_PATH} is version {lib.tvz_version()}, this binding expects {VERSION}: "
+                                   "rebuild it (python -m tvidz_amd.build --force)")
             _lib = lib
     return _lib
 

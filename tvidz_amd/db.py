@@ -99,11 +99,15 @@ class Store:
         self._dirty = False
         # write-behind of the growing cut prefixes (add_timestamps_async): latest list per video
         self._pending = {}
-        self._inflight = set()
+        self._inflight = {}              # the batch the writer thread is committing: video_id -> list
         self._wb_cv = threading.Condition()
-        self._wb_error = None
+        self._wb_errors = {}             # video_id -> exception of its failed write, raised ONCE to its owner
+        self._wb_retries = 3
         self._wb_stop = False
         self._wb_thread = None
+        # HBM row + queued SQL write of add_timestamps_async happen as one step with respect to a
+        # reload of the mirror (sync_if_stale): a reload in between would drop the HBM row for good
+        self._mirror_lock = threading.RLock()
         self.reload_corpus()
 
     # -- device mirror -------------------------------------------------------
@@ -124,9 +128,11 @@ class Store:
 
     def sync_if_stale(self, min_interval: float = 0.0) -> bool:
         """Reload the mirror if `video_timestamps` gained or lost rows that this process did not
-        write (another worker, plain SQL), or if a device upsert failed after its SQL commit.
+        write (another worker, plain SQL), or if a device upsert or a write-behind commit failed.
         `min_interval` > 0 skips the census when one ran less than that many seconds ago (the
-        driver asks once per upload; a burst of uploads shares one census)."""
+        driver asks once per upload; a burst of uploads shares one census).  Raises what flush()
+        raises (a failed write-behind of some upload, once); the reload is then done by the next
+        call."""
         from sqlalchemy import func
         import time as _time
         now = _time.monotonic()
@@ -142,8 +148,16 @@ class Store:
             stale = self._dirty or (int(cnt or 0), int(mx or 0)) != self._census
         if stale:
             self.flush()                    # our own write-behind first: its rows must be in SQL
-            with self._write_lock:
-                self.reload_corpus()
+            with self._mirror_lock:         # no add_timestamps_async between the reload and the replay
+                with self._write_lock:
+                    self.reload_corpus()
+                # uploads that raced the flush: their rows are queued for SQL (or being committed) but
+                # were not in the table the reload read - put them back into the mirror
+                with self._wb_cv:
+                    replay = dict(self._inflight)
+                    replay.update(self._pending)
+                for vid, ts in replay.items():
+                    self.corpus.upsert(int(vid), ts)
         return stale
 
     # -- reference API -------------------------------------------------------
@@ -202,31 +216,49 @@ class Store:
         the SQL row is written behind by one writer thread that coalesces the growing prefixes of
         a video (only the latest list matters: db.py:58 overwrites the row) and commits many
         videos per transaction.  flush(video_id) before reporting the upload `done` makes the
-        final table state identical to the reference's per-cut commits."""
+        final table state identical to the reference's per-cut commits.
+        A failed commit is retried with back-off; if it keeps failing the error is raised ONCE, to
+        the upload that owns the row (here or in its flush) - as the reference's per-call commit
+        (db.py:52-62) fails only the request it belongs to - and the mirror is reloaded from SQL
+        on the next sync_if_stale."""
         ts = [float(x) for x in timestamps]
-        self.corpus.upsert(int(video_id), ts)
+        vid = int(video_id)
         with self._wb_cv:
-            if self._wb_error is not None:
-                raise self._wb_error
-            self._pending[int(video_id)] = ts
-            if self._wb_thread is None:
-                self._wb_thread = threading.Thread(target=self._write_behind, name="tvz-sql-writer", daemon=True)
-                self._wb_thread.start()
-            self._wb_cv.notify_all()
+            err = self._wb_errors.pop(vid, None)
+        if err is not None:                 # before the device row: the mirror gets nothing SQL will not hold
+            raise err
+        with self._mirror_lock:
+            self.corpus.upsert(vid, ts)
+            with self._wb_cv:
+                self._pending[vid] = ts
+                if self._wb_thread is None:
+                    self._wb_thread = threading.Thread(target=self._write_behind, name="tvz-sql-writer", daemon=True)
+                    self._wb_thread.start()
+                self._wb_cv.notify_all()
 
     def flush(self, video_id=None) -> None:
-        """Block until the write-behind has committed `video_id` (or everything)."""
+        """Block until the write-behind has committed `video_id` (or everything).  Raises the
+        error of a write that could not be committed - once: flush(video_id) the error of that
+        video, flush() the first error there is (and forgets the others: their uploads are gone)."""
         with self._wb_cv:
             while True:
-                if self._wb_error is not None:
-                    raise self._wb_error
-                busy = (self._pending or self._inflight) if video_id is None else \
-                    (int(video_id) in self._pending or int(video_id) in self._inflight)
+                if video_id is None:
+                    busy = bool(self._pending or self._inflight)
+                else:
+                    busy = int(video_id) in self._pending or int(video_id) in self._inflight
                 if not busy:
+                    if video_id is not None:
+                        err = self._wb_errors.pop(int(video_id), None)
+                    else:
+                        err = next(iter(self._wb_errors.values()), None)
+                        self._wb_errors.clear()
+                    if err is not None:
+                        raise err
                     return
                 self._wb_cv.wait(timeout=0.5)
 
     def _write_behind(self) -> None:
+        import time as _time
         while True:
             with self._wb_cv:
                 while not self._pending and not self._wb_stop:
@@ -234,22 +266,32 @@ class Store:
                 if self._wb_stop and not self._pending:
                     return
                 batch, self._pending = self._pending, {}
-                self._inflight = set(batch)
-            try:
-                with self._write_lock:
-                    session = self.SessionLocal()
-                    try:
-                        for vid, ts in batch.items():
-                            self._write_timestamps_sql(session, vid, ts)
-                        session.commit()
-                    finally:
-                        session.close()
-            except Exception as e:          # surfaced by the next add_timestamps_async / flush
-                self._dirty = True
-                with self._wb_cv:
-                    self._wb_error = e
+                self._inflight = batch
+            error = None
+            for attempt in range(self._wb_retries):
+                try:
+                    with self._write_lock:
+                        session = self.SessionLocal()
+                        try:
+                            for vid, ts in batch.items():
+                                self._write_timestamps_sql(session, vid, ts)
+                            session.commit()
+                        finally:
+                            session.close()
+                    error = None
+                    break
+                except Exception as e:      # a transient SQL / connection error: back off and retry
+                    error = e
+                    _time.sleep(0.05 * (attempt + 1))
             with self._wb_cv:
-                self._inflight = set()
+                if error is not None:
+                    # given up: every video of the batch that has no newer list queued gets the error
+                    # (raised once, to its owner); the mirror may hold rows SQL does not - reload
+                    self._dirty = True
+                    for vid in batch:
+                        if vid not in self._pending:
+                            self._wb_errors[vid] = error
+                self._inflight = {}
                 self._wb_cv.notify_all()
 
     def update_duplicates(self, video_id, duplicate_ids):       # db.py:66-74

@@ -152,18 +152,20 @@ class Inspector:
         with self.analysis_lock:
             self.analysis_results.pop(analysis_key, None)
         t = time.perf_counter()
-        if hasattr(self.store, "sync_if_stale"):
-            self.store.sync_if_stale(min_interval=1.0)   # rows written by another process since our last look
-        t = self._phase("sync_census", t)
-        video = self.store.add_video(original_filename)                    # app.py:150
-        t = self._phase("add_video", t)
-        video_id = video.id
-        self._set(analysis_key, {"status": "analyzing", "scene_cuts": [], "progress": 0.0,
-                                 "total_cuts": 0, "duplicates": [], "original_filename": filename,
-                                 "clean_filename": original_filename})
         local_path = None
         reader = None
         try:
+            # inside the try: a failure here is this upload's `status: error` (app.py:303), not a
+            # dead worker with no record
+            if hasattr(self.store, "sync_if_stale"):
+                self.store.sync_if_stale(min_interval=1.0)   # rows written by another process since our last look
+            t = self._phase("sync_census", t)
+            video = self.store.add_video(original_filename)                # app.py:150
+            t = self._phase("add_video", t)
+            video_id = video.id
+            self._set(analysis_key, {"status": "analyzing", "scene_cuts": [], "progress": 0.0,
+                                     "total_cuts": 0, "duplicates": [], "original_filename": filename,
+                                     "clean_filename": original_filename})
             reader, local_path = self.frame_source(bucket, key, filename, unique_id)
             t = self._phase("open_source", t)
             scene_timestamps, dups_to_report = self._run(analysis_key, video_id, reader)
