@@ -98,7 +98,12 @@ def _sse_last(client, key):
     return events
 
 
-def test_64_concurrent_4k_uploads_through_notify_and_sse(tmp_path):
+@pytest.mark.parametrize("n_shards", [0, 8])
+def test_64_concurrent_4k_uploads_through_notify_and_sse(tmp_path, n_shards):
+    """n_shards = 0: one corpus handle (one GPU owns the table).  n_shards = 8: configs[4] as
+    written - the table in 8 shards (service.ShardedCorpus: eight handles on this one GPU stand for
+    the eight GPUs), every upload's per-micro-batch ask answered by the tick-batched sharded match
+    (per-shard index lookup + top-k, merge).  Same records either way."""
     rng = np.random.default_rng(2026)
     n_lib, n_uniq, n_copy, n_twin = 6, 40, 16, 4
     sets = _cut_sets(n_lib + n_uniq + n_twin, rng)
@@ -138,7 +143,11 @@ def test_64_concurrent_4k_uploads_through_notify_and_sse(tmp_path):
     for k, src in copy_of.items():
         expected[k] = expected[src]
 
-    store = tdb.Store(f"sqlite:///{tmp_path}/tvidz.db", device=0)
+    sharded_corpus = None
+    if n_shards:
+        from tvidz_amd import service
+        sharded_corpus = service.ShardedCorpus(0, n_shards=n_shards, k=16)
+    store = tdb.Store(f"sqlite:///{tmp_path}/tvidz.db", device=0, corpus=sharded_corpus)
     ins = insp.Inspector(store, device=DEV, max_workers=64,
                          frame_source=lambda bucket, key, filename, uid: (SynthReader(*videos[key]), None))
     app = insp.create_app(ins, sse_period=0.01)
@@ -223,6 +232,12 @@ def test_64_concurrent_4k_uploads_through_notify_and_sse(tmp_path):
             last = _sse_last(client, k)[-1]
             assert last["status"] == "done" and last["duplicates"] == [clean[k0]]
             assert last["scene_cuts"] == expected[k0][:2]
+        if n_shards:
+            # the asks went through the tick: batched across uploads (fewer ticks than asks), rows spread
+            # over the shards by who ingested them
+            b = sharded_corpus.batcher
+            assert b.asks >= 64 and b.ticks < b.asks, (b.ticks, b.asks)
+            assert sum(1 for s_ in sharded_corpus.shards if s_.stats()[0] > 0) == n_shards
     finally:
         ins.close()
         store.close()

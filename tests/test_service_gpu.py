@@ -1,0 +1,54 @@
+"""service.ShardedCorpus on the GPU: eight shard handles on one device, asks batched on a tick,
+per-shard index lookup + top-k, merge - against the oracle over the whole table."""
+import threading
+
+import numpy as np
+import pytest
+
+from oracle import oracle
+from tvidz_amd import service, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def test_sharded_corpus_answers_like_the_whole_table():
+    ids, offs, keys = synth.synth_timestamp_corpus(6000, seed=21, mean_len=60, dup_frac=0.03, frag_frac=0.03)
+    table = [(int(ids[c]), keys[offs[c]:offs[c + 1]].tolist()) for c in range(len(ids))]
+    sc = service.ShardedCorpus(0, n_shards=8, k=8)
+    try:
+        sc.upload(table)
+        assert sc.stats()[0] == len(table) and all(s.stats()[0] > 0 for s in sc.shards)
+        queries = synth.synth_queries(ids, offs, keys, 48, seed=4, mean_len=60)
+        errs = []
+
+        def ask(qi):
+            try:
+                q = queries[qi]
+                excl = int(ids[(5 * qi) % len(ids)])
+                oid, cnt, kth = oracle.match_kth(table, list(q), 2)
+                exp = sorted((int(oid[c]), int(cnt[c]), int(kth[c])) for c in range(len(table))
+                             if cnt[c] >= 2 and oid[c] != excl)
+                assert sc.find_duplicates(q, 2, exclude_id=excl) == [(v, c) for v, c, _ in exp]      # db.find_duplicates
+                got = sc.find_duplicates(q, 2, exclude_id=excl, with_kth=True)                       # the driver's ask
+                kstar = min((h[2] for h in exp), default=None)
+                assert sorted(h[0] for h in got if h[2] == kstar) == sorted(h[0] for h in exp if h[2] == kstar), qi
+                assert set(got) <= set(exp)
+            except Exception as e:                                        # pragma: no cover
+                errs.append(repr(e))
+        th = [threading.Thread(target=ask, args=(qi,)) for qi in range(48)]
+        [t.start() for t in th]
+        [t.join(120) for t in th]
+        assert not errs, errs[:2]
+        assert sc.batcher.asks == 48 and sc.batcher.ticks <= 48
+        # add_timestamps lands in one shard and is seen by the next ask; a tie set larger than k falls
+        # back to the exact per-shard path
+        ts = [9000.5 + i for i in range(6)]
+        for v in range(70000, 70020):                     # 20 videos with the same two first cuts: 20 ties at kth 1
+            sc.upsert(v, ts)
+        got = sc.find_duplicates(ts[:3], 2, exclude_id=70000, with_kth=True)
+        assert sorted(h[0] for h in got) == list(range(70001, 70020)) and all(h[2] == 1 for h in got)
+        assert sc.exact_asks >= 1
+        sc.clear()
+        assert sc.stats()[0] == 0 and sc.find_duplicates(ts, 1) == []
+    finally:
+        sc.close()

@@ -14,61 +14,10 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 from oracle import oracle
+from tests.fakes import OracleBackend
 from tvidz_amd import sharded, synth
 
 NEVER = sharded.KTH_NEVER
-
-
-class OracleBackend:
-    """Test stand-in for sharded.HipBackend (same method shapes, CPU tensors)."""
-
-    def __init__(self, ids, offs, keys):
-        self.ids, self.offs, self.keys = ids, offs, keys
-
-    def match(self, d_q, d_off, max_len, min_match, cap, d_excl):
-        q_all, off = d_q.numpy(), d_off.numpy()
-        Q = len(off) - 1
-        hits = torch.zeros((Q, cap, 3), dtype=torch.int32)
-        n = torch.zeros(Q, dtype=torch.int32)
-        for qi in range(Q):
-            q = q_all[off[qi]:off[qi + 1]]
-            cnt, kth = oracle.match_kth_csr(q, self.offs, self.keys, min_match)
-            rows = [(int(self.ids[c]), int(cnt[c]), int(kth[c])) for c in range(len(self.ids))
-                    if cnt[c] >= min_match and (d_excl is None or self.ids[c] != int(d_excl[qi]))]
-            rows = rows[::-1]  # unspecified order, like the atomic appends of the HIP kernel
-            n[qi] = len(rows)
-            for j, r in enumerate(rows[:cap]):
-                hits[qi, j] = torch.tensor(r, dtype=torch.int32)
-        return hits, n
-
-    @staticmethod
-    def _best(ent, k):
-        ent = sorted(ent, key=lambda h: (h[2], h[0], h[1]))[:k]
-        return ent + [(-1, 0, NEVER)] * (k - len(ent))
-
-    def topk_shard(self, hits, hits_n, k):
-        Q, cap, _ = hits.shape
-        out = torch.empty((Q, k + 1, 3), dtype=torch.int32)
-        for q in range(Q):
-            m = min(int(hits_n[q]), cap)
-            ent = [tuple(int(x) for x in e) for e in hits[q, :m]]
-            n = int(hits_n[q])
-            out[q] = torch.tensor(self._best(ent, k) + [(-1, -n if n > cap else n, NEVER)], dtype=torch.int32)
-        return out
-
-    def topk_merge(self, gathered, k):
-        R, Q, k1, _ = gathered.shape
-        out = torch.empty((Q, k, 3), dtype=torch.int32)
-        totals = torch.zeros(Q, dtype=torch.int32)
-        for q in range(Q):
-            ent = []
-            for r in range(R):
-                ent += [tuple(int(x) for x in e) for e in gathered[r, q, :k] if int(e[0]) >= 0]
-                totals[q] += abs(int(gathered[r, q, k, 1]))
-            if any(int(gathered[r, q, k, 1]) < 0 for r in range(R)):
-                totals[q] = -totals[q]
-            out[q] = torch.tensor(self._best(ent, k), dtype=torch.int32)
-        return out, totals
 
 
 def _expected(ids, offs, keys, queries, mm, k, excl=None):
