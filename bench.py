@@ -57,6 +57,7 @@ def parse():
     ap.add_argument("--match-steps", type=int, default=20)
     ap.add_argument("--no-match", action="store_true")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the bounded driver run (16 x 256 1080p uploads)")
     ap.add_argument("--cpu-frames", type=int, default=1536)
     ap.add_argument("--cpu-threads", type=int, default=0)
     return ap.parse_args()
@@ -254,23 +255,52 @@ def bench_match(args, rank, world, dev):
            "hit_list_capacity": CAP, "queries_with_overflowed_shard_lists": n_over,
            "scaling": "strong (the same corpus is sharded over the ranks)",
            "match_ms_per_batch_rank0": index_ms, "sweep_ms_per_batch_rank0": sweep_ms,
-           "predicted_scaling": "profiles/r2_predicted_scaling.json (single-GPU shard timings)"}
+           "predicted_scaling": "profiles/r3_predicted_scaling.json (single-GPU shard timings; no multi-GPU box was available)"}
     tag = f"C{C}_Q{Q}"
     # ---- roofline of the kernel the batch spends its time in: the index lookup ----
-    alg_ix = postings * 2.0 + len(qk) * n_sub * 16.0 + len(qk) * 8.0 * n_sub + n_hits * 12.0
+    # algorithmic bytes: every posting of the query's keys once (2 B), ONE directory entry
+    # (16 B head + 2 B per sub-index, rounded up to 8 sub-indexes; 16 B on a one-sub-index shard) and the
+    # 8-byte query key per query element, 12 B per hit
+    def ix_alg_bytes(n_sub_, postings_, n_hits_):
+        entry = 16 + (0 if n_sub_ <= 1 else 2 * ((n_sub_ + 7) // 8 * 8))
+        return postings_ * 2.0 + len(qk) * (entry + 8.0) + n_hits_ * 12.0, entry
+    alg_ix, entry_bytes = ix_alg_bytes(n_sub, postings, n_hits)
+    t_ix, t_src = pmc_traffic("ts_match_index", tag=tag + "_index") if world == 1 else (None, None)
     out["roofline"] = {
         "bound": "hbm",
-        "kernel": "ts_match_index_kernel (the event pair also covers ts_prep and the counter gather, < 2 % of it)",
+        "kernel": "ts_match_index_kernel (the event pair also covers the counter gather, < 2 % of it)",
         "achieved": alg_ix / (index_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": alg_ix / (index_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-        "traffic": pmc_traffic("ts_match_index", tag=tag + "_index") if world == 1 else None,
+        "traffic": t_ix, "traffic_source": t_src,
         "algorithmic_bytes_per_launch": alg_ix, "avg_launch_ms": index_ms,
-        "algorithmic_bytes": f"{postings} postings x 2 B + one 16 B directory entry and one 8 B query key per (query "
-                             f"element, sub-index) ({len(qk)} x {n_sub}) + {n_hits} hits x 12 B",
-        "limiter": "not HBM bandwidth: a block is a chain of dependent accesses (query offsets -> keys -> directory "
-                   "-> postings -> video ids -> hit list) with LDS-atomic counting in between; random 16 B directory "
-                   "probes and short posting lists fetch whole lines, so `traffic` (FETCH_SIZE x2 + WRITE_SIZE of "
-                   "the committed PMC pass) is ~3x the algorithmic bytes (profiles/r2_match_pmc.txt)"}
+        "algorithmic_bytes": f"{postings} postings x 2 B + one {entry_bytes} B directory entry and one 8 B query key per "
+                             f"query element ({len(qk)}) + {n_hits} hits x 12 B",
+        "limiter": "not HBM bandwidth: instruction issue and LDS latency inside a block (one block per query walks "
+                   "its sub-indexes: per sub-index ~300 postings per wave through two LDS passes and five block "
+                   "barriers); s_memtime stamps in profiles/r3_ix_stamps.txt, counters in profiles/r3_match_pmc.txt"}
+    # ---- the same batch against rank 0's share of an 8-way sharded corpus: what every GPU of configs[3] runs ----
+    if world == 1:
+        s8 = sharded.shard_csr(ids, offs, keys, 0, 8)
+        dc8 = tc.DeviceCorpus(dev.index)
+        dc8.upload_csr(*s8)
+        ms8 = kernel_ms(lambda: dc8.match(d_q, d_off, max_len, 2, CAP, out_hits=hits, out_n=n_h, stream=st,
+                                          workspace=ws), st)
+        hits8 = int(n_h.clamp(min=0).sum().item())
+        uk8, uc8 = np.unique(s8[2].view(np.int64), return_counts=True)
+        pos8 = np.searchsorted(uk8, qk)
+        pos8[pos8 >= len(uk8)] = 0
+        post8 = int(uc8[pos8][uk8[pos8] == qk].sum())
+        rows8 = dc8.stats()[0]
+        alg8, entry8 = ix_alg_bytes(-(-rows8 // 16384), post8, hits8)
+        t8, t8_src = pmc_traffic("ts_match_index", tag=f"C{rows8}_Q{Q}")
+        out["shard8_roofline"] = {
+            "bound": "hbm", "kernel": f"ts_match_index_kernel on rank 0's 1/8 shard ({rows8} rows), the same {Q} queries",
+            "achieved": alg8 / (ms8 * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": alg8 / (ms8 * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": t8, "traffic_source": t8_src,
+            "algorithmic_bytes_per_launch": alg8, "avg_launch_ms": ms8,
+            "limiter": "the per-query fixed chain (offsets -> keys -> directory probe -> postings) that does not "
+                       "shrink with the shard: 40 % of a block's cycles are the probe phase (profiles/r3_ix_stamps.txt)"}
+        dc8.close()
     # ---- the same batch forced onto the corpus sweep (what AUTO runs without an index) ----
     alg = corpus_bytes * n_tiles + n_hits * 12.0
     out["sweep"] = {
@@ -282,7 +312,8 @@ def bench_match(args, rank, world, dev):
             "achieved": alg / (sweep_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": alg / (sweep_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
             # the committed counter pass averages per LAUNCH; a batch is one launch per tile
-            "traffic": (lambda t: t * n_tiles if t else None)(pmc_traffic("ts_match_join", tag=tag)) if world == 1 else None,
+            "traffic": (lambda t: t[0] * n_tiles if t[0] else None)(pmc_traffic("ts_match_join", tag=tag)) if world == 1 else None,
+            "traffic_source": pmc_traffic("ts_match_join", tag=tag)[1] if world == 1 else None,
             "algorithmic_bytes_per_launch": alg, "avg_launch_ms": sweep_ms,
             "limiter": "not HBM: the sweep streams this rank's corpus image once per tile (16 B row entry + 8 B per "
                        "key) and is bound by the probe rate of the 2 MiB fingerprint table (one random 16 B bucket "
@@ -347,12 +378,125 @@ def bench_match_q1(args, dev, Q):
                                  "achieved": image / (q1_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                  "frac": image / (q1_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                  "frac_min_match5": image / (q1_mm5 * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                 "traffic": pmc_traffic("ts_match_q1", tag=f"C{C5}_Q1")}}
+                                 "traffic": pmc_traffic("ts_match_q1", tag=f"C{C5}_Q1")[0],
+                                 "traffic_source": pmc_traffic("ts_match_q1", tag=f"C{C5}_Q1")[1]}}
         if C5 == 5000 and not args.no_cpu:
             entry["cpu_baseline"] = cpu_baseline_match(ids5, offs5, keys5, q5)
         res[f"c{C5}"] = entry
         dc5.close()
     return res
+
+
+def bench_config0(dev, n_threads: int = 0):
+    """BASELINE.json configs[0] / BASELINE.md section 3: the reference's own CPU-runnable case - two
+    10 s 480p30 clips (854x480, 300 frames each; clip B = the same scenes with every cut shifted by 7
+    frames), scene cuts + timestamp compare.  The reference's ffmpeg is not available, so the CPU
+    figures are the oracle port (1 core and all cores) and its two matcher restatements; beside them
+    the same two clips through the HIP path."""
+    from oracle import oracle  # checker / CPU baseline only
+    n_threads = n_threads or min(os.cpu_count() or 1, 16)
+    T0, H0, W0 = 300, 480, 854
+    a, _ = synth.synth_luma(T0 + 7, H0, W0, device=dev, seed=77, min_scene=40, max_scene=70, adversarial=False)
+    clips = [a[7:].contiguous(), a[:T0].contiguous()]      # B: the same content 7 frames later
+    host = [c.cpu().numpy() for c in clips]
+    res = {"workload": "2 clips x 300 frames of 854x480 luma (10 s at 30 fps), clip B cut-shifted by 7 frames"}
+    cuts = []
+    for cores in (1, n_threads):
+        bounds = np.linspace(0, T0, cores + 1).astype(int)
+        out = np.zeros(T0, dtype=np.uint64)
+        t0, passes = time.perf_counter(), 0
+        with ThreadPoolExecutor(cores) as ex:
+            while time.perf_counter() - t0 < 1.0:
+                cuts = []
+                for h in host:
+                    list(ex.map(lambda i: oracle.luma_sad_range(h, int(bounds[i]), int(bounds[i + 1]), out), range(cores)))
+                    sel, _, _, _ = oracle.scene_select(out, H0, W0, 0.3)
+                    cuts.append([oracle.pts_time_value(int(i), 1, 30, 0) for i in np.flatnonzero(sel)])
+                passes += 1
+        dt = time.perf_counter() - t0
+        res[f"cpu_scene_{cores}_core" + ("s" if cores > 1 else "")] = {
+            "value": passes * 2 * T0 / dt, "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": f"oracle luma SAD + select + pts_time, {passes} passes over the two clips, {dt:.2f} s"}
+    # compare: clip B's fingerprint against a table holding clip A (db.py:85-91), min_match 2 (app.py:235)
+    table = [(1, cuts[0])]
+    t0, n = time.perf_counter(), 0
+    while time.perf_counter() - t0 < 0.3:
+        v_py = oracle.find_duplicates_py(table, cuts[1], 2)
+        n += 1
+    py_us = (time.perf_counter() - t0) / n * 1e6
+    t0, n = time.perf_counter(), 0
+    while time.perf_counter() - t0 < 0.3:
+        v_c = oracle.find_duplicates_c(table, cuts[1], 2)
+        n += 1
+    c_us = (time.perf_counter() - t0) / n * 1e6
+    res["cpu_compare"] = {"python_restatement_us": round(py_us, 2), "c_restatement_us": round(c_us, 2), "cores": 1,
+                          "kind": "port", "verdict": v_py, "note": "a uniformly cut-shifted copy shares no exact timestamp "
+                          "with the original: NOT a duplicate for the reference (db.py:79 exact match), nor here"}
+    assert v_py == v_c
+    # the same through the HIP path (frames resident in HBM)
+    dc = tc.DeviceCorpus(dev.index)
+    g_cuts = []
+    torch.cuda.synchronize()
+    t0, passes = time.perf_counter(), 0
+    while time.perf_counter() - t0 < 0.5:
+        g_cuts = [[ts for _, ts in scene.detect_scene_cuts(c, time_base=(1, 30), batch=T0)] for c in clips]
+        passes += 1
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    dc.upsert(1, g_cuts[0])
+    lat = []
+    for _ in range(200):
+        t1 = time.perf_counter()
+        v_g = dc.find_duplicates(g_cuts[1], 2)
+        lat.append(time.perf_counter() - t1)
+    dc.close()
+    res["gpu"] = {"scene_frames_per_s": passes * 2 * T0 / dt, "compare_us": round(float(np.median(lat)) * 1e6, 2),
+                  "verdict": v_g, "cuts_equal_cpu": g_cuts == cuts,
+                  "note": "detect_scene_cuts on two 300-frame clips, one micro-batch each (launch + one D2H per clip: "
+                          "a 123 MB clip is latency-bound, not HBM-bound) + tvz_find_duplicates through Python"}
+    return res
+
+
+def bench_e2e(dev, n_uploads: int = 8, n_frames: int = 256):
+    """A bounded run of the whole driver (BASELINE.json configs[4]'s shape at 1080p): N concurrent
+    uploads as mono Y4M files in RAM -> reader threads -> pinned slot pool -> H2D -> scene kernels ->
+    one match per micro-batch -> write-behind SQL.  PCIe-inclusive; never part of `value`.  The 16 /
+    64-upload and 4K figures are in profiles/r3_e2e_service.txt (profiles/e2e_service.py)."""
+    import shutil
+    import tempfile
+    from tvidz_amd import db as tdb, feeder, inspector as insp
+    need = n_uploads * n_frames * FRAME_BYTES * 1.2
+    root = "/dev/shm" if os.path.isdir("/dev/shm") and shutil.disk_usage("/dev/shm").free > need else None
+    tmp = tempfile.mkdtemp(prefix="tvz_bench_e2e_", dir=root)
+    try:
+        files = {}
+        for i in range(n_uploads):
+            fr, _ = synth.synth_luma(n_frames, H, W, device=dev, seed=300 + i, min_scene=20, max_scene=90)
+            name = f"17000000{i:02d}-clip{i}.y4m"
+            files[name] = os.path.join(tmp, name)
+            feeder.write_y4m(files[name], fr.cpu().numpy(), fps=(30, 1), chroma="mono")
+            del fr
+        store = tdb.Store(f"sqlite:///{tmp}/tvidz.db", device=dev.index)
+        ids, offs, keys = synth.synth_timestamp_corpus(5000, seed=1)
+        store.corpus.upload_csr(ids + 100000, offs, keys)
+        ins = insp.Inspector(store, device=str(dev), frame_source=lambda b, k, f, u: (feeder.Y4MReader(files[k]), None),
+                             batch=256, max_workers=n_uploads)
+        [f.result() for f in [ins.submit("videos", k) for k in files]]          # warm-up: slots, scorers, SQL
+        store.clear()
+        store.corpus.upload_csr(ids + 100000, offs, keys)
+        t0 = time.perf_counter()
+        res = [f.result() for f in [ins.submit("videos", k) for k in files]]
+        dt = time.perf_counter() - t0
+        ok = all(r["status"] == "done" for r in res)
+        ins.close()
+        store.close()
+        return {"value": n_uploads * n_frames / dt, "unit": "frames/s", "uploads": n_uploads, "frames_per_upload": n_frames,
+                "height": H, "width": W, "all_done": ok, "GBps_luma": n_uploads * n_frames * FRAME_BYTES / dt / 1e9,
+                "note": "whole Python driver, PCIe-inclusive, files in RAM, no decoder; short clips: per-upload set-up "
+                        "(SQL insert, reader thread, first slot) is inside the wall time.  profiles/r3_e2e_service.txt: "
+                        "16 / 64 uploads x 512 frames 26-27 k fps (the 27.6 k H2D bound), 64 x 4K ~6 k fps"}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 def h2d_cost(dev, n_frames: int = 256):
@@ -372,23 +516,27 @@ def h2d_cost(dev, n_frames: int = 256):
 
 
 def pmc_traffic(kernel: str, T: int = 0, tag: str = ""):
-    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/*_pmc_summary.json:
-    FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE).  Scene kernel: valid for the default T
-    only; matcher kernels: looked up under their workload tag (e.g. "C100000_Q1024")."""
+    """(HBM bytes per launch, provenance) from the COMMITTED rocprofv3 PMC passes
+    (profiles/*_pmc_summary.json: FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE) - counters
+    cannot be collected inside this run; the newest committed pass that has the kernel wins.  Scene
+    kernel: valid for the default T only; matcher kernels: looked up under their workload tag
+    (e.g. "C100000_Q4096_index")."""
     import glob
-    best = None
+    best, src = None, None
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json"))):
         try:
             d = json.load(open(f))
+            e = None
             if tag:
                 e = d.get(tag, {}).get(kernel)
-                if e:
-                    best = e.get("hbm_read_bytes_corrected", 0) + e.get("hbm_write_bytes", 0)
             elif d.get("_frames_per_launch", 10000) == T and kernel in d:
-                best = d[kernel].get("hbm_read_bytes_corrected", 0) + d[kernel].get("hbm_write_bytes", 0)
+                e = d[kernel]
+            if e:
+                best = e.get("hbm_read_bytes_corrected", 0) + e.get("hbm_write_bytes", 0)
+                src = f"committed counter pass profiles/{os.path.basename(f)} (not measured in this run)"
         except Exception:
             pass
-    return best
+    return best, src
 
 
 def main():
@@ -426,7 +574,8 @@ def main():
                    "parallelism": f"{world} independent video batches (no collective)"},
         "cuts_detected_per_step": res["n_cuts"],
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic("luma_sad", T),
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic("luma_sad", T)[0],
+                     "traffic_source": pmc_traffic("luma_sad", T)[1],
                      "kernel": "luma_sad_flat_kernel<8,nt> (event pair also covers scene_finalize_kernel, <1% of the step)",
                      "algorithmic_bytes_per_launch": (T - 1) * FRAME_BYTES,
                      "avg_launch_ms": kern_ms, "median_launch_ms": float(np.median(res["step_ms"])),
@@ -447,6 +596,14 @@ def main():
         out["cpu_baseline"] = None
     del res
     torch.cuda.empty_cache()
+    if rank == 0 and world == 1 and not args.no_cpu:
+        out["config0"] = bench_config0(dev, args.cpu_threads)
+    if rank == 0 and world == 1 and not args.no_e2e:
+        try:
+            out["e2e"] = bench_e2e(dev)
+        except Exception as e:            # the driver needs SQLAlchemy + a writable temp directory: report, don't die
+            out["e2e"] = {"error": repr(e)}
+        torch.cuda.empty_cache()
     if not args.no_match:
         m = bench_match(args, rank, world, dev)
         out["match"] = m

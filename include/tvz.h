@@ -310,6 +310,26 @@ int tvz_match_sharded(tvz_corpus *c, tvz_comm *comm, const double *d_queries,
 int tvz_align(tvz_corpus *c, const double *d_query, int32_t n, double eps, double max_offset,
               int32_t *d_out, void *hip_stream);
 
+/* ------------------------------------------------------------------------
+ * Frame feeder I/O - the host side of what replaces the stderr pipe of
+ * inspector/app.py:209-216: a micro-batch of luma planes from a file or a decoder pipe into the
+ * caller's (pinned) buffer in one call, no per-frame host-language loop.
+ * ------------------------------------------------------------------------ */
+
+/* n_records fixed-size records from a seekable file (positioned reads: the descriptor's offset is not
+ * used): record i starts at file_offset + i*record_bytes = [header_bytes header][payload_bytes payload]
+ * [rest skipped].  YUV4MPEG2: header "FRAME\n", payload = the Y plane, rest = chroma.  `magic`
+ * (nullable): header_bytes bytes every header must equal.  *n_done = whole records read (fewer at end
+ * of file). */
+int tvz_read_records(int fd, int64_t file_offset, int64_t n_records, int64_t record_bytes,
+                     const void *magic, int64_t header_bytes, int64_t payload_bytes, void *h_dst,
+                     int64_t *n_done);
+
+/* The same from a pipe (`ffmpeg -f rawvideo -`): payload_bytes are kept, the following skip_bytes
+ * (chroma planes) are read and dropped. */
+int tvz_read_stream(int fd, int64_t n_records, int64_t payload_bytes, int64_t skip_bytes, void *h_dst,
+                    int64_t *n_done);
+
 #ifdef __cplusplus
 }
 #endif

@@ -3,7 +3,9 @@
 driver): N distinct synthetic 1080p clips as mono Y4M files in RAM -> Inspector.submit (Y4M reader
 -> pinned ring -> H2D -> HIP scene kernels -> HIP corpus match per micro-batch -> SQL upserts).
 No decoder in the loop (the host-side ffmpeg decode is outside the hot path); PCIe-inclusive.
-   python profiles/e2e_service.py [n_uploads] [frames_per_clip] [workers]"""
+   python profiles/e2e_service.py [n_uploads] [frames_per_clip] [workers] [batch] [slot_MiB] [switch] [H] [W] [shards]
+H W default to 1080p; 2160 3840 = configs[4]'s 4K uploads.  shards > 0: the table in that many shards
+(service.ShardedCorpus), every ask through the tick-batched sharded match."""
 import json
 import os
 import shutil
@@ -25,7 +27,9 @@ SLOT_MB = int(sys.argv[5]) if len(sys.argv) > 5 else 64
 SWITCH = float(sys.argv[6]) if len(sys.argv) > 6 else 0.0
 if SWITCH > 0:
     sys.setswitchinterval(SWITCH)
-H, W = 1080, 1920
+H = int(sys.argv[7]) if len(sys.argv) > 7 else 1080
+W = int(sys.argv[8]) if len(sys.argv) > 8 else 1920
+SHARDS = int(sys.argv[9]) if len(sys.argv) > 9 else 0
 root = "/dev/shm" if os.path.isdir("/dev/shm") and shutil.disk_usage("/dev/shm").free > (N * T * H * W * 1.2) else None
 tmp = tempfile.mkdtemp(prefix="tvz_e2e_", dir=root)
 try:
@@ -36,9 +40,14 @@ try:
         files[name] = os.path.join(tmp, name)
         feeder.write_y4m(files[name], frames.cpu().numpy(), fps=(30, 1), chroma="mono")
         del frames
-    store = tdb.Store(f"sqlite:///{tmp}/tvidz.db", device=0)
+    corpus = None
+    if SHARDS:
+        from tvidz_amd import service
+        corpus = service.ShardedCorpus(0, n_shards=SHARDS, k=16)
+    store = tdb.Store(f"sqlite:///{tmp}/tvidz.db", device=0, corpus=corpus)
     ids, offs, keys = synth.synth_timestamp_corpus(5000, seed=1)
-    store.corpus.upload_csr(ids + 100000, offs, keys)     # a 5k-video corpus to match against
+    lib_rows = [(int(ids[c]) + 100000, keys[offs[c]:offs[c + 1]].tolist()) for c in range(len(ids))]
+    store.corpus.upload(lib_rows)                         # a 5k-video corpus to match against
 
     def source(bucket, key, filename, unique_id):
         return feeder.Y4MReader(files[key]), None
@@ -48,7 +57,7 @@ try:
     # warm-up pass: a long-running service has its pinned/device slots cached by the allocators
     [f.result() for f in [ins.submit("videos", k) for k in files]]
     store.clear()
-    store.corpus.upload_csr(ids + 100000, offs, keys)
+    store.corpus.upload(lib_rows)
     ins.phase_seconds.clear()
     t0 = time.perf_counter()
     futs = [ins.submit("videos", k) for k in files]
@@ -56,7 +65,7 @@ try:
     dt = time.perf_counter() - t0
     assert all(r["status"] == "done" for r in res), [r.get("error") for r in res]
     frames_done = sum(round(r["scene_cuts"][-1] * 30) if r["duplicates"] else T for r in res)
-    print(json.dumps({"uploads": N, "frames_per_clip": T, "workers": WORKERS, "batch": BATCH, "wall_s": round(dt, 3),
+    print(json.dumps({"uploads": N, "frames_per_clip": T, "height": H, "width": W, "shards": SHARDS, "workers": WORKERS, "batch": BATCH, "wall_s": round(dt, 3),
                       "frames_per_s": round(N * T / dt), "GBps_luma": round(N * T * H * W / dt / 1e9, 2),
                       "slot_MiB": SLOT_MB, "switch_interval": sys.getswitchinterval(),
                       "cuts_total": sum(r["total_cuts"] for r in res), "dups_total": sum(len(r["duplicates"]) for r in res),

@@ -2,6 +2,7 @@
 schema and upsert rule as inspector/db.py) and the Flask routes (same cases as the reference's
 inspector/test_app.py:6-64).  The device corpus is replaced by tests/fakes.OracleCorpus."""
 import json
+import os
 import threading
 import time
 
@@ -338,3 +339,38 @@ def test_sync_replays_rows_of_uploads_that_raced_the_reload(store):
     with store._wb_cv:
         store._pending.clear()
         store._inflight = {}
+
+
+def test_native_span_reads_skip_chroma_and_stop_at_partial_records(tmp_path):
+    """tvz_read_records behind Y4MReader.read_into: a micro-batch per call, Y planes only (4:2:0
+    chroma skipped by the record stride), the count of WHOLE frames at the end of a truncated file,
+    a loud error on a corrupt FRAME header."""
+    rng = np.random.default_rng(5)
+    luma = rng.integers(0, 256, size=(7, 18, 34), dtype=np.uint8)
+    path = str(tmp_path / "c.y4m")
+    feeder.write_y4m(path, luma, fps=(25, 1), chroma="420jpeg")
+    r = feeder.Y4MReader(path)
+    assert r._span_at is not None and r.total_frames == 7 and r.time_base == (1, 25)
+    out = np.zeros((4, 18, 34), dtype=np.uint8)
+    assert r.read_into(out) == 4 and (out == luma[:4]).all()
+    assert r.read_into(out) == 3 and (out[:3] == luma[4:]).all()
+    assert r.read_into(out) == 0
+    r.close()
+    assert [f.tolist() for f in feeder.Y4MReader(path)] == [f.tolist() for f in luma]      # iteration uses it too
+    size = os.path.getsize(path)
+    with open(path, "r+b") as f:
+        f.truncate(size - 10)                             # the last record loses part of its chroma: still 7 Y planes
+    with open(path, "r+b") as f:
+        f.truncate(size - (2 * 17 * 9 + 5))               # ... and now part of its Y plane: 6 frames
+    r = feeder.Y4MReader(path)
+    big = np.zeros((16, 18, 34), dtype=np.uint8)
+    assert r.read_into(big) == 6 and (big[:6] == luma[:6]).all()
+    r.close()
+    with open(path, "r+b") as f:
+        hdr = f.readline()
+        f.seek(len(hdr) + (6 + 18 * 34 + 2 * 17 * 9))     # second record's header
+        f.write(b"FRAMX\n")
+    r = feeder.Y4MReader(path)
+    with pytest.raises(RuntimeError, match="expected header"):
+        r.read_into(big)
+    r.close()

@@ -63,6 +63,9 @@ SIGNATURES = {
     "tvz_match_sharded": (C.c_int, [_P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, _P, C.c_int32,
                                     C.c_int32, _P, _P, _P, C.c_size_t, C.c_int32, _P]),
     "tvz_align": (C.c_int, [_P, _P, C.c_int32, C.c_double, C.c_double, _P, _P]),
+    "tvz_read_records": (C.c_int, [C.c_int, C.c_int64, C.c_int64, C.c_int64, _P, C.c_int64, C.c_int64, _P,
+                                   C.POINTER(C.c_int64)]),
+    "tvz_read_stream": (C.c_int, [C.c_int, C.c_int64, C.c_int64, C.c_int64, _P, C.POINTER(C.c_int64)]),
 }
 
 # per-call selectors of include/tvz.h

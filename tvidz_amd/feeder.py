@@ -27,8 +27,12 @@ import subprocess
 import threading
 from typing import Iterator, Optional, Tuple
 
+import ctypes as C
+
 import numpy as np
 import torch
+
+from . import _lib
 
 
 def _chroma_bytes(tag: str, W: int, H: int) -> int:
@@ -87,8 +91,29 @@ class Y4MReader:
         if self._own:
             size = os.path.getsize(src) - len(header)
             self.total_frames = size // (6 + self._luma + self._skip)
+        # A real file whose frames carry the plain 6-byte "FRAME\n" header is read a micro-batch at a
+        # time by the library (tvz_read_records: positioned reads straight into the caller's pinned
+        # buffer, no interpreter lock held, no per-frame Python).  Anything else (a pipe, a BytesIO,
+        # FRAME headers with parameters) keeps the per-frame loop.
+        self._span_at = None
+        try:
+            fd = self.f.fileno()
+            if self.f.seekable():
+                at = self.f.tell()
+                first = os.pread(fd, 6, at)
+                if first in (b"FRAME\n", b""):
+                    self._span_at, self._fd = at, fd
+        except (AttributeError, OSError, io.UnsupportedOperation):
+            pass
 
     def __iter__(self) -> Iterator[np.ndarray]:
+        if self._span_at is not None:
+            dt = np.uint8 if self.bps == 1 else np.dtype("<u2")
+            while True:
+                one = np.empty((1, self.H, self.W), dtype=dt)
+                if self.read_into(one) == 0:
+                    return
+                yield one[0]
         while True:
             line = self.f.readline()
             if not line:
@@ -105,6 +130,13 @@ class Y4MReader:
     def read_into(self, out: np.ndarray) -> int:
         """Fill out[n,H,W] (uint8, or a 16-bit dtype for high bit depth) with up to n frames;
         returns how many were read."""
+        if self._span_at is not None and out.flags["C_CONTIGUOUS"]:
+            done = C.c_int64(0)
+            rec = 6 + self._luma + self._skip
+            _lib.check(_lib.load().tvz_read_records(self._fd, self._span_at, out.shape[0], rec, b"FRAME\n", 6,
+                                                    self._luma, C.c_void_p(out.ctypes.data), C.byref(done)))
+            self._span_at += done.value * rec
+            return int(done.value)
         n = 0
         flat = out.reshape(out.shape[0], -1).view(np.uint8)
         while n < out.shape[0]:
@@ -204,9 +236,11 @@ class FFmpegReader:
             self.total_frames = self._count_frames(path)
         self._luma = self.W * self.H * self.bps
         self._skip = _chroma_bytes(chroma, self.W, self.H) * self.bps
+        # bufsize=0: the pipe is read by the library straight from the descriptor (tvz_read_stream),
+        # nothing may sit in a Python-side buffer
         self.proc = subprocess.Popen([self.ffmpeg, "-v", "error", "-i", path] + self._sync_flags() +
                                      ["-f", "rawvideo", "-pix_fmt", self.pix_fmt, "-"],
-                                     stdout=subprocess.PIPE)
+                                     stdout=subprocess.PIPE, bufsize=0)
         self.f = self.proc.stdout
 
     def _sync_flags(self):
@@ -253,6 +287,12 @@ class FFmpegReader:
         return self._pts[n] if n < len(self._pts) else int(n)
 
     def read_into(self, out: np.ndarray) -> int:
+        if out.flags["C_CONTIGUOUS"]:
+            # one call per micro-batch: Y planes kept, chroma read and dropped, no interpreter lock held
+            done = C.c_int64(0)
+            _lib.check(_lib.load().tvz_read_stream(self.f.fileno(), out.shape[0], self._luma, self._skip,
+                                                   C.c_void_p(out.ctypes.data), C.byref(done)))
+            return int(done.value)
         n = 0
         flat = out.reshape(out.shape[0], -1).view(np.uint8)
         while n < out.shape[0]:
