@@ -541,6 +541,12 @@ def pmc_traffic(kernel: str, T: int = 0, tag: str = ""):
 
 def main():
     args = parse()
+    # ONE JSON line on stdout, nothing else: native libraries print there too (RCCL's version banner at
+    # communicator creation), so everything written to descriptor 1 during the run goes to stderr and the
+    # result line is written to the real stdout at the end
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -611,7 +617,8 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
 
 
 if __name__ == "__main__":

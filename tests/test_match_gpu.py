@@ -139,7 +139,7 @@ def test_ragged_rows_and_long_queries(dc):
 
 def test_queries_longer_than_a_tile(dc):
     """find_duplicates has no length limit (the reference has none): > 4095 timestamps take the
-    sorted-query path; the batched tvz_match keeps the documented 4095 limit."""
+    sorted-query path (batches: test_batches_with_queries_longer_than_a_tile)."""
     rng = np.random.default_rng(77)
     rows = []
     for v in range(300):
@@ -155,9 +155,70 @@ def test_queries_longer_than_a_tile(dc):
             exp = sorted((int(ids[c]), int(cnt[c]), int(kth[c])) for c in range(len(ids))
                          if cnt[c] >= mm and ids[c] != 5)
             assert dc.find_duplicates(q, mm, exclude_id=5, with_kth=True) == exp, (n, mm)
-    d_q, d_off, max_len = tc.pack_queries([np.arange(5000, dtype=np.float64)], DEV)
-    with pytest.raises(RuntimeError, match="exceeds the supported"):
-        dc.match(d_q, d_off, max_len, 1, 8)
+
+
+def test_batches_with_queries_longer_than_a_tile(dc):
+    """db.py:87 puts no limit on len(new_timestamps), and neither do the batched calls: queries of
+    4096 and 12000 timestamps in one batch with short, empty and exactly-4095 ones - every algorithm
+    choice for the short ones, exclusions, min_match below / inside / above the index's range,
+    an empty and a non-empty delta table, the hit lists and the per-shard top-k block."""
+    rng = np.random.default_rng(78)
+    rows = []
+    for v in range(400):
+        L = int(rng.choice([0, 1, 5, 40, 300, 2000]))
+        rows.append((v + 1, np.round(rng.uniform(0, 2000, L), 1).tolist()))
+    dc.upload(rows)
+    lens = (4096, 50, 12000, 0, 4095, 300, 4097, 7)
+    queries = [np.round(rng.uniform(0, 2000, n), 1) for n in lens]
+    queries[0][10:14] = [np.nan, -0.0, 0.0, queries[0][9]]
+    queries[5] = np.asarray((rows[40][1] + rows[41][1] + rows[42][1])[:300], dtype=np.float64)
+    excl = [5, 6, 7, 8, 9, 41, 11, 12]
+    d_q, d_off, max_len = tc.pack_queries(queries, DEV)
+    d_ex = torch.tensor(excl, dtype=torch.int32, device=DEV)
+
+    def expected(rows_, mm):                              # the oracle once per (table, min_match)
+        ids, offs, keys = tc.rows_to_csr(rows_)
+        out = []
+        for q in queries:
+            cnt, kth = oracle.match_kth_csr(np.asarray(q, dtype=np.float64), offs, keys, mm)
+            out.append([(int(ids[c]), int(cnt[c]), int(kth[c])) for c in range(len(ids)) if cnt[c] >= mm])
+        return out
+
+    def check(exp, mm, algo, use_excl, cap):
+        hits, n = dc.match(d_q, d_off, max_len, mm, cap, d_exclude_ids=d_ex if use_excl else None, algo=algo)
+        torch.cuda.synchronize()
+        hits, n = hits.cpu().numpy(), n.cpu().numpy()
+        for qi in range(len(queries)):
+            e = sorted(h for h in exp[qi] if not use_excl or h[0] != excl[qi])
+            assert n[qi] == len(e), (mm, algo, qi, int(n[qi]), len(e))
+            got = sorted(tuple(int(x) for x in h) for h in hits[qi, :min(n[qi], cap)])
+            assert (got == e) if n[qi] <= cap else (len(got) == cap and set(got) <= set(e)), (mm, algo, qi)
+    for mm in (0, 1, 2, 5, 7):
+        exp = expected(rows, mm)
+        for algo in (_lib.ALGO_AUTO, _lib.ALGO_TILE, _lib.ALGO_JOIN, _lib.ALGO_Q1) + ((_lib.ALGO_INDEX,) if 1 <= mm <= 5 else ()):
+            check(exp, mm, algo, False, len(rows))
+            check(exp, mm, algo, True, 40)
+    # rows replaced / added since the index build (delta table) are found by the long queries too
+    rows2 = list(rows)
+    rows2[3] = (rows[3][0], queries[2][100:160].tolist())
+    rows2.append((999_001, queries[0][:50].tolist()))
+    dc.upsert(rows2[3][0], rows2[3][1])
+    dc.upsert(999_001, rows2[-1][1])
+    for mm in (2, 6):
+        exp = expected(rows2, mm)
+        check(exp, mm, _lib.ALGO_AUTO, False, len(rows2))
+        check(exp, mm, _lib.ALGO_TILE, True, len(rows2))
+    # per-shard top-k block over such a batch
+    K = 8
+    exp = expected(rows2, 2)
+    blk = dc.match_topk(d_q, d_off, max_len, 2, len(rows2), K)
+    torch.cuda.synchronize()
+    blk = blk.cpu().numpy()
+    for qi in range(len(queries)):
+        e = sorted(exp[qi], key=lambda h: (h[2], h[0], h[1]))
+        want = e[:K] + [(-1, 0, tc.KTH_NEVER)] * (K - min(K, len(e)))
+        assert [tuple(int(x) for x in r) for r in blk[qi, :K]] == want, qi
+        assert int(blk[qi, K, 1]) == len(e)
 
 
 def test_hit_list_overflow_reports_true_count(dc):

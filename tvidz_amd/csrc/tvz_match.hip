@@ -674,6 +674,7 @@ WsLayout ws_layout(void *base, int32_t Q, int32_t max_query_len, int32_t cap, in
     WsLayout w;
     uintptr_t p = (reinterpret_cast<uintptr_t>(base) + 255) & ~(uintptr_t)255;
     const uintptr_t p0 = p;
+    if (max_query_len > kMaxQueryLen) max_query_len = kMaxQueryLen;   // longer queries do not use the tables
     w.join_bytes = join_shape(Q, max_query_len).bytes();
     w.join = reinterpret_cast<unsigned char *>(p);
     p += al256(w.join_bytes);
@@ -890,14 +891,125 @@ int launch_index(tvz_corpus *c, const double *d_queries, const int64_t *d_q_offs
     return TVZ_OK;
 }
 
+int launch_match_short(tvz_corpus *c, const double *d_queries, const int64_t *d_q_offsets, int32_t Q,
+                       int32_t max_query_len, int32_t min_match, const int32_t *d_exclude_ids,
+                       int32_t cap, int32_t *d_hits, int32_t *d_hits_n, int32_t ns, unsigned char *ws,
+                       size_t ws_bytes, int32_t algo, hipStream_t st);
+
+// sorted distinct canonical keys + multiplicities of one query (what ts_match_longq_kernel searches)
+void sorted_distinct(const double *q, int64_t n, std::vector<int64_t> &uq, std::vector<int32_t> &mult) {
+    std::vector<int64_t> sk;
+    sk.reserve((size_t)n);
+    for (int64_t i = 0; i < n; ++i) {
+        int64_t k;
+        if (canon_key(q[i], k)) sk.push_back(k);
+    }
+    std::sort(sk.begin(), sk.end());
+    uq.clear();
+    mult.clear();
+    for (size_t i = 0; i < sk.size(); ++i) {
+        if (!uq.empty() && uq.back() == sk[i]) ++mult.back();
+        else { uq.push_back(sk[i]); mult.push_back(1); }
+    }
+}
+
+// db.py:87 has no limit on the length of new_timestamps.  A batch that holds queries of more than
+// 4095 timestamps (a video with thousands of cuts: rare) takes this detour: the host reads the
+// offsets back - the one place a batched call synchronises and allocates - the short queries go
+// the normal way (which marks the long ones INT32_MIN), and every long query is then swept on its
+// own: its sorted distinct keys + multiplicities are searched per row key (ts_match_longq_kernel),
+// kth resolved by the fix-up walk - the path tvz_find_duplicates takes for such a query.
+int launch_match_with_long(tvz_corpus *c, const double *d_queries, const int64_t *d_q_offsets, int32_t Q,
+                           int32_t min_match, const int32_t *d_exclude_ids, int32_t cap, int32_t *d_hits,
+                           int32_t *d_hits_n, int32_t ns, unsigned char *ws, size_t ws_bytes, int32_t algo,
+                           hipStream_t st) {
+    std::vector<int64_t> h_off((size_t)Q + 1);
+    std::vector<int32_t> h_ex;
+    TVZ_HIP(hipMemcpyAsync(h_off.data(), d_q_offsets, ((size_t)Q + 1) * 8, hipMemcpyDeviceToHost, st));
+    if (d_exclude_ids) {
+        h_ex.resize((size_t)Q);
+        TVZ_HIP(hipMemcpyAsync(h_ex.data(), d_exclude_ids, (size_t)Q * 4, hipMemcpyDeviceToHost, st));
+    }
+    TVZ_HIP(hipStreamSynchronize(st));
+    int64_t short_max = 0, long_keys = 0, long_distinct_bound = 0;
+    std::vector<int32_t> longs;
+    for (int32_t q = 0; q < Q; ++q) {
+        const int64_t n = h_off[(size_t)q + 1] - h_off[(size_t)q];
+        TVZ_REQUIRE(n >= 0 && n <= INT32_MAX, "query %d has a bad length", q);
+        if (n > kMaxQueryLen) { longs.push_back(q); long_keys = std::max(long_keys, n); long_distinct_bound += n + 1; }
+        else short_max = std::max(short_max, n);
+    }
+    if (int rc = launch_match_short(c, d_queries, d_q_offsets, Q, (int32_t)short_max, min_match, d_exclude_ids, cap,
+                                    d_hits, d_hits_n, ns, ws, ws_bytes, algo, st))
+        return rc;
+    if (longs.empty()) return TVZ_OK;
+    const int64_t n_rows = (int64_t)c->h_rows.size();
+    int64_t *d_sq = nullptr;
+    int32_t *d_mult = nullptr;
+    TVZ_HIP(hipMalloc(&d_sq, (size_t)long_distinct_bound * 8));
+    if (hipMalloc(&d_mult, (size_t)long_distinct_bound * 4) != hipSuccess) {
+        (void)hipGetLastError();
+        (void)hipFree(d_sq);
+        return tvz::fail(TVZ_ERR_NOMEM, "scratch for the long queries of a batch");
+    }
+    struct Free { int64_t *a; int32_t *b; ~Free() { (void)hipFree(a); (void)hipFree(b); } } fr{d_sq, d_mult};
+    std::vector<double> hq((size_t)long_keys);
+    std::vector<int64_t> uq;
+    std::vector<int32_t> mult;
+    int64_t at = 0;
+    for (int32_t q : longs) {
+        const int64_t n = h_off[(size_t)q + 1] - h_off[(size_t)q];
+        TVZ_HIP(hipMemcpyAsync(hq.data(), d_queries + h_off[(size_t)q], (size_t)n * 8, hipMemcpyDeviceToHost, st));
+        TVZ_HIP(hipStreamSynchronize(st));
+        sorted_distinct(hq.data(), n, uq, mult);
+        const int64_t m = (int64_t)uq.size();
+        int32_t *cnt = d_hits_n + (size_t)q * ns;
+        int32_t *hl = d_hits + (int64_t)q * cap * 3;
+        if (int rc = launch_prep(cnt, ns, 1, nullptr, 0, nullptr, 0, st)) return rc;    // un-poison: 0 hits so far
+        if (m && n_rows) {
+            TVZ_HIP(hipMemcpyAsync(d_sq + at, uq.data(), (size_t)m * 8, hipMemcpyHostToDevice, st));
+            TVZ_HIP(hipMemcpyAsync(d_mult + at, mult.data(), (size_t)m * 4, hipMemcpyHostToDevice, st));
+            TVZ_HIP(hipStreamSynchronize(st));                 // uq / mult are reused by the next long query
+            hipLaunchKernelGGL(ts_match_longq_kernel, dim3((unsigned)tvz::ceil_div(n_rows, kGroupsPerBlock)), dim3(kBlock),
+                               0, st, c->rows.p, n_rows, c->keys.p, d_sq + at, d_mult + at, (int32_t)m, min_match,
+                               d_exclude_ids ? h_ex[(size_t)q] : -1, cap, hl, cnt);
+            TVZ_HIP(hipGetLastError());
+            if (min_match > 0) {
+                hipLaunchKernelGGL(ts_kth_fixup_kernel, dim3(1), dim3(kBlock), 0, st, c->rows.p, c->keys.p, d_queries,
+                                   d_q_offsets + q, min_match, cap, hl, cnt, ns);
+                TVZ_HIP(hipGetLastError());
+            }
+        } else if (min_match <= 0 && n_rows) {
+            // every row is a hit with count 0 (db.py:90: 0 >= min_match): the sweep with an empty query
+            hipLaunchKernelGGL(ts_match_longq_kernel, dim3((unsigned)tvz::ceil_div(n_rows, kGroupsPerBlock)), dim3(kBlock),
+                               0, st, c->rows.p, n_rows, c->keys.p, d_sq, d_mult, 0, min_match,
+                               d_exclude_ids ? h_ex[(size_t)q] : -1, cap, hl, cnt);
+            TVZ_HIP(hipGetLastError());
+        }
+        at += m;
+    }
+    TVZ_HIP(hipStreamSynchronize(st));                         // the scratch is freed on return
+    return TVZ_OK;
+}
+
 int launch_match(tvz_corpus *c, const double *d_queries, const int64_t *d_q_offsets, int32_t Q,
                  int32_t max_query_len, int32_t min_match, const int32_t *d_exclude_ids,
                  int32_t cap, int32_t *d_hits, int32_t *d_hits_n, int32_t ns, unsigned char *ws,
                  size_t ws_bytes, int32_t algo, hipStream_t st) {
-    if (max_query_len > kMaxQueryLen)
-        return tvz::fail(TVZ_ERR_UNSUPPORTED, "query of %d timestamps exceeds the supported %d",
-                         max_query_len, kMaxQueryLen);
     TVZ_REQUIRE(algo >= TVZ_ALGO_AUTO && algo <= TVZ_ALGO_INDEX, "unknown algo %d", algo);
+    if (max_query_len > kMaxQueryLen) {
+        if (int rc = wait_mutations(c, st)) return rc;
+        return launch_match_with_long(c, d_queries, d_q_offsets, Q, min_match, d_exclude_ids, cap, d_hits, d_hits_n,
+                                      ns, ws, ws_bytes, algo, st);
+    }
+    return launch_match_short(c, d_queries, d_q_offsets, Q, max_query_len, min_match, d_exclude_ids, cap, d_hits,
+                              d_hits_n, ns, ws, ws_bytes, algo, st);
+}
+
+int launch_match_short(tvz_corpus *c, const double *d_queries, const int64_t *d_q_offsets, int32_t Q,
+                       int32_t max_query_len, int32_t min_match, const int32_t *d_exclude_ids,
+                       int32_t cap, int32_t *d_hits, int32_t *d_hits_n, int32_t ns, unsigned char *ws,
+                       size_t ws_bytes, int32_t algo, hipStream_t st) {
     if (int rc = wait_mutations(c, st)) return rc;
     RowSpan span{c->rows.p, (int64_t)c->h_rows.size()};
     bool zero_counts = true;
@@ -1631,7 +1743,7 @@ static int tvz_find_duplicates_impl(tvz_corpus *c, const double *h_query, int64_
                 if (longq) {
                     hipLaunchKernelGGL(ts_match_longq_kernel, dim3((unsigned)tvz::ceil_div(n_rows, kGroupsPerBlock)),
                                        dim3(kBlock), 0, s->stream, c->rows.p, n_rows, c->keys.p, s->d_sq,
-                                       s->d_smult, (int32_t)uq.size(), min_match, (int32_t)want, s->d_hits,
+                                       s->d_smult, (int32_t)uq.size(), min_match, -1, (int32_t)want, s->d_hits,
                                        s->d_hits_n);
                     TVZ_HIP(hipGetLastError());
                 } else {

@@ -188,6 +188,7 @@ __global__ __launch_bounds__(kTileBlock) void ts_match_tile_kernel(
     unsigned long long *top = reinterpret_cast<unsigned long long *>(epack + kTileMaxEntries);
     uint32_t *cnt = reinterpret_cast<uint32_t *>(top + kTileGroups * kTileQ);
     __shared__ int64_t s_qoff[kTileQ + 1];
+    __shared__ int32_t s_cbase[kTileQ + 1];   // first table entry of query ql; -1: longer than a tile can hold
 
     const int q0 = blockIdx.y * nq_tile;
     const int nq = (Q - q0 < nq_tile) ? Q - q0 : nq_tile;
@@ -199,19 +200,36 @@ __global__ __launch_bounds__(kTileBlock) void ts_match_tile_kernel(
     }
     __syncthreads();
     const int64_t qbase = s_qoff[0];
-    if (s_qoff[nq] - qbase > kTileMaxEntries) {
+    // A query of more than 4095 timestamps is not this kernel's (the batched calls sweep such a query
+    // on its own, tvz_match.hip launch_match_with_long): it gets no table entries and its counter is
+    // marked; the other queries of the tile are matched as usual.
+    if (threadIdx.x == 0) {
+        int32_t c = 0;
+        for (int ql = 0; ql < nq; ++ql) {
+            const int64_t len = s_qoff[ql + 1] - s_qoff[ql];
+            s_cbase[ql] = len <= kMaxQueryLen ? c : -1;
+            if (len <= kMaxQueryLen) c += (int32_t)len;
+        }
+        s_cbase[nq] = c;
+    }
+    __syncthreads();
+    if (threadIdx.x < nq && s_cbase[threadIdx.x] < 0) hits_n[(size_t)(q0 + threadIdx.x) * ns] = INT32_MIN;
+    if (s_cbase[nq] > kTileMaxEntries) {
         // the caller's max_query_len was not an upper bound: poison the affected counters instead
         // of returning silently truncated matches (every row chunk of this tile takes this exit)
         if (threadIdx.x < nq) hits_n[(size_t)(q0 + threadIdx.x) * ns] = INT32_MIN;
         return;
     }
-    const int total = (int)(s_qoff[nq] - qbase);
-    for (int e = threadIdx.x; e < total; e += kTileBlock) {
+    // (keys of skipped long queries are walked over: a tile has at most 16 queries, such a query is rare)
+    const int64_t total = s_qoff[nq] - qbase;
+    for (int64_t ee = threadIdx.x; ee < total; ee += kTileBlock) {
         int ql = 0;
-        while (ql + 1 < nq && s_qoff[ql + 1] - qbase <= e) ++ql;
-        const uint32_t pos = (uint32_t)(e - (int)(s_qoff[ql] - qbase));
+        while (ql + 1 < nq && s_qoff[ql + 1] - qbase <= ee) ++ql;
+        if (s_cbase[ql] < 0) continue;
+        const uint32_t pos = (uint32_t)(ee - (s_qoff[ql] - qbase));
+        const int e = s_cbase[ql] + (int)pos;
         int64_t k;
-        if (!canon_key(queries[qbase + e], k)) continue;   // NaN never matches
+        if (!canon_key(queries[qbase + ee], k)) continue;   // NaN never matches
         ekey[e] = k;
         uint32_t pair, tag;
         hash_pair_tag(k, pair, tag);
@@ -243,7 +261,7 @@ __global__ __launch_bounds__(kTileBlock) void ts_match_tile_kernel(
     const int g = threadIdx.x / kGroup;
     uint32_t *gcnt = cnt + g * kTileQ;
     unsigned long long *gtop = top + g * kTileQ;
-    const bool my_q = gl < nq;
+    const bool my_q = gl < nq && s_cbase[gl < nq ? gl : 0] >= 0;
     const int32_t excl = (exclude_ids && my_q) ? exclude_ids[q0 + gl] : -1;
     const bool use_excl = exclude_ids != nullptr;
     const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
@@ -641,7 +659,7 @@ __device__ __forceinline__ int dpp_row16(int v) {
 __global__ __launch_bounds__(kBlock) void ts_match_longq_kernel(
     const Row *__restrict__ rows, int64_t n_rows, const int64_t *__restrict__ keys,
     const int64_t *__restrict__ sq, const int32_t *__restrict__ smult, int32_t m, int32_t min_match,
-    int32_t cap, int32_t *__restrict__ hits, int32_t *__restrict__ hits_n) {
+    int32_t exclude_one, int32_t cap, int32_t *__restrict__ hits, int32_t *__restrict__ hits_n) {
     const int gl = threadIdx.x & (kGroup - 1);
     const int64_t r = (int64_t)blockIdx.x * kGroupsPerBlock + threadIdx.x / kGroup;
     if (r >= n_rows) return;                       // whole 16-lane groups leave together
@@ -661,7 +679,7 @@ __global__ __launch_bounds__(kBlock) void ts_match_longq_kernel(
     cnt += dpp_row16<0x4E>(cnt);    // quad_perm [2,3,0,1]
     cnt += dpp_row16<0x141>(cnt);   // row_half_mirror
     cnt += dpp_row16<0x140>(cnt);   // row_mirror
-    if (gl == 0 && cnt >= min_match) {
+    if (gl == 0 && cnt >= min_match && row.vid != exclude_one) {
         const int slot = atomicAdd(&hits_n[0], 1);
         if (slot < cap) {
             hits[slot * 3 + 0] = row.vid;
