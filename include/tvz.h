@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define TVZ_VERSION 200 /* 0.2.0 */
+#define TVZ_VERSION 300 /* 0.3.0 */
 
 typedef enum tvz_status {
     TVZ_OK = 0,
@@ -157,26 +157,31 @@ int tvz_corpus_upload(tvz_corpus *c, const int32_t *h_video_ids, const int64_t *
  * sees the new row (read-your-writes, as a committed db.py:58-62 would give). */
 int tvz_corpus_upsert(tvz_corpus *c, int32_t video_id, const double *h_keys, int64_t n);
 
-/* `/admin/clear-db` (app.py:325-333). */
+/* `/admin/clear-db` (app.py:325-333).  Matches already enqueued keep sweeping the rows they were
+ * launched with, unchanged: the arena is reused by later upserts only after those matches (the
+ * mutation stream waits for them on the device; the host does not). */
 int tvz_corpus_clear(tvz_corpus *c);
 
 int tvz_corpus_stats(tvz_corpus *c, int64_t *n_rows, int64_t *n_keys, int64_t *arena_keys);
 
 /* Inverted index (no reference counterpart: db.py:83 has no index and reads the whole table per
  * call).  The handle keeps, next to the row table, key -> rows posting lists over the rows as
- * they were at the last build, and a DELTA table with the current entry of every row added or
- * replaced since.  A match with min_match 1..5 is then a lookup (cost ~ postings of the query's
- * keys, independent of the corpus size) + a sweep of the delta table; results are identical to
- * a full sweep (every row is in exactly one of the two).
- * Built by tvz_corpus_upload, when a corpus grown by upserts reaches 4096 rows, when the delta
- * exceeds max(4096, indexed rows / 8), and by this call.  A build waits for matches in flight;
- * its buffers are sized with the corpus reservation (tvz_corpus_reserve / upload), so the rebuilds
- * that upserts trigger allocate only when the corpus has outgrown it.
+ * they were at the last build - ONE directory over the distinct keys of all rows (one probe per
+ * query timestamp), the postings of a key contiguous and ordered by sub-index of 16384 rows - and a
+ * DELTA table with the current entry of every row added or replaced since.  A match with
+ * min_match 1..5 is then a lookup (cost ~ postings of the query's keys, independent of the corpus
+ * size) + a sweep of the delta table; results are identical to a full sweep (every row is in
+ * exactly one of the two).
+ * Built by tvz_corpus_upload and by this call (both wait for matches in flight).  Rebuilt IN THE
+ * BACKGROUND - by the upserting thread that crosses the threshold, into a shadow generation that is
+ * swapped in under the handle's lock; matches and other upserts go on meanwhile, no reader waits -
+ * when a corpus grown by upserts reaches 4096 rows and when the delta table holds
+ * max(4096, indexed rows / 8) rows.  Both generations are sized with the corpus reservation
+ * (tvz_corpus_reserve / upload), so rebuilds allocate only once the corpus has outgrown it.
  * A corpus with >= 2^32 keys (per GPU) gets no index and is swept. */
 int tvz_corpus_build_index(tvz_corpus *c);
-/* indexed rows / rows in the delta table / postings / most distinct keys in one sub-index of 32768
- * rows / builds so far (any may be NULL);
- * all 0 while there is no index. */
+/* indexed rows / rows in the delta table / postings / distinct keys (directory entries in use) /
+ * builds so far (any may be NULL); all 0 while there is no index. */
 int tvz_corpus_index_stats(tvz_corpus *c, int64_t *n_indexed_rows, int64_t *n_delta_rows,
                            int64_t *n_postings, int64_t *n_distinct_keys, int64_t *n_builds);
 
@@ -200,8 +205,9 @@ int tvz_corpus_index_stats(tvz_corpus *c, int64_t *n_indexed_rows, int64_t *n_de
  *   AUTO : INDEX when the handle has one and min_match is 1..5.  Otherwise (and for the delta
  *          table): one query (or <= 4 against a small corpus) -> Q1; >= 64 queries x >= 3 M pairs
  *          with min_match 1..2 -> JOIN; else TILE
- *   INDEX: posting-list lookup, one block per query, + a sweep of the delta table (error if the
- *          handle has no index or min_match is outside 1..5)
+ *   INDEX: posting-list lookup - one block per query walks its sub-indexes (a small batch: one block per
+ *          query and sub-index) - + a sweep of the delta table (error if the handle has no index or
+ *          min_match is outside 1..5)
  *   Q1   : one corpus sweep per query, the query's keys in a small LDS table, per-lane counters
  *   TILE : one LDS hash table per tile of <= 16 queries
  *   JOIN : device-memory hash join per tile of <= 1024 queries (min_match 1..2; other values take TILE) */
@@ -223,8 +229,14 @@ size_t tvz_match_workspace_bytes(int32_t Q, int32_t max_query_len, int32_t cap, 
  *   d_exclude_ids : int32[Q] or NULL
  *   d_hits      : int32[Q][cap][3] out;  d_hits_n : int32[Q] out = number of
  *                 hits found (may exceed cap; only the first cap are stored)
- *   max_query_len : upper bound on any query's length (<= 4095; sizes the query tile).  If it
- *                 is NOT an upper bound the affected queries get d_hits_n = INT32_MIN. */
+ *   max_query_len : upper bound on any query's length (sizes the query tables).  If it is NOT an
+ *                 upper bound the affected queries get d_hits_n = INT32_MIN.
+ *                 Any length is accepted (db.py:87 has no limit).  Up to 4095 the call only enqueues
+ *                 kernels.  Above, the batch may hold queries of more than 4095 timestamps: the
+ *                 library then reads the offsets back, runs the short queries as usual and sweeps
+ *                 every long one on its own (sorted-query search + a kth fix-up pass) - the one
+ *                 batched path that synchronises the stream and allocates scratch.  Rare by nature
+ *                 (a video with thousands of cuts). */
 int tvz_match(tvz_corpus *c, const double *d_queries, const int64_t *d_q_offsets,
               int32_t Q, int32_t max_query_len, int32_t min_match,
               const int32_t *d_exclude_ids, int32_t cap,
@@ -243,8 +255,10 @@ int tvz_match_topk(tvz_corpus *c, const double *d_queries, const int64_t *d_q_of
 /* Host-in / host-out single query: the drop-in for db.find_duplicates.
  * Results sorted by (video_id, count).  *n_out = number of hits (if > cap only
  * cap are returned).  h_out_kth may be NULL.  Any query length is accepted.
- * One kernel launch + one stream synchronisation for queries of <= 4095 timestamps: the
- * kernel writes its hits straight into pinned host memory owned by the handle. */
+ * One kernel launch + one stream synchronisation for queries of <= 4095 timestamps - also when the
+ * handle has an index AND rows in the delta table (the streaming driver's call: its own row was
+ * upserted a moment ago): lookup and delta sweep are one fused launch - the kernel writes its hits
+ * straight into pinned host memory owned by the handle. */
 int tvz_find_duplicates(tvz_corpus *c, const double *h_query, int64_t n, int32_t min_match,
                         int32_t exclude_id, int64_t cap, int32_t *h_out_ids,
                         int32_t *h_out_counts, int32_t *h_out_kth, int64_t *n_out);

@@ -15,7 +15,9 @@ subprocess.check_call([sys.executable, os.path.join(dst, "summarize.py"), tag], 
 subprocess.check_call([sys.executable, os.path.join(dst, "summarize_match.py"), tag], stdout=subprocess.DEVNULL)
 for name, out in (("bench.json", f"{tag}_bench.json"), ("predicted_scaling.json", f"{tag}_predicted_scaling.json"),
                   ("find_dup_latency.txt", f"{tag}_find_dup_latency.txt"), ("e2e_service.txt", f"{tag}_e2e_service.txt"),
-                  ("match_ab.txt", f"{tag}_match_ab_raw.txt")):
+                  ("match_ab.txt", f"{tag}_match_ab_raw.txt"), ("rebuild_latency.txt", f"{tag}_rebuild_latency.txt"),
+                  ("ix_stamps.txt", f"{tag}_ix_stamps.txt"), ("scale_probe.txt", f"{tag}_scale_probe.txt"),
+                  ("fuzz_parity.txt", f"{tag}_fuzz_parity.txt")):
     p = os.path.join(src, name)
     if os.path.exists(p) and os.path.getsize(p):
         shutil.copy(p, os.path.join(dst, out))

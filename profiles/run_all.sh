@@ -1,21 +1,34 @@
 #!/bin/bash
 # Everything measured for a round, in one gpurun call (run on the GPU box from the repo root):
+#   bash profiles/variant_build.sh stamp -DTVZ_IX_STAMP      (build container, beforehand)
 #   bash profiles/run_all.sh <tag>
 # Raw output lands in gpurun_out/ (scratch); `python profiles/collect.py <tag>` (run afterwards, in the
-# build container) copies the summaries that are cited into profiles/.
-TAG=${1:-r2}
+# build container) copies the summaries that are cited into profiles/.  Every step writes its own file
+# and a progress line, so a long run never looks hung.
+TAG=${1:-r3}
 REPO=$(pwd)
 OUT=$REPO/gpurun_out/final_$TAG
 mkdir -p $OUT
 echo "== bench (un-profiled)";            python bench.py --steps 20 --warmup 5 > $OUT/bench.json 2> $OUT/bench.err; echo rc=$?
 echo "== scene kernel trace + FETCH/WRITE"; bash profiles/run_profile.sh $TAG > $OUT/run_profile.log 2>&1; echo rc=$?
-echo "== matcher trace + counters";       bash profiles/pmc_match.sh $TAG index index1 join q1_100k q1_5k tile shard8 > $OUT/pmc_match.log 2>&1; echo rc=$?
+echo "== matcher trace + counters"
+for w in index index1 shard8 join q1_100k q1_5k tile; do bash profiles/pmc_match.sh $TAG $w >> $OUT/pmc_match.log 2>&1; echo "  $w done"; done
 echo "== predicted scaling";              python profiles/predict_scaling.py 4096 2>/dev/null | tail -1 > $OUT/predicted_scaling.json; python profiles/predict_scaling.py 1024 2>/dev/null | tail -1 >> $OUT/predicted_scaling.json
 echo "== find_duplicates latency (C ABI, no Python)"
-bash profiles/fdl.sh > $OUT/find_dup_latency.txt
-echo "== driver, N concurrent uploads (1080p Y4M in RAM -> verdicts)"
-for a in "1 1024 1" "16 256 16" "32 256 16" "64 256 16" "16 512 16" "64 512 16"; do
-  python profiles/e2e_service.py $a 256 64 2>/dev/null | tail -1
+bash profiles/fdl.sh > $OUT/find_dup_latency.txt 2>&1
+echo "== lookups while the index is rebuilt (C, no Python)"
+gcc -O1 -pthread -Iinclude tests/rebuild_latency.c -o /tmp/rl -Ltvidz_amd -ltvz -lm -Wl,-rpath,$REPO/tvidz_amd -Wl,-rpath,/opt/rocm/lib \
+  && TVZ_DEBUG=1 /tmp/rl 2>&1 | grep -v "^slow" > $OUT/rebuild_latency.txt
+echo "== index lookup phase stamps (diagnostic build)"
+if [ -f variants/libtvz_stamp.so ]; then
+  for w in index shard8; do TVZ_LIB=$REPO/variants/libtvz_stamp.so python3 profiles/ix_stamps.py $w 2>/dev/null | tail -1; done > $OUT/ix_stamps.txt
+fi
+echo "== driver, N concurrent uploads (Y4M in RAM -> verdicts): 1080p, 4K, 8 shards"
+for a in "1 1024 1 256 64 0" "16 256 16 256 64 0" "64 256 16 256 64 0" "16 512 16 256 64 0" "64 512 16 256 64 0" \
+         "64 64 16 64 128 0 2160 3840" "64 128 16 64 128 0 2160 3840" "64 256 16 256 64 0 1080 1920 8"; do
+  python profiles/e2e_service.py $a 2>/dev/null | tail -1
 done > $OUT/e2e_service.txt
+echo "== index at 1 M rows";              python profiles/scale_probe.py 2>/dev/null | tail -1 > $OUT/scale_probe.txt
+echo "== differential soak, 120 s";       python profiles/fuzz_parity.py 120 4242 > $OUT/fuzz_parity.txt 2>&1; tail -1 $OUT/fuzz_parity.txt
 echo "== tile vs join vs q1 grid";        python profiles/ab_match_join.py 2>/dev/null > $OUT/match_ab.txt
 ls -la $OUT

@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.environ.get("TVZ_LIB") or os.path.join(_HERE, "libtvz.so")
 
 KTH_NEVER = 0x7FFFFFFF
-VERSION = 200
+VERSION = 300
 
 # name -> (restype, argtypes); mirrors include/tvz.h one to one
 _P = C.c_void_p
