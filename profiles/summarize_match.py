@@ -68,6 +68,14 @@ for w in sorted(os.listdir(src)):
         if "FETCH_SIZE" in avg:
             e["hbm_read_bytes_corrected"] = avg["FETCH_SIZE"] * 1024 * 2      # gfx950: FETCH_SIZE = 1/2 bytes, KiB
             der["hbm_read_MB"] = round(e["hbm_read_bytes_corrected"] / 1e6, 2)
+        # exact read bytes from the request-size classes (validated against known byte counts by
+        # profiles/calib_fetch.sh: a random 16-byte read = one 64-byte request, a wide streaming read = 128-byte
+        # requests, which FETCH_SIZE tallies at 64 - the reason for the guide's x2 rule).  Preferred over the
+        # blanket x2 for kernels that mix both, such as the index lookup.
+        if all(c in avg for c in ("TCC_EA0_RDREQ_32B_sum", "TCC_EA0_RDREQ_64B_sum", "TCC_EA0_RDREQ_128B_sum")):
+            e["hbm_read_bytes_by_request_size"] = 32 * avg["TCC_EA0_RDREQ_32B_sum"] + 64 * avg["TCC_EA0_RDREQ_64B_sum"] + \
+                128 * avg["TCC_EA0_RDREQ_128B_sum"]
+            der["hbm_read_MB_by_request_size"] = round(e["hbm_read_bytes_by_request_size"] / 1e6, 2)
         if "WRITE_SIZE" in avg:
             e["hbm_write_bytes"] = avg["WRITE_SIZE"] * 1024
             der["hbm_write_MB"] = round(e["hbm_write_bytes"] / 1e6, 2)
