@@ -651,6 +651,14 @@ __device__ __forceinline__ void ix_lookup_body(
             }
             const uint32_t incl = wave_scan_incl(mine);
             if (lane == 63) s_wc[wave] = incl;
+            // This thread's bitmap words, reset HERE - behind pass B of the last part (every reader is
+            // behind the barrier above) and AHEAD of the barrier below: a wave that runs ahead into the
+            // next sub-index's pass A sets bits in these words, which a reset after the barrier could
+            // wipe (a lost candidate).
+            if (lo + kIxSlots >= n_cand) {
+#pragma unroll
+                for (int w = 0; w < kIxWpt; ++w) { bm1[threadIdx.x * kIxWpt + w] = 0; bm2[threadIdx.x * kIxWpt + w] = 0; }
+            }
             __syncthreads();
             TVZ_STAMP(8);
             uint32_t base = 0, all = 0;
@@ -690,11 +698,12 @@ __device__ __forceinline__ void ix_lookup_body(
             }
             if (lo + kIxSlots < n_cand) __syncthreads();   // the next part rewrites elist and refills the slots
         }
-        // this thread's bitmap words: every reader (pass B of the last part) is behind a barrier
-#pragma unroll
-        for (int w = 0; w < kIxWpt; ++w) { bm1[threadIdx.x * kIxWpt + w] = 0; bm2[threadIdx.x * kIxWpt + w] = 0; }
+        if (n_cand == 0) {                                 // no part ran (pass A touched rows, none twice): reset here,
+#pragma unroll                                             // with a barrier before anybody's next pass A
+            for (int w = 0; w < kIxWpt; ++w) { bm1[threadIdx.x * kIxWpt + w] = 0; bm2[threadIdx.x * kIxWpt + w] = 0; }
+            __syncthreads();
+        }
         if (HOSTOUT && threadIdx.x == 0) *out_n = (int32_t)emitted;
-        if (n_cand == 0) __syncthreads();                  // (no part ran: keep s_wb's readers ahead of its next writer)
         TVZ_STAMP(9);
     }
     if (!HOSTOUT && alone && threadIdx.x == 0) hits_n[(size_t)q * ns] = (int32_t)emitted;
