@@ -52,3 +52,46 @@ def test_sharded_corpus_answers_like_the_whole_table():
         assert sc.stats()[0] == 0 and sc.find_duplicates(ts, 1) == []
     finally:
         sc.close()
+
+
+def test_rank_corpus_on_one_gpu_through_the_rccl_path():
+    """service.RankCorpus as a rank runs it - this rank's DeviceCorpus, asks answered on the tick through
+    sharded.RcclShardedMatcher (tvz_match_sharded: match -> top-k -> ncclAllGather -> merge behind the C
+    ABI) - at world size 1, which is all a one-GPU box can run: the tick, the packing of the asks and
+    the product matcher, against the oracle."""
+    from tvidz_amd import corpus as tc, sharded
+    ids, offs, keys = synth.synth_timestamp_corpus(3000, seed=33, mean_len=50, dup_frac=0.03, frag_frac=0.03)
+    table = [(int(ids[c]), keys[offs[c]:offs[c + 1]].tolist()) for c in range(len(ids))]
+    shard = tc.DeviceCorpus(0)
+    comm = sharded.make_comm(0)
+    matcher = sharded.RcclShardedMatcher(shard, comm, k=16, cap=2048)
+    rc = service.RankCorpus(shard, matcher, xdev="cuda:0", tick_s=0.001)
+    try:
+        rc.upload(table)
+        queries = synth.synth_queries(ids, offs, keys, 24, seed=6, mean_len=50)
+        errs = []
+
+        def ask(qi):
+            try:
+                q = queries[qi]
+                excl = int(ids[(7 * qi) % len(ids)])
+                oid, cnt, kth = oracle.match_kth(table, list(q), 2)
+                exp = sorted((int(oid[c]), int(cnt[c]), int(kth[c])) for c in range(len(table))
+                             if cnt[c] >= 2 and oid[c] != excl)
+                got = rc.find_duplicates(q, 2, exclude_id=excl, with_kth=True)
+                kstar = min((h[2] for h in exp), default=None)
+                assert sorted(h[0] for h in got if h[2] == kstar) == sorted(h[0] for h in exp if h[2] == kstar), qi
+                assert set(got) <= set(exp)
+            except Exception as e:                                        # pragma: no cover
+                errs.append(repr(e))
+        th = [threading.Thread(target=ask, args=(qi,)) for qi in range(24)]
+        [t.start() for t in th]
+        [t.join(120) for t in th]
+        assert not errs, errs[:2]
+        ts = [8000.5 + i for i in range(5)]
+        rc.upsert(80001, ts)                              # ingested here: lives in this rank's shard
+        assert rc.find_duplicates(ts[:3], 2, with_kth=True) == [(80001, 3, 1)]
+        assert rc.busy_ticks >= 2
+    finally:
+        rc.close()
+        comm.close()
