@@ -1110,23 +1110,36 @@ __device__ __forceinline__ void q1_body(
                 }
             };
             if (cand) {
+                // four 16-byte loads per lane in flight (one load per trip was a chain of ~13 L2 round
+                // trips per candidate row; a block lives as long as its slowest wave, and at min_match 2
+                // nearly every block has a candidate row)
                 const int64_t *rk = keys + row.off;
-                for (int i0 = gl * 2; i0 < row.len; i0 += 2 * kGroup) {
-                    const longlong2 a = *reinterpret_cast<const longlong2 *>(rk + i0);
-                    const int64_t kk[2] = {a.x, a.y};
-                    const bool valid[2] = {true, i0 + 1 < row.len};
+                constexpr int kEx = 4;
+                for (int base = 0; base < row.len; base += kEx * 2 * kGroup) {
+                    longlong2 a[kEx];
 #pragma unroll
-                    for (int e = 0; e < 2; ++e) {
-                        if (!valid[e]) continue;
-                        const uint32_t y = __umul24(q1_mix(kk[e]), 0x9E3779u);
-                        uint32_t h = (y >> pair_shift) << 1;
-                        while (true) {
-                            const longlong2 ww = *reinterpret_cast<const longlong2 *>(skey + h);
-                            if (ww.x == kEmpty) break;
-                            if (ww.x == kk[e]) acc(spos[h]);
-                            if (ww.y == kEmpty) break;
-                            if (ww.y == kk[e]) acc(spos[h + 1]);
-                            h = (h + 2) & smask;
+                    for (int j = 0; j < kEx; ++j) {
+                        const int i0 = base + gl * 2 + j * 2 * kGroup;
+                        a[j] = *reinterpret_cast<const longlong2 *>(i0 < row.len ? rk + i0 : keys);
+                    }
+#pragma unroll
+                    for (int j = 0; j < kEx; ++j) {
+                        const int i0 = base + gl * 2 + j * 2 * kGroup;
+                        const int64_t kk[2] = {a[j].x, a[j].y};
+                        const bool valid[2] = {i0 < row.len, i0 + 1 < row.len};
+#pragma unroll
+                        for (int e = 0; e < 2; ++e) {
+                            if (!valid[e]) continue;
+                            const uint32_t y = __umul24(q1_mix(kk[e]), 0x9E3779u);
+                            uint32_t h = (y >> pair_shift) << 1;
+                            while (true) {
+                                const longlong2 ww = *reinterpret_cast<const longlong2 *>(skey + h);
+                                if (ww.x == kEmpty) break;
+                                if (ww.x == kk[e]) acc(spos[h]);
+                                if (ww.y == kEmpty) break;
+                                if (ww.y == kk[e]) acc(spos[h + 1]);
+                                h = (h + 2) & smask;
+                            }
                         }
                     }
                 }
