@@ -1,0 +1,36 @@
+#!/usr/bin/env python3
+"""The sharded match pipeline of ONE rank's 1/N shard under a kernel trace: which kernels a batch is
+made of and how the two alternating streams overlap.   python profiles/shard_trace.py [N] [Q] [steps]
+(run under rocprofv3 --kernel-trace; profiles/shard_timeline.py reads the trace)"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from tvidz_amd import corpus as tc, sharded, synth  # noqa: E402
+
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+Q = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
+STEPS = int(sys.argv[3]) if len(sys.argv) > 3 else 40
+dev = torch.device("cuda:0")
+ids, offs, keys = synth.synth_timestamp_corpus(100000, seed=synth.CORPUS_SEED)
+queries = synth.synth_queries(ids, offs, keys, Q, seed=synth.CORPUS_SEED + 1)
+d_q, d_off, max_len = tc.pack_queries(queries, dev)
+comm = sharded.make_comm(0)
+s_ids, s_offs, s_keys = sharded.shard_csr(ids, offs, keys, 0, N)
+dc = tc.DeviceCorpus(0)
+dc.upload_csr(s_ids, s_offs, s_keys)
+sm = sharded.RcclShardedMatcher(dc, comm, k=16, cap=16384)
+for _ in range(3):
+    sm.match_topk(d_q, d_off, max_len, 2)
+torch.cuda.synchronize()
+ticket = sm.submit(d_q, d_off, max_len, 2)
+for _ in range(STEPS - 1):
+    nxt = sm.submit(d_q, d_off, max_len, 2)
+    sm.finish(ticket)
+    ticket = nxt
+sm.finish(ticket)
+torch.cuda.synchronize()
+dc.close()
+comm.close()

@@ -341,6 +341,58 @@ def test_sync_replays_rows_of_uploads_that_raced_the_reload(store):
         store._inflight = {}
 
 
+def test_audit_finds_rows_updated_in_place_by_another_writer(store):
+    """db.py:83 re-reads the table on every call, so the reference sees another worker's UPDATE at
+    once.  Here count(*)/max(id) do not move for an in-place UPDATE; the audit pass finds it by
+    content - and leaves alone the rows whose newer list is still queued for SQL."""
+    a, b, c = store.add_video("a.mp4"), store.add_video("b.mp4"), store.add_video("c.mp4")
+    store.add_timestamps(a.id, [1.0, 2.0, 3.0])
+    store.add_timestamps(b.id, [10.0, 11.0])
+    store.add_timestamps_async(c.id, [20.0, 21.0])
+    store.flush()
+    assert store.audit() == 0                           # everything SQL holds is what this process wrote
+    s = store.SessionLocal()                            # "another worker": plain SQL on the same table
+    try:
+        row = s.query(tdb.VideoTimestamps).filter_by(video_id=a.id).first()
+        row.timestamps = [1.0, 2.0, 4.5, 5.5]
+        s.commit()
+    finally:
+        s.close()
+    assert store.sync_if_stale() is False               # the census cannot see it ...
+    assert store.find_duplicates([4.5, 5.5], 2) == []
+    assert store.audit(chunk_rows=2) == 1               # ... the audit does (in chunks of two rows)
+    assert store.find_duplicates([4.5, 5.5], 2) == [(a.id, 2)]
+    assert store.find_duplicates([3.0], 1) == []        # the replaced content is gone from the mirror
+    assert store.audit() == 0 and store.audit_repairs == 1
+    # a row whose newer list is queued for SQL is this process's own: HBM stays ahead of SQL
+    store.flush = lambda video_id=None: None
+    with store._wb_cv:
+        store._pending[b.id] = [10.0, 11.0, 12.0]
+    store.corpus.upsert(b.id, [10.0, 11.0, 12.0])
+    assert store.audit() == 0 and (b.id, [10.0, 11.0, 12.0]) in store.corpus.rows
+    with store._wb_cv:
+        store._pending.clear()
+
+
+def test_audit_thread_repairs_in_the_background(tmp_path):
+    st = tdb.Store(f"sqlite:///{tmp_path}/t.db", corpus=OracleCorpus(), audit_interval=0.05)
+    try:
+        v = st.add_video("a.mp4")
+        st.add_timestamps(v.id, [1.0, 2.0])
+        s = st.SessionLocal()
+        try:
+            s.query(tdb.VideoTimestamps).filter_by(video_id=v.id).first().timestamps = [7.0, 8.0]
+            s.commit()
+        finally:
+            s.close()
+        deadline = time.time() + 10
+        while time.time() < deadline and st.audit_repairs == 0:
+            time.sleep(0.02)
+        assert st.audit_repairs == 1 and st.find_duplicates([7.0, 8.0], 2) == [(v.id, 2)]
+    finally:
+        st.close()
+
+
 def test_native_span_reads_skip_chroma_and_stop_at_partial_records(tmp_path):
     """tvz_read_records behind Y4MReader.read_into: a micro-batch per call, Y planes only (4:2:0
     chroma skipped by the record stride), the count of WHOLE frames at the end of a truncated file,

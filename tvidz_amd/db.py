@@ -20,7 +20,13 @@ reference re-reads `video_timestamps` on every call (db.py:83) and so also sees 
 other workers or by plain SQL; here such writers are detected by a cheap census
 (`SELECT count(*), max(id)`, Store.sync_if_stale - the driver runs it once per upload) that reloads
 the mirror when rows were added or removed behind its back.  An in-place UPDATE of an existing row
-by another writer is NOT detected: run one inspector process per table, or call reload_corpus().
+by another writer leaves count and max(id) alone; it is found by the AUDIT (Store.audit, run every
+`audit_interval` seconds by a background thread when that is > 0 - TVZ_AUDIT_INTERVAL, default
+off): one pass over the table in id order, chunk by chunk, comparing a digest of every row with the
+digest of what this process last read or wrote there, and upserting the rows that differ.  One audit
+reads what the reference reads on EVERY find_duplicates call (db.py:83), so a table shared by
+several writers converges within `audit_interval` at a fraction of the reference's SQL traffic;
+with one inspector process per table leave it off.
 If the device upsert fails after the SQL commit the mirror is marked dirty and reloaded on the
 next use.
 """
@@ -59,11 +65,18 @@ class VideoTimestamps(Base):                                    # db.py:22-27
     video = relationship("Video", back_populates="timestamps")
 
 
+def _digest(ts) -> int:
+    """Digest of one row's timestamp list (audit): equal lists give equal digests."""
+    from array import array
+    return hash(array("d", ts).tobytes())       # by content: NaN and -0.0 are their bit patterns
+
+
 class Store:
     """SQL persistence (same schema as the reference) + the device corpus that mirrors
     `video_timestamps`.  Thread-safe: one short session per call, like the reference."""
 
-    def __init__(self, url: Optional[str] = None, device: int = 0, corpus=None):
+    def __init__(self, url: Optional[str] = None, device: int = 0, corpus=None,
+                 audit_interval: Optional[float] = None):
         self.url = url or os.environ.get("POSTGRES_URL", DEFAULT_URL)
         kw = {}
         if self.url.startswith("sqlite") and (":memory:" in self.url or self.url in ("sqlite://", "sqlite:///")):
@@ -108,7 +121,17 @@ class Store:
         # HBM row + queued SQL write of add_timestamps_async happen as one step with respect to a
         # reload of the mirror (sync_if_stale): a reload in between would drop the HBM row for good
         self._mirror_lock = threading.RLock()
+        # video_id -> digest of the row SQL holds as far as this process knows (audit())
+        self._sql_digest = {}
+        self.audit_interval = float(os.environ.get("TVZ_AUDIT_INTERVAL", "0") if audit_interval is None
+                                    else audit_interval)
+        self.audit_repairs = 0           # rows the audits found changed behind this process's back
+        self._audit_stop = threading.Event()
+        self._audit_thread = None
         self.reload_corpus()
+        if self.audit_interval > 0:
+            self._audit_thread = threading.Thread(target=self._audit_loop, name="tvz-sql-audit", daemon=True)
+            self._audit_thread.start()
 
     # -- device mirror -------------------------------------------------------
     def reload_corpus(self) -> int:
@@ -122,6 +145,7 @@ class Store:
         finally:
             session.close()
         self.corpus.upload(data)
+        self._sql_digest = {vid: _digest(ts) for vid, ts in data}
         self._census = census
         self._dirty = False
         return len(data)
@@ -160,6 +184,50 @@ class Store:
                     self.corpus.upsert(int(vid), ts)
         return stale
 
+    def audit(self, chunk_rows: int = 4096) -> int:
+        """One pass over `video_timestamps` in id order: every row whose content is not what this
+        process last read or wrote for that video was UPDATEd in place by another writer (the
+        census of sync_if_stale cannot see that) - its HBM row is replaced by the SQL content.
+        Rows of uploads with a queued or in-flight write-behind are this process's own and are
+        skipped (HBM is ahead of SQL there by design).  Returns the number of rows repaired.
+        The write lock is held per CHUNK, so uploads interleave with a long audit."""
+        repaired, last_id = 0, 0
+        while True:
+            with self._write_lock:
+                session = self.SessionLocal()
+                try:
+                    rows = (session.query(VideoTimestamps.id, VideoTimestamps.video_id, VideoTimestamps.timestamps)
+                            .filter(VideoTimestamps.id > last_id).order_by(VideoTimestamps.id)
+                            .limit(int(chunk_rows)).all())
+                finally:
+                    session.close()
+                if not rows:
+                    break
+                last_id = int(rows[-1][0])
+                with self._wb_cv:
+                    own = set(self._pending) | set(self._inflight)
+                for _id, vid, ts in rows:
+                    if vid is None or int(vid) in own:
+                        continue
+                    ts = [float(x) for x in (ts or [])]
+                    d = _digest(ts)
+                    if self._sql_digest.get(int(vid)) != d:
+                        with self._mirror_lock:
+                            self.corpus.upsert(int(vid), ts)
+                        self._sql_digest[int(vid)] = d
+                        repaired += 1
+            if len(rows) < int(chunk_rows):
+                break
+        self.audit_repairs += repaired
+        return repaired
+
+    def _audit_loop(self) -> None:
+        while not self._audit_stop.wait(self.audit_interval):
+            try:
+                self.audit()
+            except Exception:               # a failed audit (connection lost ...) is retried next period
+                pass
+
     # -- reference API -------------------------------------------------------
     def add_video(self, filename, thumbnail_path=None):         # db.py:32-41
         with self._sql_write:
@@ -189,6 +257,7 @@ class Store:
                     session.add(ts_row)
                     session.commit()
                     self._census = (self._census[0] + 1, max(self._census[1], int(ts_row.id)))
+                self._sql_digest[int(video_id)] = _digest(ts)
             finally:
                 session.close()
             try:
@@ -209,6 +278,7 @@ class Store:
             session.add(ts_row)
             session.flush()
             self._census = (self._census[0] + 1, max(self._census[1], int(ts_row.id)))
+        self._sql_digest[int(video_id)] = _digest(ts)   # (a failed commit marks the mirror dirty: reloaded)
 
     def add_timestamps_async(self, video_id, timestamps) -> None:
         """add_timestamps for the streaming driver: the HBM row - what the NEXT find_duplicates of
@@ -349,6 +419,7 @@ class Store:
                 session.close()
             self.corpus.clear()
             self._census = (0, 0)
+            self._sql_digest = {}
 
     def list_videos(self):                                      # app.py:347-366
         session = self.SessionLocal()
@@ -375,6 +446,9 @@ class Store:
             self._wb_cv.notify_all()
         if self._wb_thread is not None:
             self._wb_thread.join(timeout=5)
+        self._audit_stop.set()
+        if self._audit_thread is not None:
+            self._audit_thread.join(timeout=5)
         self.corpus.close()
         self.engine.dispose()
 
