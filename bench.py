@@ -203,9 +203,9 @@ def bench_match(args, rank, world, dev):
     t0 = time.perf_counter()
     # a stream of query batches over two HIP streams: the all-gather + merge of batch i overlap the
     # sweep of batch i+1; every batch is fully merged inside the timed region
-    ticket = sm.submit(d_q, d_off, max_len, 2)
+    ticket = sm.submit(d_q, d_off, max_len, 2, inputs_ready=True)
     for _ in range(args.match_steps - 1):
-        nxt = sm.submit(d_q, d_off, max_len, 2)
+        nxt = sm.submit(d_q, d_off, max_len, 2, inputs_ready=True)
         merged, totals = sm.finish(ticket)
         ticket = nxt
     merged, totals = sm.finish(ticket)

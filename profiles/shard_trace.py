@@ -13,6 +13,10 @@ from tvidz_amd import corpus as tc, sharded, synth  # noqa: E402
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 Q = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
 STEPS = int(sys.argv[3]) if len(sys.argv) > 3 else 40
+N_STREAMS = int(sys.argv[4]) if len(sys.argv) > 4 else 2
+NO_WAIT = len(sys.argv) > 5 and sys.argv[5] == "nowait"      # probe only: drop the wait on the caller's stream
+if NO_WAIT:
+    torch.cuda.Stream.wait_stream = lambda self, other: None
 dev = torch.device("cuda:0")
 ids, offs, keys = synth.synth_timestamp_corpus(100000, seed=synth.CORPUS_SEED)
 queries = synth.synth_queries(ids, offs, keys, Q, seed=synth.CORPUS_SEED + 1)
@@ -21,16 +25,19 @@ comm = sharded.make_comm(0)
 s_ids, s_offs, s_keys = sharded.shard_csr(ids, offs, keys, 0, N)
 dc = tc.DeviceCorpus(0)
 dc.upload_csr(s_ids, s_offs, s_keys)
-sm = sharded.RcclShardedMatcher(dc, comm, k=16, cap=16384)
+sm = sharded.RcclShardedMatcher(dc, comm, k=16, cap=16384, n_streams=N_STREAMS)
 for _ in range(3):
     sm.match_topk(d_q, d_off, max_len, 2)
 torch.cuda.synchronize()
-ticket = sm.submit(d_q, d_off, max_len, 2)
+import time
+t0 = time.perf_counter()
+ticket = sm.submit(d_q, d_off, max_len, 2, inputs_ready=True)
 for _ in range(STEPS - 1):
-    nxt = sm.submit(d_q, d_off, max_len, 2)
+    nxt = sm.submit(d_q, d_off, max_len, 2, inputs_ready=True)
     sm.finish(ticket)
     ticket = nxt
 sm.finish(ticket)
 torch.cuda.synchronize()
+print(f"N={N} Q={Q} streams={N_STREAMS} nowait={NO_WAIT}: {(time.perf_counter() - t0) * 1e6 / STEPS:.1f} us per batch")
 dc.close()
 comm.close()

@@ -145,11 +145,18 @@ class RcclShardedMatcher:
         self._i = 0
 
     def submit(self, d_queries: torch.Tensor, d_q_offsets: torch.Tensor, max_query_len: int,
-               min_match: int, d_exclude_ids: Optional[torch.Tensor] = None):
+               min_match: int, d_exclude_ids: Optional[torch.Tensor] = None, inputs_ready: bool = False):
         """Enqueue one batch; the returned ticket's tensors belong to this matcher and are
         overwritten by the submit() `n_streams` calls later - consume them (or copy) before that.
         Nothing is allocated per batch: at 8 GPUs a batch is ~0.1 ms of device time, and fresh
-        output tensors + events per call were a comparable amount of host time."""
+        output tensors + events per call were a comparable amount of host time.
+        `inputs_ready`: the query tensors are complete already and nothing pending on the caller's
+        stream still reads this slot's previous results, so the side stream does not wait for the
+        caller's stream.  That wait
+        is a marker in the caller's queue BEHIND the caller's earlier finish() waits - a chain of
+        cross-queue barriers the command processor resolves in 10-40 us, which at 8 GPUs (a batch
+        is ~60 us of kernels) left the chip idle between two batches' match kernels
+        (profiles/r3_shard_pipeline.txt)."""
         from . import corpus as tc
         i = self._i
         self._i = (i + 1) % len(self.streams)
@@ -161,7 +168,8 @@ class RcclShardedMatcher:
         if self.out[i] is None or self.out[i][0].shape[0] != Q:
             self.out[i] = (torch.empty((Q, self.k, 3), dtype=torch.int32, device=self.dev),
                            torch.empty(Q, dtype=torch.int32, device=self.dev))
-        st.wait_stream(torch.cuda.current_stream(self.dev))     # queries are ready; the slot's buffers are free
+        if not inputs_ready:
+            st.wait_stream(torch.cuda.current_stream(self.dev))   # the queries are complete before the match reads them
         merged, totals = self.comm.match_sharded(self.corpus, d_queries, d_q_offsets, max_query_len,
                                                  min_match, self.cap, self.k, d_exclude_ids,
                                                  workspace=self.ws[i], stream=st, out=self.out[i])
