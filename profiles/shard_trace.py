@@ -34,9 +34,9 @@ t0 = time.perf_counter()
 ticket = sm.submit(d_q, d_off, max_len, 2, inputs_ready=True)
 for _ in range(STEPS - 1):
     nxt = sm.submit(d_q, d_off, max_len, 2, inputs_ready=True)
-    sm.finish(ticket)
+    sm.finish(ticket, host=True)
     ticket = nxt
-sm.finish(ticket)
+sm.finish(ticket, host=True)
 torch.cuda.synchronize()
 print(f"N={N} Q={Q} streams={N_STREAMS} nowait={NO_WAIT}: {(time.perf_counter() - t0) * 1e6 / STEPS:.1f} us per batch")
 dc.close()

@@ -38,9 +38,17 @@ for counter, sub, fn in (("FETCH_SIZE", "pmc_fetch", "fetch"), ("WRITE_SIZE", "p
             w.writerow([name, r["Grid_Size"], r["Workgroup_Size"], r["VGPR_Count"], r["SGPR_Count"],
                         r["LDS_Block_Size"], counter, r["Counter_Value"],
                         int(r["End_Timestamp"]) - int(r["Start_Timestamp"])])
+    # bench.py also launches the scene kernels on small inputs (config0's 480p clips, the e2e leg's
+    # micro-batches): per kernel only the launches of the LARGEST grid - the headline workload - count
+    big = collections.defaultdict(int)
+    for r in rows:
+        k = next(o for o in OURS if o in r["Kernel_Name"])
+        big[k] = max(big[k], int(r["Grid_Size"]))
     agg = collections.defaultdict(list)
     for r in rows:
-        agg[next(o for o in OURS if o in r["Kernel_Name"])].append(float(r["Counter_Value"]))
+        k = next(o for o in OURS if o in r["Kernel_Name"])
+        if int(r["Grid_Size"]) == big[k]:
+            agg[k].append(float(r["Counter_Value"]))
     for k, v in agg.items():
         summary.setdefault(k, {})[counter + "_KiB_avg"] = sum(v) / len(v)
         summary[k][counter + "_launches"] = len(v)

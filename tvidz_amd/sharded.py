@@ -177,9 +177,15 @@ class RcclShardedMatcher:
         ev.record(st)
         return (merged, totals, ev)
 
-    def finish(self, ticket):
+    def finish(self, ticket, host: bool = False):
+        """Order the consumer behind the batch: the caller's current stream waits for it (default),
+        or - `host=True`, what a consumer that reads the verdicts on the host does anyway - the
+        calling thread does (no barrier packet in the caller's queue)."""
         merged, totals, ev = ticket
-        torch.cuda.current_stream(self.dev).wait_event(ev)
+        if host:
+            ev.synchronize()
+        else:
+            torch.cuda.current_stream(self.dev).wait_event(ev)
         return merged, totals
 
     def match_topk(self, d_queries, d_q_offsets, max_query_len, min_match, d_exclude_ids=None):
