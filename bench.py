@@ -371,9 +371,10 @@ def bench_match_q1(args, dev, Q):
                  "q1_sweep_kernel_ms": round(q1_ms, 4), "q1_sweep_kernel_ms_min_match5": round(q1_mm5, 4),
                  "find_duplicates_latency_us": round(float(np.median(lat[10:])) * 1e6, 1),
                  "roofline_q1": {"bound": "hbm", "kernel": "ts_match_q1_kernel, forced (one query, whole corpus image "
-                                                           "streamed once; event pair also covers ts_prep + the counter "
-                                                           "gather); AUTO answers from the index instead, see "
-                                                           "kernel_by_batch_size",
+                                                           "streamed once; the event pair also covers the counter-zeroing "
+                                                           "launch in front of it - the kernel alone, rocprofv3 average: "
+                                                           "profiles/r3_match_q1_100k_kernel_stats.csv); AUTO answers "
+                                                           "from the index instead, see kernel_by_batch_size",
                                  "algorithmic_bytes_per_launch": image,
                                  "achieved": image / (q1_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                  "frac": image / (q1_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
@@ -494,7 +495,7 @@ def bench_e2e(dev, n_uploads: int = 8, n_frames: int = 256):
                 "height": H, "width": W, "all_done": ok, "GBps_luma": n_uploads * n_frames * FRAME_BYTES / dt / 1e9,
                 "note": "whole Python driver, PCIe-inclusive, files in RAM, no decoder; short clips: per-upload set-up "
                         "(SQL insert, reader thread, first slot) is inside the wall time.  profiles/r3_e2e_service.txt: "
-                        "16 / 64 uploads x 512 frames 26-27 k fps (the 27.6 k H2D bound), 64 x 4K ~6 k fps"}
+                        "16 / 64 uploads x 512 frames 24 / 31 k fps (H2D bound 27.6 k at one copy in flight), 64 x 4K 5.6-5.8 k fps"}
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
 

@@ -1515,8 +1515,10 @@ static int tvz_match_impl(tvz_corpus *c, const double *d_queries, const int64_t 
         if (workspace_bytes >= w.total) {
             ws = w.join;
             ws_bytes = w.join_bytes;
-            cnt = w.counters;
-            ns = kCountStride;
+            if (Q > 1) {                 // a lone query's counter shares its line with nobody: no gather launch
+                cnt = w.counters;
+                ns = kCountStride;
+            }
         } else if (algo == TVZ_ALGO_JOIN) {
             return tvz::fail(TVZ_ERR_WORKSPACE, "workspace of %zu bytes, the hash join needs %zu: size it with "
                                                 "tvz_match_workspace_bytes", workspace_bytes, w.total);
