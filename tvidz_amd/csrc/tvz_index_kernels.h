@@ -10,6 +10,7 @@
 //          uint16 counts - the key's postings in each SUB-INDEX of 2^14 rows (ks = sub-indexes
 //          rounded up to 8; ks = 0 for a corpus of one sub-index: the head's total is the count).
 //          One probe (head + counts share a cache line) tells a query element everything.
+//          Probing is linear INSIDE a slice of 2^slice_log2 entries (kernel argument dir_bits).
 //   post : posting lists, one uint16 LOCAL row number per (row, key) pair; the postings of a key
 //          are contiguous, ordered by sub-index - the pieces a block reads one sub-index after the
 //          other lie next to each other in memory
@@ -33,9 +34,13 @@
 // The walks are laid out so that every wave owns a contiguous range of the flattened postings:
 // consecutive lanes read consecutive postings and a lane's list pointer only moves forward.
 //
-// Build (tvz_match.hip: into a SHADOW buffer set, readers keep using the old index meanwhile):
-// count postings per (key, sub-index) with find-or-insert, hand out posting ranges with a block
-// scan + one atomic per block, fill.  No sort.
+// Build (tvz_match.hip: into a SHADOW buffer set, readers keep using the old index meanwhile): the
+// directory is cut into SLICES of ~32 KB; an entry lives in the slice of its home slot (linear
+// probing wraps inside the slice).  The (key, row) pairs of all rows are partitioned by slice
+// (histogram, scan, LDS-staged scatter: whole lines leave the chip), then ONE block per slice makes
+// the slice's entries, counts and posting ranges in LDS and writes them out once.  No sort, no
+// global scatter: 0.8 ms for 100k rows / 19.9 M keys (count + fill over the whole directory, kept
+// for directories of more than 4,096 slices: 2.7 ms).
 #pragma once
 #include "tvz_match_kernels.h"
 
@@ -65,6 +70,11 @@ constexpr int kSubRows = 1 << kSubLog2;
 inline int ix_ks(int n_sub) { return n_sub <= 1 ? 0 : (n_sub + 7) & ~7; }   // uint16 counts per entry
 inline int ix_entry_bytes(int ks) { return 16 + 2 * ks; }
 
+// kernel argument `dir_bits` = log2 of the directory entries | log2 of the entries per SLICE << 8: an
+// entry lives in the slice of its home slot (linear probing wraps inside the slice), so that a build
+// can make a slice in LDS from the keys that hash into it and nothing else
+inline int ix_dir_bits(int dir_log2, int slice_log2) { return dir_log2 | (slice_log2 << 8); }
+
 __device__ __forceinline__ uint32_t ix_slot(int64_t k, int dir_log2) {
     return (q1_mix(k) * 0x9E3779B1u) >> (32 - dir_log2);
 }
@@ -86,8 +96,9 @@ __global__ __launch_bounds__(kBlock) void ix_clear_kernel(uint4 *__restrict__ di
 
 // find (or, with INSERT, claim) the directory entry of key k; returns the slot or -1
 template <bool INSERT>
-__device__ __forceinline__ int64_t ix_find(unsigned char *dir, int es, int dir_log2, int64_t k, bool &is_new) {
-    const uint32_t mask = (1u << dir_log2) - 1u;
+__device__ __forceinline__ int64_t ix_find(unsigned char *dir, int es, int dir_bits, int64_t k, bool &is_new) {
+    const int dir_log2 = dir_bits & 0xff;
+    const uint32_t smask = (1u << (dir_bits >> 8)) - 1u;      // probes wrap inside the key's directory slice
     uint32_t s = ix_slot(k, dir_log2);
     is_new = false;
     for (int probes = 0; probes < kIxMaxProbe; ++probes) {
@@ -102,7 +113,7 @@ __device__ __forceinline__ int64_t ix_find(unsigned char *dir, int es, int dir_l
             if (old == (unsigned long long)kEmpty) { is_new = true; return s; }
             if ((int64_t)old == k) return s;
         }
-        s = (s + 1) & mask;
+        s = (s & ~smask) | ((s + 1) & smask);
     }
     return -1;
 }
@@ -112,7 +123,7 @@ __device__ __forceinline__ int64_t ix_find(unsigned char *dir, int es, int dir_l
 // sub-index, so the low half cannot carry into the high half).
 __global__ __launch_bounds__(kBlock) void ix_count_kernel(const Row *__restrict__ rows, int64_t n_rows,
                                                           const int64_t *__restrict__ keys, unsigned char *dir,
-                                                          int es, int ks, int dir_log2, int32_t *__restrict__ ivid,
+                                                          int es, int ks, int dir_bits, int32_t *__restrict__ ivid,
                                                           IxBuildInfo *info) {
     const int lane = threadIdx.x & 63;
     for (int64_t r = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6); r < n_rows;
@@ -123,7 +134,7 @@ __global__ __launch_bounds__(kBlock) void ix_count_kernel(const Row *__restrict_
         uint32_t mine = 0;
         for (int i = lane; i < row.len; i += 64) {
             bool is_new;
-            const int64_t s = ix_find<true>(dir, es, dir_log2, keys[row.off + i], is_new);
+            const int64_t s = ix_find<true>(dir, es, dir_bits, keys[row.off + i], is_new);
             if (s < 0) { info->failed = 1; continue; }
             unsigned char *e = dir + (size_t)s * es;
             if (ks) atomicAdd(reinterpret_cast<uint32_t *>(e + 16) + (sub >> 1), 1u << ((sub & 1u) * 16u));
@@ -180,7 +191,7 @@ __global__ __launch_bounds__(kBlock) void ix_offsets_kernel(unsigned char *dir, 
 // fillc: one 32-bit word per two sub-indexes of an entry (ks = 0: one word per entry), zeroed.
 __global__ __launch_bounds__(kBlock) void ix_fill_kernel(const Row *__restrict__ rows, int64_t n_rows,
                                                          const int64_t *__restrict__ keys, unsigned char *dir, int es,
-                                                         int ks, int dir_log2, uint32_t *__restrict__ fillc,
+                                                         int ks, int dir_bits, uint32_t *__restrict__ fillc,
                                                          uint16_t *__restrict__ post) {
     const int lane = threadIdx.x & 63;
     const int fw = ks ? ks / 2 : 1;                    // fill-cursor words per entry
@@ -190,7 +201,7 @@ __global__ __launch_bounds__(kBlock) void ix_fill_kernel(const Row *__restrict__
         const uint32_t sub = (uint32_t)(r >> kSubLog2);
         for (int i = lane; i < row.len; i += 64) {
             bool is_new;
-            const int64_t s = ix_find<false>(dir, es, dir_log2, keys[row.off + i], is_new);
+            const int64_t s = ix_find<false>(dir, es, dir_bits, keys[row.off + i], is_new);
             if (s < 0) continue;                       // cannot happen after a successful count pass
             const unsigned char *e = dir + (size_t)s * es;
             uint32_t p = reinterpret_cast<const DirHead *>(e)->base;
@@ -204,6 +215,304 @@ __global__ __launch_bounds__(kBlock) void ix_fill_kernel(const Row *__restrict__
             }
             post[p + k] = (uint16_t)(r & (kSubRows - 1));
         }
+    }
+}
+
+// ---- partitioned build (round 3): no global scatter --------------------------------------------
+// count + fill above touch the whole directory and the whole posting array at random from every
+// block: 20 M probes, 20 M memory-side atomics and 20 M two-byte writes = 9.6 GB of line traffic for
+// a 160 MB corpus.  Here the (key, row) pairs are first PARTITIONED by directory slice (two
+// streaming passes: histogram, then scatter with one reservation per block and slice), and each
+// slice - its entries, counts and posting ranges - is then built by ONE block in LDS and written out
+// once: the directory and the postings leave the chip as whole lines.
+constexpr int kIxMaxParts = 4096;          // slices (LDS histogram + cursors of the partition kernels: 8 B each)
+constexpr int kIxSliceBlock = 512;
+
+__global__ void ix_part_clear_kernel(uint32_t *__restrict__ hist, int n, IxBuildInfo *info) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) hist[i] = 0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) { info->cursor = 0; info->n_distinct = 0; info->failed = 0; info->pad = 0; }
+}
+
+// a block takes `rpb` consecutive rows (a wave per row, in turns).  SCATTER = false: the slices'
+// pair counts (LDS histogram, one global add per block and non-empty slice) and the rows' video ids.
+// SCATTER = true: counts again, reserves the block's range of every slice with ONE atomic on the
+// slice's cursor (`gcnt` then holds the slices' running write positions) and writes the pairs.
+template <bool SCATTER>
+__global__ __launch_bounds__(kBlock) void ix_partition_kernel(
+    const Row *__restrict__ rows, int64_t n_rows, int32_t rpb, const int64_t *__restrict__ keys, int dir_bits,
+    int n_parts, uint32_t *__restrict__ gcnt, int64_t *__restrict__ pkeys, uint32_t *__restrict__ prows,
+    int32_t *__restrict__ ivid) {
+    extern __shared__ uint32_t ix_part_sh[];
+    uint32_t *hist = ix_part_sh, *base = ix_part_sh + n_parts;
+    const int dir_log2 = dir_bits & 0xff, slice_log2 = dir_bits >> 8;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int i = threadIdx.x; i < n_parts; i += kBlock) hist[i] = 0;
+    __syncthreads();
+    const int64_t r0 = (int64_t)blockIdx.x * rpb;
+    const int64_t r1 = r0 + rpb < n_rows ? r0 + rpb : n_rows;
+    for (int64_t r = r0 + wave; r < r1; r += kBlock / 64) {
+        const Row row = load_row(rows + r);
+        if (!SCATTER && lane == 0) ivid[r] = row.vid;
+        for (int i = lane; i < row.len; i += 64)
+            atomicAdd(&hist[ix_slot(keys[row.off + i], dir_log2) >> slice_log2], 1u);
+    }
+    __syncthreads();
+    if (!SCATTER) {
+        for (int i = threadIdx.x; i < n_parts; i += kBlock)
+            if (hist[i]) atomicAdd(&gcnt[i], hist[i]);
+        return;
+    }
+    for (int i = threadIdx.x; i < n_parts; i += kBlock) {
+        const uint32_t c = hist[i];
+        base[i] = c ? atomicAdd(&gcnt[i], c) : 0u;
+        hist[i] = 0;
+    }
+    __syncthreads();
+    for (int64_t r = r0 + wave; r < r1; r += kBlock / 64) {
+        const Row row = load_row(rows + r);
+        for (int i = lane; i < row.len; i += 64) {
+            const int64_t k = keys[row.off + i];
+            const uint32_t p = ix_slot(k, dir_log2) >> slice_log2;
+            const uint32_t pos = base[p] + atomicAdd(&hist[p], 1u);
+            pkeys[pos] = k;
+            prows[pos] = (uint32_t)r;
+        }
+    }
+}
+
+// The scatter, staged: a block of 1024 threads takes rows worth ~kIxStagePairs pairs, counts them per
+// slice, gives every slice its LOCAL range in an LDS staging area (block scan over the slices) and
+// its GLOBAL range (one atomic per non-empty slice), drops the pairs into the staging area in slice
+// order, and then writes the staging area out with consecutive threads on consecutive pairs - the
+// pairs of one slice go out as one run of whole lines.  (Writing every pair to its slice directly,
+// ix_partition_kernel<true>, left ~2,000 partly written lines per block in flight - 67 MB over the
+// chip against 32 MB of L2 - and took 1.15 ms of a 1.6 ms build.)  Pairs beyond the staging area
+// (rows longer than expected) are written directly.
+constexpr int kIxScatterBlock = 1024;
+constexpr int kIxStagePairs = 8192;        // 96 KB of LDS: 8 B key + 4 B row
+
+__global__ __launch_bounds__(kIxScatterBlock) void ix_scatter_kernel(
+    const Row *__restrict__ rows, int64_t n_rows, int32_t rpb, const int64_t *__restrict__ keys, int dir_bits,
+    int n_parts, uint32_t *__restrict__ gcur, int64_t *__restrict__ pkeys, uint32_t *__restrict__ prows) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char ix_scat_sh[];
+    int64_t *st_k = reinterpret_cast<int64_t *>(ix_scat_sh);                       // [kIxStagePairs]
+    uint32_t *st_r = reinterpret_cast<uint32_t *>(st_k + kIxStagePairs);           // [kIxStagePairs]
+    uint32_t *hist = st_r + kIxStagePairs;                                         // [n_parts] counts, then fill cursors
+    uint32_t *lstart = hist + n_parts;                                             // [n_parts + 1] first staged pair of a slice
+    uint32_t *base = lstart + n_parts + 1;                                         // [n_parts] first global pair of the block's run
+    __shared__ uint32_t s_w[kIxScatterBlock / 64];
+    const int dir_log2 = dir_bits & 0xff, slice_log2 = dir_bits >> 8;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int i = threadIdx.x; i < n_parts; i += kIxScatterBlock) hist[i] = 0;
+    __syncthreads();
+    const int64_t r0 = (int64_t)blockIdx.x * rpb;
+    const int64_t r1 = r0 + rpb < n_rows ? r0 + rpb : n_rows;
+    for (int64_t r = r0 + wave; r < r1; r += kIxScatterBlock / 64) {
+        const Row row = load_row(rows + r);
+        for (int i = lane; i < row.len; i += 64)
+            atomicAdd(&hist[ix_slot(keys[row.off + i], dir_log2) >> slice_log2], 1u);
+    }
+    __syncthreads();
+    // local and global ranges: thread t owns the slices [t * per, (t + 1) * per)
+    const int per = (n_parts + kIxScatterBlock - 1) / kIxScatterBlock;
+    const int p0 = threadIdx.x * per;
+    uint32_t mine = 0;
+    for (int i = p0; i < p0 + per && i < n_parts; ++i) mine += hist[i];
+    const uint32_t incl = wave_scan_incl(mine);
+    if (lane == 63) s_w[wave] = incl;
+    __syncthreads();
+    uint32_t before = 0, all = 0;
+#pragma unroll
+    for (int w = 0; w < kIxScatterBlock / 64; ++w) { if (w < wave) before += s_w[w]; all += s_w[w]; }
+    {
+        uint32_t run = before + incl - mine;
+        for (int i = p0; i < p0 + per && i < n_parts; ++i) {
+            const uint32_t c = hist[i];
+            lstart[i] = run;
+            base[i] = c ? atomicAdd(&gcur[i], c) : 0u;
+            hist[i] = 0;
+            run += c;
+        }
+        if (threadIdx.x == 0) lstart[n_parts] = all;
+    }
+    __syncthreads();
+    for (int64_t r = r0 + wave; r < r1; r += kIxScatterBlock / 64) {
+        const Row row = load_row(rows + r);
+        for (int i = lane; i < row.len; i += 64) {
+            const int64_t k = keys[row.off + i];
+            const uint32_t p = ix_slot(k, dir_log2) >> slice_log2;
+            const uint32_t j = atomicAdd(&hist[p], 1u);
+            const uint32_t t = lstart[p] + j;
+            if (t < (uint32_t)kIxStagePairs) {
+                st_k[t] = k;
+                st_r[t] = (uint32_t)r;
+            } else {
+                pkeys[base[p] + j] = k;
+                prows[base[p] + j] = (uint32_t)r;
+            }
+        }
+    }
+    __syncthreads();
+    const uint32_t staged = all < (uint32_t)kIxStagePairs ? all : (uint32_t)kIxStagePairs;
+    for (uint32_t t = threadIdx.x; t < staged; t += kIxScatterBlock) {
+        int lo = 0, hi = n_parts;                       // the slice of staged pair t: lstart[lo] <= t < lstart[lo + 1]
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (lstart[mid] <= t) lo = mid; else hi = mid;
+        }
+        const uint32_t g = base[lo] + (t - lstart[lo]);
+        pkeys[g] = st_k[t];
+        prows[g] = st_r[t];
+    }
+}
+
+// exclusive scan of the slices' pair counts (one block; n <= kIxMaxParts): start[i], start[n] = all
+// pairs; cur[i] = start[i] (the scatter's cursors); info->cursor = all pairs
+__global__ __launch_bounds__(1024) void ix_part_scan_kernel(const uint32_t *__restrict__ cnt, int n,
+                                                            uint32_t *__restrict__ start, uint32_t *__restrict__ cur,
+                                                            IxBuildInfo *info) {
+    __shared__ uint32_t s_w[16];
+    const int per = (n + 1023) / 1024;
+    const int lo = threadIdx.x * per;
+    uint32_t mine = 0;
+    for (int i = lo; i < lo + per && i < n; ++i) mine += cnt[i];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t incl = wave_scan_incl(mine);
+    if (lane == 63) s_w[wave] = incl;
+    __syncthreads();
+    uint32_t before = 0, all = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) { if (w < wave) before += s_w[w]; all += s_w[w]; }
+    uint32_t run = before + incl - mine;
+    for (int i = lo; i < lo + per && i < n; ++i) {
+        const uint32_t c = cnt[i];
+        start[i] = run;
+        cur[i] = run;
+        run += c;
+    }
+    if (threadIdx.x == 0) { start[n] = all; info->cursor = all; }
+}
+
+// one block per slice: the slice's directory entries are made in LDS from the slice's pairs (find-or-
+// insert by 64-bit LDS CAS, the uint16 count of the (key, sub-index) bumped through its 32-bit word),
+// posting ranges handed out by a block scan (the slice's postings are exactly its pairs, so its first
+// posting is its first pair), the slice written to the directory as whole lines, and then every pair
+// takes a place in its (key, sub-index) piece by counting the LDS count DOWN (the copy in the
+// directory keeps the counts; a piece starts at base + the counts of the lower sub-indexes, read
+// from that copy).
+__global__ __launch_bounds__(kIxSliceBlock) void ix_slice_build_kernel(
+    const int64_t *__restrict__ pkeys, const uint32_t *__restrict__ prows, const uint32_t *__restrict__ start,
+    unsigned char *dir, int es, int ks, int dir_bits, uint16_t *__restrict__ post, IxBuildInfo *info) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char ix_slice_sh[];
+    __shared__ uint32_t s_w[kIxSliceBlock / 64], s_d[kIxSliceBlock / 64];
+    unsigned char *sl = ix_slice_sh;
+    const int dir_log2 = dir_bits & 0xff, slice_log2 = dir_bits >> 8;
+    const uint32_t se = 1u << slice_log2, smask = se - 1u;
+    const uint32_t part = blockIdx.x;
+    const uint32_t lo = start[part], hi = start[part + 1];
+    const int e16 = es / 16;
+    {
+        uint4 head;
+        head.x = (uint32_t)(uint64_t)kEmpty;
+        head.y = (uint32_t)((uint64_t)kEmpty >> 32);
+        head.z = 0;
+        head.w = 0;
+        uint4 *s16 = reinterpret_cast<uint4 *>(sl);
+        for (uint32_t i = threadIdx.x; i < se * (uint32_t)e16; i += kIxSliceBlock)
+            s16[i] = (i % (uint32_t)e16 == 0) ? head : make_uint4(0, 0, 0, 0);
+    }
+    __syncthreads();
+    // the entry of key k in this slice (INSERT: claimed if absent); -1: the slice is full
+    auto find = [&](int64_t k, bool insert) -> int {
+        uint32_t s = ix_slot(k, dir_log2) & smask;
+        for (uint32_t probes = 0; probes < se; ++probes) {
+            unsigned long long *kp = reinterpret_cast<unsigned long long *>(sl + (size_t)s * es);
+            const int64_t cur = (int64_t)*reinterpret_cast<volatile unsigned long long *>(kp);
+            if (cur == k) return (int)s;
+            if (cur == kEmpty) {
+                if (!insert) return -1;
+                const unsigned long long old = atomicCAS(kp, (unsigned long long)kEmpty, (unsigned long long)k);
+                if (old == (unsigned long long)kEmpty || (int64_t)old == k) return (int)s;
+            }
+            s = (s + 1) & smask;
+        }
+        return -1;
+    };
+    for (uint32_t j = lo + threadIdx.x; j < hi; j += kIxSliceBlock) {
+        const int s = find(pkeys[j], true);
+        if (s < 0) { info->failed = 1; continue; }
+        const uint32_t sub = prows[j] >> kSubLog2;
+        unsigned char *e = sl + (size_t)s * es;
+        if (ks) atomicAdd(reinterpret_cast<uint32_t *>(e + 16) + (sub >> 1), 1u << ((sub & 1u) * 16u));
+        else atomicAdd(&reinterpret_cast<DirHead *>(e)->total, 1u);
+    }
+    __syncthreads();
+    // totals and posting ranges: thread t owns the entries [t * per, (t + 1) * per)
+    const uint32_t per = se >= (uint32_t)kIxSliceBlock ? se / kIxSliceBlock : 1u;
+    const uint32_t e0 = threadIdx.x * per;
+    uint32_t mine = 0, used = 0;
+    if (e0 < se) {
+        for (uint32_t i = e0; i < e0 + per; ++i) {
+            DirHead *h = reinterpret_cast<DirHead *>(sl + (size_t)i * es);
+            uint32_t total = 0;
+            if (ks) {
+                const uint32_t *c = reinterpret_cast<const uint32_t *>(sl + (size_t)i * es + 16);
+                for (int w = 0; w < ks / 2; ++w) total += (c[w] & 0xffffu) + (c[w] >> 16);
+                h->total = total;
+            } else {
+                total = h->total;
+            }
+            mine += total;
+            used += h->key != kEmpty ? 1u : 0u;
+        }
+    }
+    {
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        const uint32_t incl = wave_scan_incl(mine);
+        const uint32_t dsum = wave_total(wave_scan_incl(used));
+        if (lane == 63) { s_w[wave] = incl; s_d[wave] = dsum; }
+        __syncthreads();
+        uint32_t before = 0, dall = 0;
+#pragma unroll
+        for (int w = 0; w < kIxSliceBlock / 64; ++w) { if (w < wave) before += s_w[w]; dall += s_d[w]; }
+        if (threadIdx.x == 0 && dall) atomicAdd(&info->n_distinct, dall);
+        uint32_t run = lo + before + incl - mine;
+        if (e0 < se) {
+            for (uint32_t i = e0; i < e0 + per; ++i) {
+                DirHead *h = reinterpret_cast<DirHead *>(sl + (size_t)i * es);
+                if (h->total) { h->base = run; run += h->total; }
+            }
+        }
+    }
+    __syncthreads();
+    unsigned char *gsl = dir + (size_t)part * se * es;           // this slice in the directory
+    {
+        const uint4 *s16 = reinterpret_cast<const uint4 *>(sl);
+        uint4 *g16 = reinterpret_cast<uint4 *>(gsl);
+        for (uint32_t i = threadIdx.x; i < se * (uint32_t)e16; i += kIxSliceBlock) g16[i] = s16[i];
+    }
+    __syncthreads();                                             // (the fill reads the counts back from there)
+    for (uint32_t j = lo + threadIdx.x; j < hi; j += kIxSliceBlock) {
+        const int s = find(pkeys[j], false);
+        if (s < 0) continue;                                     // only after a failed insert above
+        const uint32_t row = prows[j], sub = row >> kSubLog2;
+        unsigned char *e = sl + (size_t)s * es;
+        uint32_t p = reinterpret_cast<const DirHead *>(e)->base, k;
+        if (ks) {
+            const uint32_t sh = (sub & 1u) * 16u;
+            k = ((atomicSub(reinterpret_cast<uint32_t *>(e + 16) + (sub >> 1), 1u << sh) >> sh) & 0xffffu) - 1u;
+            const uint16_t *cn = reinterpret_cast<const uint16_t *>(gsl + (size_t)s * es + 16);
+            for (uint32_t c = 0; c * 8 < sub; ++c) {             // 16-byte pieces of the counts
+                const uint4 v = *reinterpret_cast<const uint4 *>(cn + c * 8);
+                const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int h = 0; h < 8; ++h)
+                    if (c * 8 + h < sub) p += (w[h >> 1] >> ((h & 1) * 16)) & 0xffffu;
+            }
+        } else {
+            k = atomicSub(&reinterpret_cast<DirHead *>(e)->total, 1u) - 1u;   // (the directory copy keeps the total)
+        }
+        post[p + k] = (uint16_t)(row & (uint32_t)(kSubRows - 1));
     }
 }
 
@@ -290,12 +599,13 @@ inline size_t ix_lds_bytes(int max_len, int spb) {
 // block's cycles were barrier waits.)
 template <bool HOSTOUT, bool TOP5>
 __device__ __forceinline__ void ix_lookup_body(
-    const unsigned char *__restrict__ dir, int dir_log2, int ks, const uint16_t *__restrict__ post,
+    const unsigned char *__restrict__ dir, int dir_bits, int ks, const uint16_t *__restrict__ post,
     const int32_t *__restrict__ ivid, int64_t n_indexed, int32_t n_sub, int32_t spb,
     const double *__restrict__ queries, const int64_t *__restrict__ q_offsets, int32_t max_len,
     int32_t min_match, const int32_t *__restrict__ exclude_ids, int32_t exclude_one, int32_t cap,
     int32_t *__restrict__ hits, int32_t *__restrict__ hits_n, int32_t ns, const QByVal &qv, const int q,
     const int group, const int n_groups) {
+    const int dir_log2 = dir_bits & 0xff;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t *bm1 = reinterpret_cast<uint32_t *>(smem);
     uint32_t *bm2 = bm1 + kIxWords;
@@ -344,7 +654,7 @@ __device__ __forceinline__ void ix_lookup_body(
     for (int i = threadIdx.x; i < kIxSlots; i += kIxBlock) reset_slot((uint32_t)i);
 
     // ---- directory: ONE probe per query position; the counts of this block's sub-indexes to LDS ----
-    const uint32_t dmask = (1u << dir_log2) - 1u;
+    const uint32_t smask = (1u << (dir_bits >> 8)) - 1u;   // probes wrap inside the directory slice
     const int es = 16 + 2 * ks;
     for (int i = threadIdx.x; i < n; i += kIxBlock) {
         uint32_t base = 0, total = 0;
@@ -358,7 +668,7 @@ __device__ __forceinline__ void ix_lookup_body(
                 const int64_t ek = (int64_t)(((uint64_t)(uint32_t)h.y << 32) | (uint32_t)h.x);
                 if (ek == k) { base = (uint32_t)h.z; total = (uint32_t)h.w; ent = e; break; }
                 if (ek == kEmpty) break;
-                s = (s + 1) & dmask;
+                s = (s & ~smask) | ((s + 1) & smask);
             }
         }
         uint16_t *el = e_len + (size_t)i * nsb;
@@ -717,12 +1027,12 @@ __device__ __forceinline__ void ix_lookup_body(
 
 template <bool HOSTOUT, bool TOP5>
 __global__ __launch_bounds__(kIxBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) void ts_match_index_kernel(
-    const unsigned char *__restrict__ dir, int dir_log2, int ks, const uint16_t *__restrict__ post,
+    const unsigned char *__restrict__ dir, int dir_bits, int ks, const uint16_t *__restrict__ post,
     const int32_t *__restrict__ ivid, int64_t n_indexed, int32_t n_sub, int32_t spb,
     const double *__restrict__ queries, const int64_t *__restrict__ q_offsets, int32_t max_len,
     int32_t min_match, const int32_t *__restrict__ exclude_ids, int32_t exclude_one, int32_t cap,
     int32_t *__restrict__ hits, int32_t *__restrict__ hits_n, int32_t ns, const QByVal qv) {
-    ix_lookup_body<HOSTOUT, TOP5>(dir, dir_log2, ks, post, ivid, n_indexed, n_sub, spb, queries, q_offsets, max_len,
+    ix_lookup_body<HOSTOUT, TOP5>(dir, dir_bits, ks, post, ivid, n_indexed, n_sub, spb, queries, q_offsets, max_len,
                                   min_match, exclude_ids, exclude_one, cap, hits, hits_n, ns, qv, (int)blockIdx.x,
                                   (int)blockIdx.y, (int)gridDim.y);
 }
@@ -734,14 +1044,14 @@ __global__ __launch_bounds__(kIxBlock) __attribute__((amdgpu_waves_per_eu(8, 8))
 // share nothing; two launches on one stream cost ~8 us more.
 template <bool TOP5>
 __global__ __launch_bounds__(kIxBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) void ts_find_fused_kernel(
-    const unsigned char *__restrict__ dir, int dir_log2, int ks, const uint16_t *__restrict__ post,
+    const unsigned char *__restrict__ dir, int dir_bits, int ks, const uint16_t *__restrict__ post,
     const int32_t *__restrict__ ivid, int64_t n_indexed, int32_t n_sub, int32_t spb, int32_t n_groups,
     const double *__restrict__ queries, const int64_t *__restrict__ q_offsets, int32_t max_len,
     int32_t min_match, int32_t exclude_one, int32_t *__restrict__ ix_hits, int32_t *__restrict__ ix_hits_n,
     const Row *__restrict__ delta_rows, int64_t n_delta, const int64_t *__restrict__ keys, int32_t s_log2,
     HostOut ho, const QByVal qv) {
     if ((int)blockIdx.x < n_groups)
-        ix_lookup_body<true, TOP5>(dir, dir_log2, ks, post, ivid, n_indexed, n_sub, spb, queries, q_offsets, max_len,
+        ix_lookup_body<true, TOP5>(dir, dir_bits, ks, post, ivid, n_indexed, n_sub, spb, queries, q_offsets, max_len,
                                    min_match, nullptr, exclude_one, 0, ix_hits, ix_hits_n, 1, qv, 0, (int)blockIdx.x,
                                    n_groups);
     else

@@ -81,6 +81,10 @@ struct RingSlot {
 // Inverted index over rows [0, n_main) as they were when it was built (tvz_index_kernels.h) plus
 // the DELTA table: the current entry of every row that was added or replaced since.  A match with
 // the index = index lookup (rows that are unchanged since the build) + a sweep of the delta table.
+constexpr int kIxMaxLds = 159 * 1024;               // gfx950: 160 KiB of LDS per workgroup, less the static part
+constexpr int64_t kIxSliceBytes = 32 * 1024;        // a directory slice, built by one block in LDS
+constexpr int64_t kIxSliceBytesMax = 128 * 1024;
+constexpr int kIxSliceLdsFloor = 40 * 1024;         // LDS asked for per slice block: at most 3 per CU, 40 KB stay free
 constexpr int64_t kIndexMinRows = 4096;           // a corpus grown by upserts gets its first index here
 constexpr int64_t kIndexMinDelta = 4096;          // rebuilt when the delta exceeds max(this, n_main / 8)
 
@@ -93,6 +97,8 @@ struct IndexBuf {
     DevBuf<int32_t> ivid;
     DevBuf<Row> drows;                // the delta table that goes with this generation
     int dir_log2 = 0;
+    int slice_log2 = 0;               // entries per directory slice (probing wraps inside a slice)
+    int dir_bits() const { return ix_dir_bits(dir_log2, slice_log2); }   // the kernels' argument
     int n_sub = 0;                    // sub-indexes of kSubRows rows
     int ks = 0;                       // uint16 counts per directory entry
     int64_t n_main = 0;               // rows [0, n_main) are indexed
@@ -108,7 +114,10 @@ struct Index {
     std::unordered_map<int64_t, int32_t> delta_slot;   // row index -> slot in buf[cur].drows
     // build scratch (only the builder touches it)
     IxBuildInfo *info = nullptr;      // device
-    DevBuf<uint32_t> fillc;           // per (entry, sub-index pair) fill cursors
+    DevBuf<uint32_t> fillc;           // per (entry, sub-index pair) fill cursors (unpartitioned build only)
+    DevBuf<int64_t> pkeys;            // partitioned build: the (key, row) pairs grouped by directory slice
+    DevBuf<uint32_t> prows;
+    DevBuf<uint32_t> pcnt;            // per slice: pair counts | first pair (+1 entry) | scatter cursors
     DevBuf<Row> snap_rows;            // the row table as it was when a background build started
     DevBuf<int32_t> dead_rows;        // rows upserted during that build (dead in the new generation)
     hipStream_t bstream = nullptr;    // background builds run here, not on the mutation stream
@@ -370,36 +379,77 @@ int build_kernels(tvz_corpus *c, IndexBuf &b, const Row *d_rows, int64_t n_rows,
     // with lookups, whose few blocks get a CU as soon as any of these retires
     const int64_t blocks = tvz::ceil_div(n_rows, kBlock / 64);
     IxBuildInfo info{};
+    int slice_log2 = 0;
     while (true) {
         TVZ_REQUIRE(log2 <= 30, "index directory would exceed 2^30 entries");
         const int64_t dn = (int64_t)1 << log2;
-        const int64_t fw = ks ? ks / 2 : 1;
         if (int rc = ensure(b.dir, dn * es, 0)) return rc;
-        if (int rc = ensure(ix.fillc, tvz::round_up(dn * fw, 4), 0)) return rc;
-        hipLaunchKernelGGL(ix_clear_kernel, dim3(2048), dim3(kBlock), 0, st, reinterpret_cast<uint4 *>(b.dir.p),
-                           (size_t)(dn * es / 16), es / 16, reinterpret_cast<uint4 *>(ix.fillc.p),
-                           (size_t)(tvz::round_up(dn * fw, 4) / 4), ix.info);
-        hipLaunchKernelGGL(ix_count_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, st, d_rows, n_rows, c->keys.p,
-                           b.dir.p, es, ks, log2, b.ivid.p, ix.info);
+        // Directory slices of ~32 KB (one block builds a slice in LDS; three such blocks leave room on
+        // a CU for a lookup's block); larger ones if the slices would otherwise outnumber what the
+        // partition kernels keep in LDS.  A directory of more than kIxMaxParts slices of 128 KB takes
+        // the unpartitioned build (count + fill over the whole directory: one slice).
+        slice_log2 = 6;
+        while (((int64_t)2 << slice_log2) * es <= kIxSliceBytes && slice_log2 < log2) ++slice_log2;
+        while ((dn >> slice_log2) > kIxMaxParts && ((int64_t)2 << slice_log2) * es <= kIxSliceBytesMax) ++slice_log2;
+        const int64_t n_parts = dn >> slice_log2;
+        const bool partitioned = n_parts <= kIxMaxParts;
+        if (!partitioned) slice_log2 = log2;
+        const int bits = ix_dir_bits(log2, slice_log2);
+        if (partitioned) {
+            const int64_t pairs_cap = std::max<int64_t>(keys_cap, live_keys);
+            if (int rc = ensure(ix.pkeys, pairs_cap, 0)) return rc;
+            if (int rc = ensure(ix.prows, pairs_cap, 0)) return rc;
+            if (int rc = ensure(ix.pcnt, 3 * (int64_t)kIxMaxParts + 4, 0)) return rc;
+            uint32_t *cnt = ix.pcnt.p, *start = cnt + kIxMaxParts, *cur = start + kIxMaxParts + 1;
+            // rows per block of the partition kernels: ~16 pairs per block and slice, so that a block's
+            // one reservation per slice is a small share of its work
+            const int64_t mean_len = std::max<int64_t>(1, live_keys / n_rows);
+            const int32_t rpb = (int32_t)std::min<int64_t>(4096, std::max<int64_t>(kBlock / 64 * 2, 16 * n_parts / mean_len));
+            const unsigned pblocks = (unsigned)tvz::ceil_div(n_rows, rpb);
+            const size_t plds = (size_t)n_parts * 8;
+            const size_t slds = std::max<size_t>(((size_t)es << slice_log2), (size_t)kIxSliceLdsFloor);
+            hipLaunchKernelGGL(ix_part_clear_kernel, dim3(4), dim3(kBlock), 0, st, cnt, (int)n_parts, ix.info);
+            hipLaunchKernelGGL(ix_partition_kernel<false>, dim3(pblocks), dim3(kBlock), plds, st, d_rows, n_rows, rpb,
+                               c->keys.p, bits, (int)n_parts, cnt, ix.pkeys.p, ix.prows.p, b.ivid.p);
+            hipLaunchKernelGGL(ix_part_scan_kernel, dim3(1), dim3(1024), 0, st, cnt, (int)n_parts, start, cur, ix.info);
+            // the scatter: rows worth about one staging area per block
+            const int32_t srpb = (int32_t)std::max<int64_t>(1, kIxStagePairs / mean_len);
+            const size_t sclds = (size_t)kIxStagePairs * 12 + ((size_t)3 * n_parts + 1) * 4;
+            hipLaunchKernelGGL(ix_scatter_kernel, dim3((unsigned)tvz::ceil_div(n_rows, srpb)), dim3(kIxScatterBlock), sclds,
+                               st, d_rows, n_rows, srpb, c->keys.p, bits, (int)n_parts, cur, ix.pkeys.p, ix.prows.p);
+            hipLaunchKernelGGL(ix_slice_build_kernel, dim3((unsigned)n_parts), dim3(kIxSliceBlock), slds, st,
+                               ix.pkeys.p, ix.prows.p, start, b.dir.p, es, ks, bits, b.post.p, ix.info);
+        } else {
+            const int64_t fw = ks ? ks / 2 : 1;
+            if (int rc = ensure(ix.fillc, tvz::round_up(dn * fw, 4), 0)) return rc;
+            hipLaunchKernelGGL(ix_clear_kernel, dim3(2048), dim3(kBlock), 0, st, reinterpret_cast<uint4 *>(b.dir.p),
+                               (size_t)(dn * es / 16), es / 16, reinterpret_cast<uint4 *>(ix.fillc.p),
+                               (size_t)(tvz::round_up(dn * fw, 4) / 4), ix.info);
+            hipLaunchKernelGGL(ix_count_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, st, d_rows, n_rows, c->keys.p,
+                               b.dir.p, es, ks, bits, b.ivid.p, ix.info);
+        }
         TVZ_HIP(hipGetLastError());
         TVZ_HIP(hipMemcpyAsync(ix.h_info, ix.info, sizeof(info), hipMemcpyDeviceToHost, st));
         if (int rc = wait_stream_polling(st, ix.build_ev)) return rc;
         info = *ix.h_info;
-        if (!info.failed && (int64_t)info.n_distinct * 2 <= dn) break;
-        ++log2;                                       // too crowded: twice the directory
+        if (!info.failed && (int64_t)info.n_distinct * 2 <= dn) {
+            if (partitioned) break;
+            hipLaunchKernelGGL(ix_offsets_kernel, dim3((unsigned)tvz::ceil_div(dn, kBlock)), dim3(kBlock), 0, st, b.dir.p,
+                               (size_t)dn, es, ks, ix.info);
+            hipLaunchKernelGGL(ix_fill_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, st, d_rows, n_rows, c->keys.p,
+                               b.dir.p, es, ks, bits, ix.fillc.p, b.post.p);
+            TVZ_HIP(hipGetLastError());
+            TVZ_HIP(hipMemcpyAsync(ix.h_info, ix.info, sizeof(info), hipMemcpyDeviceToHost, st));
+            if (int rc = wait_stream_polling(st, ix.build_ev)) return rc;
+            info = *ix.h_info;
+            break;
+        }
+        ++log2;                                       // too crowded (or a slice overflowed): twice the directory
     }
-    const int64_t dn = (int64_t)1 << log2;
-    hipLaunchKernelGGL(ix_offsets_kernel, dim3((unsigned)tvz::ceil_div(dn, kBlock)), dim3(kBlock), 0, st, b.dir.p,
-                       (size_t)dn, es, ks, ix.info);
-    hipLaunchKernelGGL(ix_fill_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, st, d_rows, n_rows, c->keys.p, b.dir.p,
-                       es, ks, log2, ix.fillc.p, b.post.p);
-    TVZ_HIP(hipGetLastError());
-    TVZ_HIP(hipMemcpyAsync(ix.h_info, ix.info, sizeof(info), hipMemcpyDeviceToHost, st));
-    if (int rc = wait_stream_polling(st, ix.build_ev)) return rc;
-    info = *ix.h_info;
     if ((int64_t)info.cursor != live_keys)
         return tvz::fail(TVZ_ERR_INVALID, "internal: index holds %u postings for %lld keys", info.cursor,
                          (long long)live_keys);
+    b.slice_log2 = slice_log2;
     b.n_sub = n_sub;
     b.ks = ks;
     b.dir_log2 = log2;
@@ -429,7 +479,8 @@ int build_index(tvz_corpus *c) {
     const IndexBuf &n = ix.buf[ix.cur];
     const int64_t dir_bytes = ((int64_t)1 << n.dir_log2) * ix_entry_bytes(n.ks);
     (void)ensure(o.dir, 2 * dir_bytes, 0);         // room for the directory to double once
-    (void)ensure(ix.fillc, 2 * (((int64_t)1 << n.dir_log2) * (n.ks ? n.ks / 2 : 1)), 0);
+    if (n.slice_log2 == n.dir_log2)                // the unpartitioned build's cursors
+        (void)ensure(ix.fillc, 2 * (((int64_t)1 << n.dir_log2) * (n.ks ? n.ks / 2 : 1)), 0);
     (void)ensure(o.post, n.post.cap, 0);
     (void)ensure(o.ivid, n.ivid.cap, 0);
     (void)ensure(o.drows, n.drows.cap, 0);
@@ -853,7 +904,6 @@ bool index_usable(const tvz_corpus *c, int32_t min_match) {
     return c->ix.valid && min_match >= 1 && min_match <= kTop;
 }
 
-constexpr int kIxMaxLds = 159 * 1024;               // gfx950: 160 KiB of LDS per workgroup, less the static part
 
 // How many sub-indexes one block walks.  A big batch gives every query ONE block (the query's keys
 // are probed once and the hit list needs no atomics); a small batch spreads a query over up to
@@ -882,7 +932,7 @@ int launch_index(tvz_corpus *c, const double *d_queries, const int64_t *d_q_offs
     const size_t lds = ix_lds_bytes(max_query_len, spb);
 #define TVZ_IX(TOP5)                                                                                        \
     hipLaunchKernelGGL((ts_match_index_kernel<HOSTOUT, TOP5>), dim3((unsigned)Q, (unsigned)groups),          \
-                       dim3(kIxBlock), lds, st, ix.dir.p, ix.dir_log2, ix.ks, ix.post.p, ix.ivid.p, ix.n_main, \
+                       dim3(kIxBlock), lds, st, ix.dir.p, ix.dir_bits(), ix.ks, ix.post.p, ix.ivid.p, ix.n_main, \
                        ix.n_sub, spb, d_queries, d_q_offsets, max_query_len, min_match, d_exclude_ids,        \
                        exclude_one, cap, d_hits, d_hits_n, ns, byval ? *byval : kNoQuery)
     if (min_match <= 2) TVZ_IX(false); else TVZ_IX(true);
@@ -1168,6 +1218,11 @@ static int tvz_corpus_create_impl(tvz_corpus **out, int device) {
                                 hipFuncAttributeMaxDynamicSharedMemorySize, kIxMaxLds))
     TVZ_IX_ATTR(false, false); TVZ_IX_ATTR(false, true); TVZ_IX_ATTR(true, false); TVZ_IX_ATTR(true, true);
 #undef TVZ_IX_ATTR
+    TVZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(ix_slice_build_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)kIxSliceBytesMax));
+    TVZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(ix_scatter_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize,
+                                kIxStagePairs * 12 + (3 * kIxMaxParts + 1) * 4));
     TVZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(ts_find_fused_kernel<false>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, kIxMaxLds));
     TVZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(ts_find_fused_kernel<true>),
@@ -1219,6 +1274,9 @@ static int tvz_corpus_destroy_impl(tvz_corpus *c) {
             if (b.drows.p) (void)hipFree(b.drows.p);
         }
         if (c->ix.fillc.p) (void)hipFree(c->ix.fillc.p);
+        if (c->ix.pkeys.p) (void)hipFree(c->ix.pkeys.p);
+        if (c->ix.prows.p) (void)hipFree(c->ix.prows.p);
+        if (c->ix.pcnt.p) (void)hipFree(c->ix.pcnt.p);
         if (c->ix.snap_rows.p) (void)hipFree(c->ix.snap_rows.p);
         if (c->ix.dead_rows.p) (void)hipFree(c->ix.dead_rows.p);
         if (c->ix.info) (void)hipFree(c->ix.info);
@@ -1624,7 +1682,7 @@ static int tvz_find_duplicates_impl(tvz_corpus *c, const double *h_query, int64_
                             static const QByVal kNoQuery = {};
 #define TVZ_FUSED(TOP5)                                                                                               \
     hipLaunchKernelGGL((ts_find_fused_kernel<TOP5>), dim3((unsigned)(n_sub + blocks)), dim3(kIxBlock), lds, s->stream, \
-                       ib.dir.p, ib.dir_log2, ib.ks, ib.post.p, ib.ivid.p, ib.n_main, ib.n_sub, 1, n_sub, dq, dqo,       \
+                       ib.dir.p, ib.dir_bits(), ib.ks, ib.post.p, ib.ivid.p, ib.n_main, ib.n_sub, 1, n_sub, dq, dqo,       \
                        (int32_t)n, min_match, excl, s->dh_ix_hits, s->dh_counts + kQ1MaxBlocks, span.p, span.n,         \
                        c->keys.p, s_log2, ho, by_value ? qv : kNoQuery)
                             if (min_match <= 2) TVZ_FUSED(false); else TVZ_FUSED(true);
