@@ -997,10 +997,14 @@ __device__ __forceinline__ void ix_lookup_body(
                     if ((int64_t)o < room) {
 #endif
                         int32_t *hp = out_hits + (int64_t)o * 3;
-                        hp[0] = vid[u];
-                        hp[1] = (int32_t)tcnt[k];
-                        hp[2] = TOP5 ? (int32_t)((uint32_t)(ttop[k] >> (12 * (min_match - 1))) & 0xfffu)
-                                     : (int32_t)(min_match == 1 ? m1[k] : m2[k]);
+                        const int32_t kth = TOP5 ? (int32_t)((uint32_t)(ttop[k] >> (12 * (min_match - 1))) & 0xfffu)
+                                                 : (int32_t)(min_match == 1 ? m1[k] : m2[k]);
+                        // streaming stores: 100 MB of hits per batch would otherwise push the posting
+                        // lines a block comes back to in its next sub-index out of the XCD's 4 MB L2
+                        // (HBM reads per launch 559 -> 507 MB, profiles/r3_match_pmc.txt)
+                        __builtin_nontemporal_store(vid[u], &hp[0]);
+                        __builtin_nontemporal_store((int32_t)tcnt[k], &hp[1]);
+                        __builtin_nontemporal_store(kth, &hp[2]);
                     }
                     ++o;
                 }
