@@ -13,7 +13,9 @@
 //          Probing is linear INSIDE a slice of 2^slice_log2 entries (kernel argument dir_bits).
 //   post : posting lists, one uint16 LOCAL row number per (row, key) pair; the postings of a key
 //          are contiguous, ordered by sub-index - the pieces a block reads one sub-index after the
-//          other lie next to each other in memory
+//          other lie next to each other in memory - and placed so that a key crosses no 128-byte
+//          line it need not cross (size classes, see ix_slice_count_kernel): a key of up to 64
+//          postings is ONE line, which the block's seven passes then find in the L2
 //   ivid : video_id per indexed row; -1 once the row was replaced by an upsert (its postings are
 //          then stale and ignored; the row's current content lives in the delta table, which the
 //          sweep kernels read).
@@ -38,8 +40,8 @@
 // directory is cut into SLICES of ~32 KB; an entry lives in the slice of its home slot (linear
 // probing wraps inside the slice).  The (key, row) pairs of all rows are partitioned by slice
 // (histogram, scan, LDS-staged scatter: whole lines leave the chip), then ONE block per slice makes
-// the slice's entries, counts and posting ranges in LDS and writes them out once.  No sort, no
-// global scatter: 0.8 ms for 100k rows / 19.9 M keys (count + fill over the whole directory, kept
+// the slice's entries, counts and posting places in LDS and writes them out once.  No sort, no
+// global scatter: 1.0 ms for 100k rows / 19.9 M keys (count + fill over the whole directory, kept
 // for directories of more than 4,096 slices: 2.7 ms).
 #pragma once
 #include "tvz_match_kernels.h"
@@ -390,21 +392,53 @@ __global__ __launch_bounds__(1024) void ix_part_scan_kernel(const uint32_t *__re
         cur[i] = run;
         run += c;
     }
-    if (threadIdx.x == 0) { start[n] = all; info->cursor = all; }
+    if (threadIdx.x == 0) { start[n] = all; if (info) info->cursor = all; }
 }
 
-// one block per slice: the slice's directory entries are made in LDS from the slice's pairs (find-or-
-// insert by 64-bit LDS CAS, the uint16 count of the (key, sub-index) bumped through its 32-bit word),
-// posting ranges handed out by a block scan (the slice's postings are exactly its pairs, so its first
-// posting is its first pair), the slice written to the directory as whole lines, and then every pair
-// takes a place in its (key, sub-index) piece by counting the LDS count DOWN (the copy in the
-// directory keeps the counts; a piece starts at base + the counts of the lower sub-indexes, read
-// from that copy).
-__global__ __launch_bounds__(kIxSliceBlock) void ix_slice_build_kernel(
+// ---- one block per slice -------------------------------------------------------------------------
+// ix_slice_count_kernel: the slice's directory entries are made in LDS from the slice's pairs (find-
+// or-insert by 64-bit LDS CAS, the uint16 count of the (key, sub-index) bumped through its 32-bit
+// word) and every key's postings get a place in the slice's posting range such that NO KEY CROSSES A
+// 128-BYTE LINE IT NEED NOT CROSS: keys are placed by size class - 1, 2, 4 .. 32 postings (a
+// power-of-two slot each, the class regions start on line boundaries) and "more than 32" (a whole
+// number of lines each).  A lookup touches a key's postings once per sub-index; with the keys packed
+// back to back a key of 45 postings (90 B) lay in 1.7 lines on average, and the lines a block comes
+// back to did not fit the XCD's L2.  The padding is bounded by 2x.  The slice goes to the directory
+// with bases RELATIVE to the slice's posting range; its padded size goes to ptot[slice].
+// ix_slice_fill_kernel (after a scan of ptot): the slice comes back into LDS, the bases become
+// absolute, and every pair takes a place in its (key, sub-index) piece by counting the LDS count
+// DOWN (the copy in the directory keeps the counts; a piece starts at base + the counts of the lower
+// sub-indexes, read from that copy).
+constexpr int kIxClasses = 7;              // posting-count classes: 2^0 .. 2^5, and whole lines
+constexpr uint32_t kIxLine = 64;           // postings per 128-byte line
+
+__device__ __forceinline__ int ix_find_lds(unsigned char *sl, int es, uint32_t smask, uint32_t home, int64_t k,
+                                           bool insert) {
+    uint32_t s = home & smask;
+    for (uint32_t probes = 0; probes <= smask; ++probes) {
+        unsigned long long *kp = reinterpret_cast<unsigned long long *>(sl + (size_t)s * es);
+        const int64_t cur = (int64_t)*reinterpret_cast<volatile unsigned long long *>(kp);
+        if (cur == k) return (int)s;
+        if (cur == kEmpty) {
+            if (!insert) return -1;
+            const unsigned long long old = atomicCAS(kp, (unsigned long long)kEmpty, (unsigned long long)k);
+            if (old == (unsigned long long)kEmpty || (int64_t)old == k) return (int)s;
+        }
+        s = (s + 1) & smask;
+    }
+    return -1;                             // the slice is full
+}
+
+__device__ __forceinline__ void ix_class_of(uint32_t total, int &cls, uint32_t &size) {
+    if (total > 32u) { cls = kIxClasses - 1; size = (total + kIxLine - 1u) & ~(kIxLine - 1u); }
+    else { cls = total <= 1u ? 0 : 32 - __clz((int)(total - 1u)); size = 1u << cls; }
+}
+
+__global__ __launch_bounds__(kIxSliceBlock) void ix_slice_count_kernel(
     const int64_t *__restrict__ pkeys, const uint32_t *__restrict__ prows, const uint32_t *__restrict__ start,
-    unsigned char *dir, int es, int ks, int dir_bits, uint16_t *__restrict__ post, IxBuildInfo *info) {
+    unsigned char *dir, int es, int ks, int dir_bits, uint32_t *__restrict__ ptot, IxBuildInfo *info) {
     extern __shared__ __attribute__((aligned(16))) unsigned char ix_slice_sh[];
-    __shared__ uint32_t s_w[kIxSliceBlock / 64], s_d[kIxSliceBlock / 64];
+    __shared__ uint32_t s_w[kIxClasses][kIxSliceBlock / 64], s_d[kIxSliceBlock / 64];
     unsigned char *sl = ix_slice_sh;
     const int dir_log2 = dir_bits & 0xff, slice_log2 = dir_bits >> 8;
     const uint32_t se = 1u << slice_log2, smask = se - 1u;
@@ -422,24 +456,9 @@ __global__ __launch_bounds__(kIxSliceBlock) void ix_slice_build_kernel(
             s16[i] = (i % (uint32_t)e16 == 0) ? head : make_uint4(0, 0, 0, 0);
     }
     __syncthreads();
-    // the entry of key k in this slice (INSERT: claimed if absent); -1: the slice is full
-    auto find = [&](int64_t k, bool insert) -> int {
-        uint32_t s = ix_slot(k, dir_log2) & smask;
-        for (uint32_t probes = 0; probes < se; ++probes) {
-            unsigned long long *kp = reinterpret_cast<unsigned long long *>(sl + (size_t)s * es);
-            const int64_t cur = (int64_t)*reinterpret_cast<volatile unsigned long long *>(kp);
-            if (cur == k) return (int)s;
-            if (cur == kEmpty) {
-                if (!insert) return -1;
-                const unsigned long long old = atomicCAS(kp, (unsigned long long)kEmpty, (unsigned long long)k);
-                if (old == (unsigned long long)kEmpty || (int64_t)old == k) return (int)s;
-            }
-            s = (s + 1) & smask;
-        }
-        return -1;
-    };
     for (uint32_t j = lo + threadIdx.x; j < hi; j += kIxSliceBlock) {
-        const int s = find(pkeys[j], true);
+        const int64_t k = pkeys[j];
+        const int s = ix_find_lds(sl, es, smask, ix_slot(k, dir_log2), k, true);
         if (s < 0) { info->failed = 1; continue; }
         const uint32_t sub = prows[j] >> kSubLog2;
         unsigned char *e = sl + (size_t)s * es;
@@ -447,10 +466,12 @@ __global__ __launch_bounds__(kIxSliceBlock) void ix_slice_build_kernel(
         else atomicAdd(&reinterpret_cast<DirHead *>(e)->total, 1u);
     }
     __syncthreads();
-    // totals and posting ranges: thread t owns the entries [t * per, (t + 1) * per)
+    // totals, then places by size class: thread t owns the entries [t * per, (t + 1) * per)
     const uint32_t per = se >= (uint32_t)kIxSliceBlock ? se / kIxSliceBlock : 1u;
     const uint32_t e0 = threadIdx.x * per;
-    uint32_t mine = 0, used = 0;
+    uint32_t mine[kIxClasses], used = 0;
+#pragma unroll
+    for (int c = 0; c < kIxClasses; ++c) mine[c] = 0;
     if (e0 < se) {
         for (uint32_t i = e0; i < e0 + per; ++i) {
             DirHead *h = reinterpret_cast<DirHead *>(sl + (size_t)i * es);
@@ -462,39 +483,94 @@ __global__ __launch_bounds__(kIxSliceBlock) void ix_slice_build_kernel(
             } else {
                 total = h->total;
             }
-            mine += total;
+            if (total) {
+                int cls;
+                uint32_t size;
+                ix_class_of(total, cls, size);
+#pragma unroll
+                for (int c = 0; c < kIxClasses; ++c) mine[c] += c == cls ? size : 0u;
+            }
             used += h->key != kEmpty ? 1u : 0u;
         }
     }
-    {
-        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-        const uint32_t incl = wave_scan_incl(mine);
-        const uint32_t dsum = wave_total(wave_scan_incl(used));
-        if (lane == 63) { s_w[wave] = incl; s_d[wave] = dsum; }
-        __syncthreads();
-        uint32_t before = 0, dall = 0;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t excl[kIxClasses];
 #pragma unroll
-        for (int w = 0; w < kIxSliceBlock / 64; ++w) { if (w < wave) before += s_w[w]; dall += s_d[w]; }
-        if (threadIdx.x == 0 && dall) atomicAdd(&info->n_distinct, dall);
-        uint32_t run = lo + before + incl - mine;
-        if (e0 < se) {
-            for (uint32_t i = e0; i < e0 + per; ++i) {
-                DirHead *h = reinterpret_cast<DirHead *>(sl + (size_t)i * es);
-                if (h->total) { h->base = run; run += h->total; }
+    for (int c = 0; c < kIxClasses; ++c) {
+        const uint32_t incl = wave_scan_incl(mine[c]);
+        if (lane == 63) s_w[c][wave] = incl;
+        excl[c] = incl - mine[c];
+    }
+    {
+        const uint32_t dsum = wave_total(wave_scan_incl(used));
+        if (lane == 63) s_d[wave] = dsum;
+    }
+    __syncthreads();
+    uint32_t region = 0;                   // first posting (relative to the slice) of the class regions, in turn
+#pragma unroll
+    for (int c = 0; c < kIxClasses; ++c) {
+        uint32_t before = 0, all = 0;
+#pragma unroll
+        for (int w = 0; w < kIxSliceBlock / 64; ++w) { const uint32_t a = s_w[c][w]; if (w < wave) before += a; all += a; }
+        excl[c] += before + region;
+        region += (all + kIxLine - 1u) & ~(kIxLine - 1u);
+    }
+    if (threadIdx.x == 0) {
+        uint32_t dall = 0;
+#pragma unroll
+        for (int w = 0; w < kIxSliceBlock / 64; ++w) dall += s_d[w];
+        if (dall) atomicAdd(&info->n_distinct, dall);
+        ptot[part] = region;
+    }
+    if (e0 < se) {
+        for (uint32_t i = e0; i < e0 + per; ++i) {
+            DirHead *h = reinterpret_cast<DirHead *>(sl + (size_t)i * es);
+            if (h->total) {
+                int cls;
+                uint32_t size;
+                ix_class_of(h->total, cls, size);
+#pragma unroll
+                for (int c = 0; c < kIxClasses; ++c)
+                    if (c == cls) { h->base = excl[c]; excl[c] += size; }
             }
         }
     }
     __syncthreads();
+    const uint4 *s16 = reinterpret_cast<const uint4 *>(sl);
+    uint4 *g16 = reinterpret_cast<uint4 *>(dir + (size_t)part * se * es);
+    for (uint32_t i = threadIdx.x; i < se * (uint32_t)e16; i += kIxSliceBlock) g16[i] = s16[i];
+}
+
+__global__ __launch_bounds__(kIxSliceBlock) void ix_slice_fill_kernel(
+    const int64_t *__restrict__ pkeys, const uint32_t *__restrict__ prows, const uint32_t *__restrict__ start,
+    const uint32_t *__restrict__ pstart, unsigned char *dir, int es, int ks, int dir_bits,
+    uint16_t *__restrict__ post) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char ix_slice_sh[];
+    unsigned char *sl = ix_slice_sh;
+    const int dir_log2 = dir_bits & 0xff, slice_log2 = dir_bits >> 8;
+    const uint32_t se = 1u << slice_log2, smask = se - 1u;
+    const uint32_t part = blockIdx.x;
+    const uint32_t lo = start[part], hi = start[part + 1];
+    const uint32_t first = pstart[part];                         // the slice's first posting
+    const int e16 = es / 16;
     unsigned char *gsl = dir + (size_t)part * se * es;           // this slice in the directory
     {
-        const uint4 *s16 = reinterpret_cast<const uint4 *>(sl);
+        uint4 *s16 = reinterpret_cast<uint4 *>(sl);
         uint4 *g16 = reinterpret_cast<uint4 *>(gsl);
-        for (uint32_t i = threadIdx.x; i < se * (uint32_t)e16; i += kIxSliceBlock) g16[i] = s16[i];
+        for (uint32_t i = threadIdx.x; i < se * (uint32_t)e16; i += kIxSliceBlock) {
+            uint4 v = g16[i];
+            if (i % (uint32_t)e16 == 0 && v.w) {                 // a head with postings: base becomes absolute
+                v.z += first;
+                g16[i] = v;
+            }
+            s16[i] = v;
+        }
     }
-    __syncthreads();                                             // (the fill reads the counts back from there)
+    __syncthreads();
     for (uint32_t j = lo + threadIdx.x; j < hi; j += kIxSliceBlock) {
-        const int s = find(pkeys[j], false);
-        if (s < 0) continue;                                     // only after a failed insert above
+        const int64_t key = pkeys[j];
+        const int s = ix_find_lds(sl, es, smask, ix_slot(key, dir_log2), key, false);
+        if (s < 0) continue;                                     // only after a failed insert in the count kernel
         const uint32_t row = prows[j], sub = row >> kSubLog2;
         unsigned char *e = sl + (size_t)s * es;
         uint32_t p = reinterpret_cast<const DirHead *>(e)->base, k;

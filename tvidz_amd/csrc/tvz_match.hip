@@ -361,8 +361,10 @@ int build_kernels(tvz_corpus *c, IndexBuf &b, const Row *d_rows, int64_t n_rows,
     const int n_sub = (int)tvz::ceil_div(n_rows, kSubRows);
     TVZ_REQUIRE(n_sub <= 4096, "too many rows for the index (%lld)", (long long)n_rows);
     const int ks = ix_ks(n_sub), es = ix_entry_bytes(ks);
-    // (+64: the lookup's last step reads up to 63 postings past the last list and discards them)
-    if (int rc = ensure(b.post, std::max<int64_t>(keys_cap, live_keys) + 64, 0)) return rc;
+    // (+64: the lookup's last step reads up to 63 postings past the last list and discards them; x2 +
+    // a line per size class and slice: the partitioned build pads keys to line-friendly places)
+    const int64_t post_cap = 2 * std::max<int64_t>(keys_cap, live_keys) + (int64_t)kIxMaxParts * kIxClasses * 64 + 64;
+    if (int rc = ensure(b.post, post_cap, 0)) return rc;
     if (int rc = ensure(b.ivid, std::max<int64_t>(rows_cap, n_rows), 0)) return rc;
     if (int rc = ensure(b.drows, delta_capacity(std::max<int64_t>(rows_cap, n_rows)), 0)) return rc;
     // ONE directory over the distinct keys of all rows, load <= 0.5.  Sized from a guess - a
@@ -392,15 +394,16 @@ int build_kernels(tvz_corpus *c, IndexBuf &b, const Row *d_rows, int64_t n_rows,
         while (((int64_t)2 << slice_log2) * es <= kIxSliceBytes && slice_log2 < log2) ++slice_log2;
         while ((dn >> slice_log2) > kIxMaxParts && ((int64_t)2 << slice_log2) * es <= kIxSliceBytesMax) ++slice_log2;
         const int64_t n_parts = dn >> slice_log2;
-        const bool partitioned = n_parts <= kIxMaxParts;
+        const bool partitioned = n_parts <= kIxMaxParts && post_cap < (int64_t)0xfffffff0LL;   // (32-bit posting offsets)
         if (!partitioned) slice_log2 = log2;
         const int bits = ix_dir_bits(log2, slice_log2);
         if (partitioned) {
             const int64_t pairs_cap = std::max<int64_t>(keys_cap, live_keys);
             if (int rc = ensure(ix.pkeys, pairs_cap, 0)) return rc;
             if (int rc = ensure(ix.prows, pairs_cap, 0)) return rc;
-            if (int rc = ensure(ix.pcnt, 3 * (int64_t)kIxMaxParts + 4, 0)) return rc;
+            if (int rc = ensure(ix.pcnt, 6 * (int64_t)kIxMaxParts + 8, 0)) return rc;
             uint32_t *cnt = ix.pcnt.p, *start = cnt + kIxMaxParts, *cur = start + kIxMaxParts + 1;
+            uint32_t *ptot = cur + kIxMaxParts, *pstart = ptot + kIxMaxParts, *scratch = pstart + kIxMaxParts + 1;
             // rows per block of the partition kernels: ~16 pairs per block and slice, so that a block's
             // one reservation per slice is a small share of its work
             const int64_t mean_len = std::max<int64_t>(1, live_keys / n_rows);
@@ -417,8 +420,12 @@ int build_kernels(tvz_corpus *c, IndexBuf &b, const Row *d_rows, int64_t n_rows,
             const size_t sclds = (size_t)kIxStagePairs * 12 + ((size_t)3 * n_parts + 1) * 4;
             hipLaunchKernelGGL(ix_scatter_kernel, dim3((unsigned)tvz::ceil_div(n_rows, srpb)), dim3(kIxScatterBlock), sclds,
                                st, d_rows, n_rows, srpb, c->keys.p, bits, (int)n_parts, cur, ix.pkeys.p, ix.prows.p);
-            hipLaunchKernelGGL(ix_slice_build_kernel, dim3((unsigned)n_parts), dim3(kIxSliceBlock), slds, st,
-                               ix.pkeys.p, ix.prows.p, start, b.dir.p, es, ks, bits, b.post.p, ix.info);
+            hipLaunchKernelGGL(ix_slice_count_kernel, dim3((unsigned)n_parts), dim3(kIxSliceBlock), slds, st,
+                               ix.pkeys.p, ix.prows.p, start, b.dir.p, es, ks, bits, ptot, ix.info);
+            hipLaunchKernelGGL(ix_part_scan_kernel, dim3(1), dim3(1024), 0, st, ptot, (int)n_parts, pstart, scratch,
+                               static_cast<IxBuildInfo *>(nullptr));
+            hipLaunchKernelGGL(ix_slice_fill_kernel, dim3((unsigned)n_parts), dim3(kIxSliceBlock), slds, st,
+                               ix.pkeys.p, ix.prows.p, start, pstart, b.dir.p, es, ks, bits, b.post.p);
         } else {
             const int64_t fw = ks ? ks / 2 : 1;
             if (int rc = ensure(ix.fillc, tvz::round_up(dn * fw, 4), 0)) return rc;
@@ -1218,7 +1225,9 @@ static int tvz_corpus_create_impl(tvz_corpus **out, int device) {
                                 hipFuncAttributeMaxDynamicSharedMemorySize, kIxMaxLds))
     TVZ_IX_ATTR(false, false); TVZ_IX_ATTR(false, true); TVZ_IX_ATTR(true, false); TVZ_IX_ATTR(true, true);
 #undef TVZ_IX_ATTR
-    TVZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(ix_slice_build_kernel),
+    TVZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(ix_slice_count_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)kIxSliceBytesMax));
+    TVZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(ix_slice_fill_kernel),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)kIxSliceBytesMax));
     TVZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(ix_scatter_kernel),
                                 hipFuncAttributeMaxDynamicSharedMemorySize,
