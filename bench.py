@@ -568,7 +568,13 @@ def main():
     # concurrently.  Behind the scene / e2e legs (which use the default stream and a dozen others
     # first) the two streams landed on queues 2 and 6 and the batches serialised: 0.45 ms per batch
     # instead of 0.34 (profiles/r3_shard_pipeline.txt).
-    match_leg = None if args.no_match else bench_match(args, rank, world, dev)
+    match_leg = None
+    if not args.no_match:
+        try:
+            match_leg = bench_match(args, rank, world, dev)
+        except Exception as e:            # the headline (scene) leg below must not die with the secondary one
+            match_leg = {"error": repr(e)}
+            print(f"[bench] corpus-match leg failed on rank {rank}: {e!r}", file=sys.stderr)
     torch.cuda.empty_cache()
 
     res = bench_scene(args, rank, world, dev)
