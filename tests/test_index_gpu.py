@@ -127,6 +127,35 @@ def test_corpus_larger_than_the_candidate_bitmap(dc):
             assert sorted(tuple(int(x) for x in h) for h in hits[qi, :n[qi]]) == exp
 
 
+def test_build_with_every_posting_size_class_and_a_first_directory_far_too_small(dc):
+    """The partitioned build: (a) nearly all keys are distinct, so the first directory (sized from
+    the key count) is crowded, slices overflow and the build repeats with twice the directory until
+    it fits; (b) key j = 1..130 is in exactly j rows - every posting size class (1, 2, 4 .. 32,
+    whole lines) with its boundaries, min_match 1 makes every single posting count; (c) one key is
+    in every row (a list of several lines in every slice-local layout)."""
+    C = 3000
+    rng = np.random.default_rng(11)
+    rows = []
+    nxt = 1000.0
+    for c in range(C):
+        own = nxt + np.arange(100) * 0.5                                # 100 keys nobody else has
+        nxt += 100.0
+        r = list(own) + [0.25]                                          # (c): in every row
+        r += [float(j) for j in range(1, 131) if c < j]                 # (b): key j in rows 0 .. j-1
+        rows.append((c + 1, r))
+    dc.upload(rows)
+    st = dc.index_stats()
+    assert st["indexed_rows"] == C and st["distinct_keys"] == C * 100 + 1 + 130
+    queries = [np.arange(1, 131, dtype=np.float64),                     # every class at once
+               np.array([0.25, 64.0, 65.0, 33.0, 32.0]),
+               np.array(rows[7][1][:100]),                              # a row's own keys
+               np.array([1.0, 2.0, 3.0, 4.0, 5.0, 8.0, 9.0, 16.0, 17.0])]
+    for mm in (1, 2, 3):
+        _check(dc, rows, queries, mm)
+    _check_single(dc, rows, queries[0], 1)
+    _check_single(dc, rows, queries[1], 2)
+
+
 def test_upserts_replace_indexed_rows_and_add_new_ones(dc):
     C = 1200
     ids, offs, keys = synth.synth_timestamp_corpus(C, seed=11, mean_len=60, dup_frac=0.05)
