@@ -72,6 +72,14 @@ int nccl_fail(const char *what, int rc) {
 struct tvz_comm {
     NcclComm comm = nullptr;
     int32_t n_ranks = 0, rank = 0, device = 0;
+    // The collectives of ONE communicator are issued from whichever stream the caller passes (two
+    // alternating streams in sharded.RcclShardedMatcher).  Their order is made explicit: a collective
+    // on a stream other than the previous one's waits for an event recorded behind the previous one,
+    // so the communicator never has two collectives in flight whatever RCCL does about stream changes.
+    std::mutex mu;
+    hipStream_t last_stream = nullptr;
+    bool any = false;
+    hipEvent_t last_ev = nullptr;       // created on first use
 };
 
 static int tvz_comm_unique_id_impl(void *out_id) {
@@ -113,6 +121,7 @@ static int tvz_comm_init_impl(tvz_comm **out, const void *unique_id, int32_t n_r
 static int tvz_comm_destroy_impl(tvz_comm *comm) {
     if (!comm) return TVZ_OK;
     if (comm->comm && g_api.ok) (void)g_api.CommDestroy(comm->comm);
+    if (comm->last_ev) (void)hipEventDestroy(comm->last_ev);
     delete comm;
     return TVZ_OK;
 }
@@ -139,8 +148,21 @@ static int tvz_match_sharded_impl(tvz_corpus *c, tvz_comm *comm, const double *d
     int prev = -1;
     (void)hipGetDevice(&prev);
     if (prev != comm->device) TVZ_HIP(hipSetDevice(comm->device));
-    const int grc = g_api.AllGather(local, gathered, count, kNcclInt32, comm->comm, st);
+    int grc = 0;
+    hipError_t herr = hipSuccess;
+    {
+        std::lock_guard<std::mutex> lk(comm->mu);
+        if (!comm->last_ev) herr = hipEventCreateWithFlags(&comm->last_ev, hipEventDisableTiming);
+        if (herr == hipSuccess && comm->any && comm->last_stream != st) herr = hipStreamWaitEvent(st, comm->last_ev, 0);
+        if (herr == hipSuccess) {
+            grc = g_api.AllGather(local, gathered, count, kNcclInt32, comm->comm, st);
+            if (!grc) herr = hipEventRecord(comm->last_ev, st);
+            comm->last_stream = st;
+            comm->any = true;
+        }
+    }
     if (prev >= 0 && prev != comm->device) (void)hipSetDevice(prev);
+    if (herr != hipSuccess) return tvz::fail(TVZ_ERR_HIP, "ordering the collective failed: %s", hipGetErrorString(herr));
     if (grc) return nccl_fail("ncclAllGather", grc);
     return tvz_topk_merge_ws(gathered, comm->n_ranks, Q, k, d_topk, d_totals, d_workspace, max_query_len, cap,
                              hip_stream);
