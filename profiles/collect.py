@@ -17,7 +17,7 @@ for name, out in (("bench.json", f"{tag}_bench.json"), ("predicted_scaling.json"
                   ("find_dup_latency.txt", f"{tag}_find_dup_latency.txt"), ("e2e_service.txt", f"{tag}_e2e_service.txt"),
                   ("match_ab.txt", f"{tag}_match_ab_raw.txt"), ("rebuild_latency.txt", f"{tag}_rebuild_latency.txt"),
                   ("ix_stamps.txt", f"{tag}_ix_stamps.txt"), ("scale_probe.txt", f"{tag}_scale_probe.txt"),
-                  ("fuzz_parity.txt", f"{tag}_fuzz_parity.txt")):
+                  ("fuzz_parity.txt", f"{tag}_fuzz_parity.txt"), ("rebuild_trace.txt", f"{tag}_rebuild_trace.txt")):
     p = os.path.join(src, name)
     if os.path.exists(p) and os.path.getsize(p):
         shutil.copy(p, os.path.join(dst, out))

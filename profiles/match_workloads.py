@@ -11,6 +11,8 @@ counter row can be attributed by kernel name alone:
      index  : C=100k x Q=4096, inverted-index lookup (ts_match_index_kernel)           tag C100000_Q4096
      index1 : C=100k x Q=1 lookup + find_duplicates latency                            tag C100000_Q1
      index1_5k : the same at C=5k                                                      tag C5000_Q1
+     rebuild: C=100k, `reps` x tvz_corpus_build_index after the upload (the upload's own build takes a
+              second pass at the size its count revealed; a rebuild is one pass) + one batch of 64 queries
    topk / shard8 take the index too (AUTO); `join`, `tile`, `q1_*` force the sweep kernels.
 Prints one JSON line with the event-timed median of the call."""
 import json
@@ -32,7 +34,7 @@ C, Q, algo = {"join": (100000, 4096, _lib.ALGO_JOIN), "q1_100k": (100000, 1, _li
               "q1_5k": (5000, 1, _lib.ALGO_Q1), "tile": (100000, 64, _lib.ALGO_TILE),
               "topk": (100000, 4096, _lib.ALGO_AUTO), "shard8": (100000, 4096, _lib.ALGO_AUTO),
               "index": (100000, 4096, _lib.ALGO_INDEX), "index1": (100000, 1, _lib.ALGO_INDEX),
-              "index1_5k": (5000, 1, _lib.ALGO_INDEX)}[which]
+              "index1_5k": (5000, 1, _lib.ALGO_INDEX), "rebuild": (100000, 64, _lib.ALGO_INDEX)}[which]
 ids, offs, keys = synth.synth_timestamp_corpus(C, seed=synth.CORPUS_SEED)
 queries = synth.synth_queries(ids, offs, keys, max(Q, 64), seed=synth.CORPUS_SEED + 1)
 dc = tc.DeviceCorpus(0)
@@ -41,6 +43,14 @@ if which == "shard8":          # rank 0's shard of an 8-way sharded corpus, the 
     dc.upload_csr(*sharded.shard_csr(ids, offs, keys, 0, 8))
 else:
     dc.upload_csr(ids, offs, keys)
+rebuild_ms = []
+if which == "rebuild":
+    torch.cuda.synchronize()
+    for _ in range(reps):
+        t = time.perf_counter()
+        dc.build_index()
+        rebuild_ms.append((time.perf_counter() - t) * 1e3)
+    reps = 3
 d_q, d_off, ml = tc.pack_queries(queries[:Q], dev)
 CAP = 16384 if Q > 1 else 4096
 hits = torch.empty((Q, CAP, 3), dtype=torch.int32, device=dev)
@@ -71,6 +81,9 @@ if which in ("q1_5k", "index1", "index1_5k"):     # find_duplicates takes the in
         lat.append(time.perf_counter() - t)
     res["find_duplicates_us"] = round(float(np.median(lat[20:])) * 1e6, 1)
     res["find_duplicates_p10_p90_us"] = [round(float(np.percentile(lat[20:], p)) * 1e6, 1) for p in (10, 90)]
+if rebuild_ms:
+    res["build_index_call_ms"] = {"median": round(float(np.median(rebuild_ms)), 3), "min": round(min(rebuild_ms), 3),
+                                  "note": "host to host: drains readers, builds, reads the status back twice"}
 res["index"] = dc.index_stats()
 rows, nkeys, _ = dc.stats()
 res["corpus_image_bytes"] = 16 * rows + 8 * nkeys

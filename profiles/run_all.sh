@@ -13,6 +13,7 @@ echo "== bench (un-profiled)";            python bench.py --steps 20 --warmup 5 
 echo "== scene kernel trace + FETCH/WRITE"; bash profiles/run_profile.sh $TAG > $OUT/run_profile.log 2>&1; echo rc=$?
 echo "== matcher trace + counters"
 for w in index index1 shard8 join q1_100k q1_5k tile; do bash profiles/pmc_match.sh $TAG $w >> $OUT/pmc_match.log 2>&1; echo "  $w done"; done
+echo "== index rebuild, 100k rows (kernel trace)"; bash profiles/trace_one.sh rebuild 10 > $OUT/rebuild_trace.txt 2>&1
 echo "== predicted scaling";              python profiles/predict_scaling.py 4096 2>/dev/null | tail -1 > $OUT/predicted_scaling.json; python profiles/predict_scaling.py 1024 2>/dev/null | tail -1 >> $OUT/predicted_scaling.json
 echo "== find_duplicates latency (C ABI, no Python)"
 bash profiles/fdl.sh > $OUT/find_dup_latency.txt 2>&1

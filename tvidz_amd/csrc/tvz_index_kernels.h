@@ -235,17 +235,13 @@ __global__ void ix_part_clear_kernel(uint32_t *__restrict__ hist, int n, IxBuild
     if (blockIdx.x == 0 && threadIdx.x == 0) { info->cursor = 0; info->n_distinct = 0; info->failed = 0; info->pad = 0; }
 }
 
-// a block takes `rpb` consecutive rows (a wave per row, in turns).  SCATTER = false: the slices'
-// pair counts (LDS histogram, one global add per block and non-empty slice) and the rows' video ids.
-// SCATTER = true: counts again, reserves the block's range of every slice with ONE atomic on the
-// slice's cursor (`gcnt` then holds the slices' running write positions) and writes the pairs.
-template <bool SCATTER>
+// the slices' pair counts and the rows' video ids: a block takes `rpb` consecutive rows (a wave per row,
+// in turns), counts in an LDS histogram and adds its non-zero counts to the global ones
 __global__ __launch_bounds__(kBlock) void ix_partition_kernel(
     const Row *__restrict__ rows, int64_t n_rows, int32_t rpb, const int64_t *__restrict__ keys, int dir_bits,
-    int n_parts, uint32_t *__restrict__ gcnt, int64_t *__restrict__ pkeys, uint32_t *__restrict__ prows,
-    int32_t *__restrict__ ivid) {
+    int n_parts, uint32_t *__restrict__ gcnt, int32_t *__restrict__ ivid) {
     extern __shared__ uint32_t ix_part_sh[];
-    uint32_t *hist = ix_part_sh, *base = ix_part_sh + n_parts;
+    uint32_t *hist = ix_part_sh;
     const int dir_log2 = dir_bits & 0xff, slice_log2 = dir_bits >> 8;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int i = threadIdx.x; i < n_parts; i += kBlock) hist[i] = 0;
@@ -254,41 +250,22 @@ __global__ __launch_bounds__(kBlock) void ix_partition_kernel(
     const int64_t r1 = r0 + rpb < n_rows ? r0 + rpb : n_rows;
     for (int64_t r = r0 + wave; r < r1; r += kBlock / 64) {
         const Row row = load_row(rows + r);
-        if (!SCATTER && lane == 0) ivid[r] = row.vid;
+        if (lane == 0) ivid[r] = row.vid;
         for (int i = lane; i < row.len; i += 64)
             atomicAdd(&hist[ix_slot(keys[row.off + i], dir_log2) >> slice_log2], 1u);
     }
     __syncthreads();
-    if (!SCATTER) {
-        for (int i = threadIdx.x; i < n_parts; i += kBlock)
-            if (hist[i]) atomicAdd(&gcnt[i], hist[i]);
-        return;
-    }
-    for (int i = threadIdx.x; i < n_parts; i += kBlock) {
-        const uint32_t c = hist[i];
-        base[i] = c ? atomicAdd(&gcnt[i], c) : 0u;
-        hist[i] = 0;
-    }
-    __syncthreads();
-    for (int64_t r = r0 + wave; r < r1; r += kBlock / 64) {
-        const Row row = load_row(rows + r);
-        for (int i = lane; i < row.len; i += 64) {
-            const int64_t k = keys[row.off + i];
-            const uint32_t p = ix_slot(k, dir_log2) >> slice_log2;
-            const uint32_t pos = base[p] + atomicAdd(&hist[p], 1u);
-            pkeys[pos] = k;
-            prows[pos] = (uint32_t)r;
-        }
-    }
+    for (int i = threadIdx.x; i < n_parts; i += kBlock)
+        if (hist[i]) atomicAdd(&gcnt[i], hist[i]);
 }
 
 // The scatter, staged: a block of 1024 threads takes rows worth ~kIxStagePairs pairs, counts them per
 // slice, gives every slice its LOCAL range in an LDS staging area (block scan over the slices) and
 // its GLOBAL range (one atomic per non-empty slice), drops the pairs into the staging area in slice
 // order, and then writes the staging area out with consecutive threads on consecutive pairs - the
-// pairs of one slice go out as one run of whole lines.  (Writing every pair to its slice directly,
-// ix_partition_kernel<true>, left ~2,000 partly written lines per block in flight - 67 MB over the
-// chip against 32 MB of L2 - and took 1.15 ms of a 1.6 ms build.)  Pairs beyond the staging area
+// pairs of one slice go out as one run of whole lines.  (Writing every pair to its slice directly
+// left ~2,000 partly written lines per block in flight - 67 MB over the chip against 32 MB of L2 -
+// and took 1.15 ms of a 1.6 ms build.)  Pairs beyond the staging area
 // (rows longer than expected) are written directly.
 constexpr int kIxScatterBlock = 1024;
 constexpr int kIxStagePairs = 8192;        // 96 KB of LDS: 8 B key + 4 B row

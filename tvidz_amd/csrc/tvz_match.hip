@@ -111,6 +111,7 @@ struct Index {
     bool valid = false;
     int64_t n_delta = 0;
     int64_t builds = 0;
+    int64_t hint_post = 0, hint_distinct = 0;   // postings / distinct keys of the last build (sizes the next directory)
     std::unordered_map<int64_t, int32_t> delta_slot;   // row index -> slot in buf[cur].drows
     // build scratch (only the builder touches it)
     IxBuildInfo *info = nullptr;      // device
@@ -371,11 +372,12 @@ int build_kernels(tvz_corpus *c, IndexBuf &b, const Row *d_rows, int64_t n_rows,
     // fingerprint corpus repeats its keys many times over (cuts sit on frame grids) - and doubled
     // while too crowded
     int log2 = 10;
-    while (((int64_t)1 << log2) < live_keys / 8) ++log2;
-    if (ix.valid && ix.now().n_post > 0) {
-        // the current generation knows how often this corpus repeats its keys: one count pass, no retry
-        const double guess = (double)ix.now().n_distinct * (double)live_keys / (double)ix.now().n_post * 1.25;
+    if (ix.hint_post > 0) {
+        // the last build knows how often this corpus repeats its keys: one pass, no retry
+        const double guess = (double)ix.hint_distinct * (double)live_keys / (double)ix.hint_post * 1.25;
         while ((double)((int64_t)1 << log2) < 2.0 * guess && log2 < 30) ++log2;
+    } else {
+        while (((int64_t)1 << log2) < live_keys / 8) ++log2;
     }
     // one row per wave and SHORT-LIVED blocks (no grid-stride loop): a background build shares the GPU
     // with lookups, whose few blocks get a CU as soon as any of these retires
@@ -410,11 +412,11 @@ int build_kernels(tvz_corpus *c, IndexBuf &b, const Row *d_rows, int64_t n_rows,
             const int64_t mean_len = std::max<int64_t>(1, live_keys / n_rows);
             const int32_t rpb = (int32_t)std::min<int64_t>(4096, std::max<int64_t>(kBlock / 64 * 2, 16 * n_parts / mean_len));
             const unsigned pblocks = (unsigned)tvz::ceil_div(n_rows, rpb);
-            const size_t plds = (size_t)n_parts * 8;
+            const size_t plds = (size_t)n_parts * 4;
             const size_t slds = std::max<size_t>(((size_t)es << slice_log2), (size_t)kIxSliceLdsFloor);
             hipLaunchKernelGGL(ix_part_clear_kernel, dim3(4), dim3(kBlock), 0, st, cnt, (int)n_parts, ix.info);
-            hipLaunchKernelGGL(ix_partition_kernel<false>, dim3(pblocks), dim3(kBlock), plds, st, d_rows, n_rows, rpb,
-                               c->keys.p, bits, (int)n_parts, cnt, ix.pkeys.p, ix.prows.p, b.ivid.p);
+            hipLaunchKernelGGL(ix_partition_kernel, dim3(pblocks), dim3(kBlock), plds, st, d_rows, n_rows, rpb,
+                               c->keys.p, bits, (int)n_parts, cnt, b.ivid.p);
             hipLaunchKernelGGL(ix_part_scan_kernel, dim3(1), dim3(1024), 0, st, cnt, (int)n_parts, start, cur, ix.info);
             // the scatter: rows worth about one staging area per block
             const int32_t srpb = (int32_t)std::max<int64_t>(1, kIxStagePairs / mean_len);
@@ -473,6 +475,8 @@ int build_kernels(tvz_corpus *c, IndexBuf &b, const Row *d_rows, int64_t n_rows,
     b.dir_log2 = log2;
     b.n_main = n_rows;
     b.n_post = info.cursor;
+    ix.hint_post = (int64_t)info.cursor;
+    ix.hint_distinct = (int64_t)info.n_distinct;
     b.n_distinct = info.n_distinct;
     return TVZ_OK;
 }
