@@ -176,7 +176,7 @@ int tvz_corpus_stats(tvz_corpus *c, int64_t *n_rows, int64_t *n_keys, int64_t *a
  * BACKGROUND - by the upserting thread that crosses the threshold, into a shadow generation that is
  * swapped in under the handle's lock; matches and other upserts go on meanwhile, no reader waits -
  * when a corpus grown by upserts reaches 4096 rows and when the delta table holds
- * max(4096, indexed rows / 8) rows.  Both generations are sized with the corpus reservation
+ * max(512, indexed rows / 256) rows.  Both generations are sized with the corpus reservation
  * (tvz_corpus_reserve / upload), so rebuilds allocate only once the corpus has outgrown it.
  * A corpus with >= 2^32 keys (per GPU) gets no index and is swept. */
 int tvz_corpus_build_index(tvz_corpus *c);
@@ -203,7 +203,7 @@ int tvz_corpus_index_stats(tvz_corpus *c, int64_t *n_indexed_rows, int64_t *n_de
 
 /* How the corpus is matched, PER CALL (there is no global knob); results never depend on it.
  *   AUTO : INDEX when the handle has one and min_match is 1..5.  Otherwise (and for the delta
- *          table): one query (or <= 4 against a small corpus) -> Q1; >= 64 queries x >= 3 M pairs
+ *          table): one query (or <= 4 against a small corpus) -> Q1; >= 64 queries x >= 2,100 + 340,000 / Q rows
  *          with min_match 1..2 -> JOIN; else TILE
  *   INDEX: posting-list lookup - one block per query walks its sub-indexes (a small batch: one block per
  *          query and sub-index) - + a sweep of the delta table (error if the handle has no index or

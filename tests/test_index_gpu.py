@@ -210,7 +210,8 @@ def test_upserts_replace_indexed_rows_and_add_new_ones(dc):
 
 def test_a_corpus_grown_by_upserts_gets_and_refreshes_its_index(dc):
     """add_timestamps only (db.py:43-64), as the service does: first index at 4096 rows, rebuilt
-    when the delta table (max(4096, rows / 8) entries) is full; matches are right at every stage."""
+    whenever the delta table has grown to max(512, rows / 256) entries; matches are right at every
+    stage."""
     rng = np.random.default_rng(21)
     grid = np.arange(1, 30_001) / 10.0
     rows = []
@@ -222,16 +223,19 @@ def test_a_corpus_grown_by_upserts_gets_and_refreshes_its_index(dc):
             ts += probe[:10].tolist()
         dc.upsert(v, ts)
         rows.append((v, ts))
-        if v in (100, 4095, 4096, 4097, 6000, 8191, 8193, 8499):
+        if v in (100, 4095, 4096, 4097, 4500, 4607, 4608, 4609, 6000, 8191, 8193, 8499):
             builds.append((v, dc.index_stats()))
             _check_single(dc, rows, probe, 2)
-            if v in (4097, 8499):
+            if v in (4097, 4609, 8499):
                 _check(dc, rows, [probe, np.asarray(rows[10][1])], 2, algo=_lib.ALGO_AUTO)
     st = dict(builds)
     assert st[100]["builds"] == 0 and st[4095]["builds"] == 0
     assert st[4096]["builds"] == 1 and st[4096]["indexed_rows"] == 4096 and st[4096]["delta_rows"] == 0
-    assert st[4097]["delta_rows"] == 1 and st[6000]["delta_rows"] == 6000 - 4096
-    assert st[8499]["builds"] == 2 and st[8499]["indexed_rows"] > 8000     # the delta filled up once
+    assert st[4097]["delta_rows"] == 1 and st[4500]["delta_rows"] == 4500 - 4096 and st[4607]["builds"] == 1
+    assert st[4608]["builds"] == 2 and st[4608]["indexed_rows"] == 4608 and st[4608]["delta_rows"] == 0
+    assert st[4609]["delta_rows"] == 1
+    assert st[6000]["builds"] == 4 and st[6000]["indexed_rows"] == 4096 + 3 * 512
+    assert st[8499]["builds"] == 9 and st[8499]["indexed_rows"] == 4096 + 8 * 512 and st[8499]["delta_rows"] == 8499 - 8192
 
 
 def test_lookups_stay_exact_while_upserts_rebuild_the_index(dc):

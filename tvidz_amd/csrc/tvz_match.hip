@@ -86,7 +86,7 @@ constexpr int64_t kIxSliceBytes = 32 * 1024;        // a directory slice, built 
 constexpr int64_t kIxSliceBytesMax = 128 * 1024;
 constexpr int kIxSliceLdsFloor = 40 * 1024;         // LDS asked for per slice block: at most 3 per CU, 40 KB stay free
 constexpr int64_t kIndexMinRows = 4096;           // a corpus grown by upserts gets its first index here
-constexpr int64_t kIndexMinDelta = 4096;          // rebuilt when the delta exceeds max(this, n_main / 8)
+constexpr int64_t kIndexMinDelta = 512;           // rebuilt when the delta exceeds max(this, n_main / 256)
 
 // One generation of the index's device image (tvz_index_kernels.h).  There are two: matches read
 // `cur`, a rebuild fills the other one (the SHADOW) while they keep running, and a swap under the
@@ -296,7 +296,12 @@ void index_drop(tvz_corpus *c) {
 
 // The delta table holds delta_capacity() entries; a rebuild is started when it is HALF full, so
 // upserts keep landing in the old generation's table while the new one is being built.
-int64_t delta_trigger(int64_t n_main) { return std::max<int64_t>(kIndexMinDelta, n_main / 8); }
+// A SMALL delta table: a build is ~1 ms per 20 M keys (9 ms for the unpartitioned build of a 1 M-row
+// corpus) and runs in the background - a few microseconds of GPU per upsert at this trigger - while
+// every batched match sweeps the whole delta table: 4096 queries against the 12,500 delta rows that
+// max(4096, n / 8) allowed at 100k rows cost more than their lookup in the index of 100,000
+// (profiles/r3_delta_probe.txt).
+int64_t delta_trigger(int64_t n_main) { return std::max<int64_t>(kIndexMinDelta, n_main / 256); }
 int64_t delta_capacity(int64_t n_main) { return 2 * delta_trigger(n_main) + 64; }
 
 // Order `st` behind every match that has been enqueued so far: the event-tracked batched calls by
@@ -778,13 +783,18 @@ WsLayout ws_layout(void *base, int32_t Q, int32_t max_query_len, int32_t cap, in
 constexpr int kQ1MaxQ = 1;
 constexpr int kQ1SmallRows = 20000;       // up to 4 queries also sweep one by one below this
 constexpr int kJoinMinQ = 64;
-constexpr int64_t kJoinMinPairs = 3000000;
+// The hash join pays ~80 us per tile of 1024 queries before it reads a row (table build + launches);
+// the LDS tile kernel pays per (tile of 16 queries, row).  Measured crossover
+// (profiles/r3_ab_small_corpus.txt; rows x Q in 64..12000 x 64..4096): the join wins from
+// ~2,100 rows for thousands of queries, ~3,400 rows for 256, ~7,400 rows for 64.
+constexpr int64_t kJoinMinRows = 2100;
+constexpr int64_t kJoinRowsTimesQ = 340000;
 
 int pick_algo(int32_t algo, int32_t Q, int64_t n_rows, int32_t max_query_len, int32_t min_match) {
     const bool join_legal = min_match >= 1 && min_match <= 2 && max_query_len > 0;
     if (algo == TVZ_ALGO_AUTO) {
         if (Q <= kQ1MaxQ || (Q <= 4 && n_rows <= kQ1SmallRows)) return TVZ_ALGO_Q1;
-        if (join_legal && Q >= kJoinMinQ && (int64_t)Q * n_rows >= kJoinMinPairs) return TVZ_ALGO_JOIN;
+        if (join_legal && Q >= kJoinMinQ && n_rows >= kJoinMinRows + kJoinRowsTimesQ / Q) return TVZ_ALGO_JOIN;
         return TVZ_ALGO_TILE;
     }
     if (algo == TVZ_ALGO_JOIN && !join_legal) return TVZ_ALGO_TILE;   // documented: min_match <= 2 only
