@@ -448,17 +448,15 @@ int build_kernels(tvz_corpus *c, IndexBuf &b, const Row *d_rows, int64_t n_rows,
         if (int rc = wait_stream_polling(st, ix.build_ev)) return rc;
         info = *ix.h_info;
         if (!info.failed && (int64_t)info.n_distinct * 2 <= dn) {
-            if (partitioned) {
-                // A directory guessed from the key count of a corpus that repeats its keys (the first
-                // build of a handle) comes out many times too large - 4 M entries for 442 k distinct
-                // keys at 100k rows: every probe of a lookup then misses the L2.  The partitioned build
-                // is cheap enough to run once more at the size the count has just revealed (load <= 0.5),
-                // if that is at least four times smaller.
-                int fit = 10;
-                while (((int64_t)1 << fit) < (int64_t)info.n_distinct * 2) ++fit;
-                if (!shrunk && fit + 1 < log2) { log2 = fit; shrunk = true; continue; }
-                break;
-            }
+            // A directory guessed from the key count of a corpus that repeats its keys (the first
+            // build of a handle) comes out many times too large - 4 M entries for 442 k distinct keys
+            // at 100k rows, 128 MB instead of 32 - and at 1 M rows too large for the partitioned
+            // build.  The count is cheap enough to run once more at the size it has just revealed
+            // (load <= 0.5), if that is at least four times smaller.
+            int fit = 10;
+            while (((int64_t)1 << fit) < (int64_t)info.n_distinct * 2) ++fit;
+            if (!shrunk && fit + 1 < log2) { log2 = fit; shrunk = true; continue; }
+            if (partitioned) break;
             hipLaunchKernelGGL(ix_offsets_kernel, dim3((unsigned)tvz::ceil_div(dn, kBlock)), dim3(kBlock), 0, st, b.dir.p,
                                (size_t)dn, es, ks, ix.info);
             hipLaunchKernelGGL(ix_fill_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, st, d_rows, n_rows, c->keys.p,
