@@ -35,6 +35,25 @@ for t in tickets:
     torch.cuda.synchronize()
     same = same and torch.equal(m2, merged) and torch.equal(t2, totals)
 out["pipelined_equal"] = bool(same)
+# the streaming form (bench.py): no wait on the caller's stream, results read after a host-side wait;
+# two different batches alternate, every ticket must carry ITS batch's answer
+queries_b = synth.synth_queries(ids, offs, keys, Q, seed=9, mean_len=60)
+d_qb, d_offb, max_len_b = tc.pack_queries(queries_b, dev)
+merged_b, totals_b = comm.match_sharded(dc, d_qb, d_offb, max_len_b, mm, 64, k, d_exclude_ids=excl)
+torch.cuda.synchronize()
+batches = [(d_q, d_off, max_len, merged, totals), (d_qb, d_offb, max_len_b, merged_b, totals_b)]
+stream_ok = not torch.equal(merged, merged_b)
+ticket, want = None, None
+for i in range(7):
+    b = batches[i % 2]
+    nxt = sm.submit(b[0], b[1], b[2], mm, excl, inputs_ready=True)
+    if ticket is not None:
+        m4, t4 = sm.finish(ticket, host=True)
+        stream_ok = stream_ok and torch.equal(m4, want[3]) and torch.equal(t4, want[4])
+    ticket, want = nxt, b
+m4, t4 = sm.finish(ticket, host=True)
+stream_ok = stream_ok and torch.equal(m4, want[3]) and torch.equal(t4, want[4])
+out["streaming_equal"] = bool(stream_ok)
 # a truncated shard list is signalled through the all-gather by a negative total
 m3, t3 = comm.match_sharded(dc, d_q, d_off, max_len, 0, 50, 8)
 torch.cuda.synchronize()

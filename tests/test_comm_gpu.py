@@ -39,4 +39,5 @@ def test_match_sharded_through_rccl_world_size_1():
         exp += [(-1, 0, NEVER)] * (k - len(exp))
         assert [tuple(r) for r in res["merged"][qi]] == exp, qi
     assert res["pipelined_equal"] is True
+    assert res["streaming_equal"] is True          # submit(inputs_ready=True) + finish(host=True), alternating batches
     assert res["overflow_totals"] == [-C] * Q          # min_match 0: every row hits, cap 50 overflows
