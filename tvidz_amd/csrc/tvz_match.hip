@@ -402,7 +402,8 @@ int build_kernels(tvz_corpus *c, IndexBuf &b, const Row *d_rows, int64_t n_rows,
         while (((int64_t)2 << slice_log2) * es <= kIxSliceBytes && slice_log2 < log2) ++slice_log2;
         while ((dn >> slice_log2) > kIxMaxParts && ((int64_t)2 << slice_log2) * es <= kIxSliceBytesMax) ++slice_log2;
         const int64_t n_parts = dn >> slice_log2;
-        const bool partitioned = n_parts <= kIxMaxParts && post_cap < (int64_t)0xfffffff0LL;   // (32-bit posting offsets)
+        const bool partitioned = n_parts <= kIxMaxParts && post_cap < (int64_t)0xfffffff0LL &&   // (32-bit posting offsets)
+                                 ((int64_t)es << slice_log2) <= kIxSliceBytesMax;   // (entries of > 2 KB: > 16 M rows)
         if (!partitioned) slice_log2 = log2;
         const int bits = ix_dir_bits(log2, slice_log2);
         if (partitioned) {
