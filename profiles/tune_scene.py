@@ -18,7 +18,10 @@ H, W = 1080, 1920
 dev = torch.device("cuda:0")
 lib = _lib.load()
 frames = torch.randint(0, 256, (T, H, W), dtype=torch.uint8, device=dev)
-variants = [(U, tc, nt) for U, tc, nt in itertools.product((1, 2, 4, 8), (64, 128, 256, 512), (0, 1))]
+if len(sys.argv) > 3 and sys.argv[3] == "tc":      # the time-chunk sweep at the widest strip: wave-count quantisation
+    variants = [(8, tc, 1) for tc in (128, 192, 256, 320, 384, 448, 512, 640, 832, 1280, 2560)]
+else:
+    variants = [(U, tc, nt) for U, tc, nt in itertools.product((1, 2, 4, 8), (64, 128, 256, 512), (0, 1))]
 sc = scene.SceneScorer(H, W, T, dev)       # workspace covers every shape
 times = {v: [] for v in variants}
 ref = None
