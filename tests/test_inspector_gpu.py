@@ -209,3 +209,38 @@ def test_container_time_base_and_real_pts_reach_the_fingerprint(tmp_path):
     finally:
         ins.close()
         store.close()
+
+
+def test_store_bulk_load_and_audit_against_the_device_corpus(tmp_path):
+    """f-2 on the real DeviceCorpus: rows written by plain SQL (another worker) are bulk-loaded into
+    HBM by reload_corpus (columns -> numpy -> tvz_corpus_upload), an in-place UPDATE is found by the
+    audit, and find_duplicates answers like the oracle's db.py:85-91 loop at every step."""
+    store = tdb.Store(f"sqlite:///{tmp_path}/t.db", device=0)
+    try:
+        rng = np.random.default_rng(4)
+        grid = np.arange(1, 4001) / 8.0
+        rows = [(v, sorted(rng.choice(grid, size=int(rng.integers(5, 60)), replace=False).tolist())) for v in range(1, 301)]
+        rows[41] = (42, [])                                        # an empty fingerprint
+        s = store.SessionLocal()
+        try:
+            for v, ts in rows:
+                s.add(tdb.VideoTimestamps(video_id=v, timestamps=ts))
+            s.commit()
+        finally:
+            s.close()
+        assert store.find_duplicates(rows[7][1], 2) == []            # the mirror has not seen them yet
+        assert store.sync_if_stale() is True                       # census: rows appeared -> bulk load
+        for q, mm in ((rows[7][1], 2), (rows[100][1][:9], 3), (grid[:200].tolist(), 2)):
+            assert store.find_duplicates(q, mm) == sorted(oracle.find_duplicates_py(rows, q, mm))
+        s = store.SessionLocal()
+        try:
+            s.query(tdb.VideoTimestamps).filter_by(video_id=8).first().timestamps = [0.125, 0.25, 0.375]
+            s.commit()
+        finally:
+            s.close()
+        rows[7] = (8, [0.125, 0.25, 0.375])
+        assert store.sync_if_stale() is False and store.audit() == 1
+        for q, mm in (([0.125, 0.25, 0.375], 2), (grid[:200].tolist(), 2)):
+            assert store.find_duplicates(q, mm) == sorted(oracle.find_duplicates_py(rows, q, mm))
+    finally:
+        store.close()
