@@ -1,0 +1,55 @@
+"""The shape of bench.py's one JSON line, checked on the line the final build printed on the GPU box
+(profiles/r3_bench.json): the driver's contract fields, the roofline and cpu_baseline objects, and
+the arithmetic that ties them together.  (bench.py itself needs a GPU: tests/test_abi.py checks that
+it refuses to run without one.)"""
+import json
+import os
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _line():
+    with open(os.path.join(ROOT, "profiles", "r3_bench.json")) as f:
+        lines = [ln for ln in f.read().splitlines() if ln.strip()]
+    assert len(lines) == 1, "bench.py prints ONE line on stdout"
+    return json.loads(lines[0])
+
+
+def test_driver_contract_fields():
+    d = _line()
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+              "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["unit"] == "frames/s" and d["higher_is_better"] is True and d["scaling"] == "weak"
+    assert d["dtype"] == "u8" and d["data"] == "synthetic" and d["vs_baseline"] is None
+    assert "workload" in d["config"] and "model" not in d["config"]
+    # value = frames of all ranks per second of the timed region
+    frames = d["n_gpus"] * d["config"]["frames_per_gpu"] * d["steps"]
+    assert abs(d["value"] - frames / (d["ms_per_step"] * 1e-3 * d["steps"])) / d["value"] < 1e-6
+
+
+def test_roofline_and_cpu_baseline_objects():
+    d = _line()
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    # achieved = algorithmic bytes per launch / the kernel's average launch duration
+    assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 1e9) / r["achieved"] < 1e-6
+    assert r["algorithmic_bytes_per_launch"] == (d["config"]["frames_per_gpu"] - 1) * 1080 * 1920
+    # measured traffic (committed counter pass) is what the kernel needs and no more
+    assert r["traffic"] is None or 1.0 <= r["traffic"] / r["algorithmic_bytes_per_launch"] < 1.05
+    assert "traffic_source" in r
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["unit"] == "frames/s" and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
+    assert c["agrees_with_gpu"] is True and c["single_core"]["cores"] == 1
+
+
+def test_secondary_objects():
+    d = _line()
+    m = d["match"]
+    assert m["unit"] == "pairs/s" and m["corpus_videos"] == 100000 and m["queries_per_batch"] == 4096
+    assert abs(m["value"] - m["corpus_videos"] * m["queries_per_batch"] / (m["ms_per_batch"] * 1e-3)) / m["value"] < 1e-6
+    assert m["roofline"]["bound"] == "hbm" and 0 < m["roofline"]["frac"] < 1 and m["queries_with_overflowed_shard_lists"] == 0
+    assert "shard8_roofline" in m and "config2" in m
+    assert d["config0"]["gpu"]["cuts_equal_cpu"] is True
+    assert d["e2e"]["all_done"] is True and d["h2d"]["GBps"] > 0
