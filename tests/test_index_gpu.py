@@ -103,9 +103,10 @@ def test_more_candidates_than_the_lds_table_holds(dc):
     _check_single(dc, rows, queries[4], 1)
 
 
-def test_corpus_larger_than_the_candidate_bitmap(dc):
-    """> 2^17 rows: rows share bits of the seen-once / seen-twice bitmaps; counts stay exact."""
-    C = 150_000
+@pytest.mark.parametrize("C", [150_000, 300_000])
+def test_corpus_larger_than_the_candidate_bitmap(dc, C):
+    """> 2^17 rows: rows share bits of the seen-once / seen-twice bitmaps; counts stay exact.
+    (10 and 19 sub-indexes: directory entries of 48 and 64 bytes, slices of 512 entries.)"""
     rng = np.random.default_rng(5)
     alphabet = np.arange(1, 40_001) / 4.0
     lens = rng.integers(2, 6, size=C)
@@ -117,13 +118,14 @@ def test_corpus_larger_than_the_candidate_bitmap(dc):
     ids2, offs2, keys2 = ids, offs, keys                              # rows may repeat a key: still a set
     queries = [rng.choice(alphabet, size=n, replace=False) for n in (50, 400, 3000)]
     d_q, d_off, max_len = tc.pack_queries(queries, DEV)
+    cap = 60000 * (C // 150_000)
     for mm in (1, 2, 3):
-        hits, n = dc.match(d_q, d_off, max_len, mm, 60000, algo=_lib.ALGO_INDEX)
+        hits, n = dc.match(d_q, d_off, max_len, mm, cap, algo=_lib.ALGO_INDEX)
         torch.cuda.synchronize()
         hits, n = hits.cpu().numpy(), n.cpu().numpy()
         for qi, q in enumerate(queries):
             exp = _expected(ids2, offs2, keys2, q, mm)
-            assert n[qi] == len(exp) <= 60000
+            assert n[qi] == len(exp) <= cap
             assert sorted(tuple(int(x) for x in h) for h in hits[qi, :n[qi]]) == exp
 
 
