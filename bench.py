@@ -483,16 +483,20 @@ def bench_e2e(dev, n_uploads: int = 8, n_frames: int = 256):
         ins = insp.Inspector(store, device=str(dev), frame_source=lambda b, k, f, u: (feeder.Y4MReader(files[k]), None),
                              batch=256, max_workers=n_uploads)
         [f.result() for f in [ins.submit("videos", k) for k in files]]          # warm-up: slots, scorers, SQL
-        store.clear()
-        store.corpus.upload_csr(ids + 100000, offs, keys)
-        t0 = time.perf_counter()
-        res = [f.result() for f in [ins.submit("videos", k) for k in files]]
-        dt = time.perf_counter() - t0
-        ok = all(r["status"] == "done" for r in res)
+        ok, dts = True, []
+        for _ in range(3):               # three timed passes, the median reported: a 0.15 s run is at the host's mercy
+            store.clear()
+            store.corpus.upload_csr(ids + 100000, offs, keys)
+            t0 = time.perf_counter()
+            res = [f.result() for f in [ins.submit("videos", k) for k in files]]
+            dts.append(time.perf_counter() - t0)
+            ok = ok and all(r["status"] == "done" for r in res)
+        dt = float(np.median(dts))
         ins.close()
         store.close()
         return {"value": n_uploads * n_frames / dt, "unit": "frames/s", "uploads": n_uploads, "frames_per_upload": n_frames,
                 "height": H, "width": W, "all_done": ok, "GBps_luma": n_uploads * n_frames * FRAME_BYTES / dt / 1e9,
+                "passes_s": [round(x, 4) for x in dts],
                 "note": "whole Python driver, PCIe-inclusive, files in RAM, no decoder; short clips: per-upload set-up "
                         "(SQL insert, reader thread, first slot) is inside the wall time.  profiles/r3_e2e_service.txt: "
                         "16 / 64 uploads x 512 frames 24 / 31 k fps (H2D bound 27.6 k at one copy in flight), 64 x 4K 5.6-5.8 k fps"}
