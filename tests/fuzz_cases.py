@@ -77,8 +77,8 @@ def run(seconds: float = 60.0, seed: int = 12345, max_cases: int = 0, device: st
             cap = int(rng.choice([1, 5, max(C, 1)]))
             mode = int(rng.choice([_lib.ALGO_AUTO, _lib.ALGO_AUTO, _lib.ALGO_INDEX, _lib.ALGO_Q1, _lib.ALGO_TILE,
                                    _lib.ALGO_JOIN]))
-            if mode == _lib.ALGO_INDEX and not 1 <= mm <= 5:
-                mode = _lib.ALGO_AUTO              # the index answers min_match 1..5 only (an error otherwise)
+            if mode == _lib.ALGO_INDEX and mm < 1:
+                mode = _lib.ALGO_AUTO              # the index answers min_match >= 1 only (an error otherwise)
             d_q, d_off, ml = tc.pack_queries(queries, dev)
             d_ex = torch.tensor(excl, dtype=torch.int32, device=dev) if excl is not None else None
             hits, n = dc.match(d_q, d_off, ml, mm, cap, d_exclude_ids=d_ex, algo=mode)

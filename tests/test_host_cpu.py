@@ -329,7 +329,7 @@ def test_sync_replays_rows_of_uploads_that_raced_the_reload(store):
     a = store.add_video("a.mp4")
     store.add_timestamps(a.id, [1.0, 2.0])
     b = store.add_video("b.mp4")
-    store.flush = lambda video_id=None: None            # the race: the writer has not committed b yet
+    store._wait_write_behind = lambda: None             # the race: the writer has not committed b yet
     with store._wb_cv:
         store._pending[b.id] = [8.0, 9.0]               # queued ...
         store._inflight = {777: [3.0]}                   # ... and one batch being committed
@@ -372,6 +372,113 @@ def test_audit_finds_rows_updated_in_place_by_another_writer(store):
     assert store.audit() == 0 and (b.id, [10.0, 11.0, 12.0]) in store.corpus.rows
     with store._wb_cv:
         store._pending.clear()
+
+
+def test_audit_and_sync_take_their_locks_in_one_order(store):
+    """audit() took write lock -> mirror lock, sync_if_stale mirror lock -> write lock; with
+    another writer adding rows (stale census) AND updating rows in place (audit mismatch) the two
+    deadlocked and the upload hung inside analyze_file.  Both run here, many times, against a table
+    that keeps changing behind the store's back; every thread must come back."""
+    vids = [store.add_video(f"{i}.mp4") for i in range(6)]
+    for i, v in enumerate(vids):
+        store.add_timestamps(v.id, [float(i), float(i) + 0.5])
+    stop = threading.Event()
+    errors = []
+
+    def other_writer():
+        n = 0
+        while not stop.is_set():
+            s = store.SessionLocal()
+            try:
+                with store._sql_write:
+                    row = s.query(tdb.VideoTimestamps).filter_by(video_id=vids[n % 6].id).first()
+                    row.timestamps = [100.0 + n, 200.0 + n]                 # in place: only the audit sees it
+                    if n % 3 == 0:
+                        v = tdb.Video(filename=f"ext{n}.mp4")
+                        s.add(v); s.flush()
+                        s.add(tdb.VideoTimestamps(video_id=v.id, timestamps=[float(n)]))   # a new row: stale census
+                    s.commit()
+            except Exception as e:                      # pragma: no cover - reported below
+                errors.append(e)
+            finally:
+                s.close()
+            n += 1
+
+    def loop(fn):
+        try:
+            for _ in range(60):
+                fn()
+        except Exception as e:                          # pragma: no cover
+            errors.append(e)
+
+    w = threading.Thread(target=other_writer, daemon=True)
+    t1 = threading.Thread(target=loop, args=(store.audit,), daemon=True)
+    t2 = threading.Thread(target=loop, args=(store.sync_if_stale,), daemon=True)
+    t3 = threading.Thread(target=loop, args=(lambda: store.add_timestamps_async(vids[0].id, [1.0, 2.0]),), daemon=True)
+    for t in (w, t1, t2, t3):
+        t.start()
+    for t in (t1, t2, t3):
+        t.join(timeout=60)
+    stop.set()
+    w.join(timeout=10)
+    assert not any(t.is_alive() for t in (t1, t2, t3)), "audit() and sync_if_stale() deadlocked"
+    assert not errors, errors
+    store.flush()
+
+
+def test_audit_with_several_sql_rows_per_video(store):
+    """video_timestamps has no UNIQUE(video_id) (db.py:22-27) and find_duplicates reads every row
+    (db.py:83-91).  A digest per VIDEO saw a mismatch on each of a video's rows in turn, on every
+    pass, and its upsert replaced only the first device row (mirror B,B for SQL A,B).  Digests are per
+    row id; a changed row of a multi-row video marks the mirror dirty and the reload keeps both."""
+    a = store.add_video("a.mp4")
+    store.add_timestamps(a.id, [1.0, 2.0])
+    s = store.SessionLocal()
+    try:
+        s.add(tdb.VideoTimestamps(video_id=a.id, timestamps=[5.0, 6.0])); s.commit()      # an older writer's second row
+    finally:
+        s.close()
+    assert store.sync_if_stale() is True
+    assert sorted(store.corpus.rows) == [(a.id, [1.0, 2.0]), (a.id, [5.0, 6.0])]
+    assert store.audit() == 0 and store.audit() == 0                  # two rows of one video: no phantom mismatch
+    s = store.SessionLocal()
+    try:
+        s.query(tdb.VideoTimestamps).filter_by(video_id=a.id).order_by(tdb.VideoTimestamps.id.desc()).first() \
+            .timestamps = [5.0, 7.0]
+        s.commit()
+    finally:
+        s.close()
+    assert store.audit() == 1 and store._dirty                         # not upserted over the FIRST row
+    assert store.audit() == 0 and store.audit_repairs == 1             # ... and not found again
+    assert store.sync_if_stale() is True
+    assert sorted(store.corpus.rows) == [(a.id, [1.0, 2.0]), (a.id, [5.0, 7.0])]
+    assert store.find_duplicates([5.0, 7.0], 2) == [(a.id, 2)]
+
+
+def test_sync_leaves_a_failed_write_to_the_upload_that_owns_it(store):
+    """sync_if_stale() called flush(), which raised the first write-behind error of ANY
+    upload and cleared the rest - an unrelated upload went `status: error` and the owner reported
+    `done` with no SQL row.  The error now waits for its owner."""
+    a, b = store.add_video("a.mp4"), store.add_video("b.mp4")
+    real = store._write_timestamps_sql
+    fails = {"n": store._wb_retries}
+
+    def flaky(session, vid, ts):
+        if fails["n"] > 0:
+            fails["n"] -= 1
+            raise RuntimeError("connection reset")
+        return real(session, vid, ts)
+    store._write_timestamps_sql = flaky
+    store.add_timestamps_async(b.id, [5.0, 6.0])
+    deadline = time.time() + 10
+    while time.time() < deadline and b.id not in store._wb_errors:
+        time.sleep(0.01)
+    assert store._dirty
+    assert store.sync_if_stale() is True                # another upload's census: no error raised here
+    with pytest.raises(RuntimeError, match="connection reset"):
+        store.flush(b.id)                               # the owner gets it, once
+    store.flush(b.id)
+    store.flush(a.id)
 
 
 def test_audit_thread_repairs_in_the_background(tmp_path):

@@ -1,7 +1,7 @@
 """GPU parity of the inverted index (tvz_index_kernels.h) against the oracle's restatement of
 db.find_duplicates (inspector/db.py:76-94) and against the sweep kernels: lookup + delta sweep must
 return exactly what a full sweep returns - bit-exact (video_id, count, kth) triples - for every
-min_match the index serves (1..5), through upserts that replace indexed rows, new rows, automatic
+min_match the index serves (>= 1), through upserts that replace indexed rows, new rows, automatic
 rebuilds, corpora larger than the candidate bitmap, and queries with more candidates than the LDS
 table holds."""
 import numpy as np
@@ -74,10 +74,13 @@ def test_index_equals_oracle_and_sweeps(dc, C, mean_len, Q):
         for q in queries[:4]:
             _check_single(dc, rows, q, mm)
             _check_single(dc, rows, q, mm, excl=excl[0])
-    for mm in (0, 6):                                                 # not the index's: refused / swept
-        with pytest.raises(RuntimeError, match="min_match 1..5"):
-            _check(dc, rows, queries, mm)
-        _check(dc, rows, queries, mm, algo=_lib.ALGO_AUTO)
+    with pytest.raises(RuntimeError, match="min_match >= 1"):        # every row is a hit: a sweep's job
+        _check(dc, rows, queries, 0)
+    _check(dc, rows, queries, 0, algo=_lib.ALGO_AUTO)
+    for mm in (6, 9, 40):                                             # count-only pass B + the kth fix-up walk
+        _check(dc, rows, queries, mm)
+        _check(dc, rows, queries, mm, excl=excl, algo=_lib.ALGO_AUTO)
+        _check(dc, rows, queries, mm, cap=3)
 
 
 def test_more_candidates_than_the_lds_table_holds(dc):

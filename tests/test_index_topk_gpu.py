@@ -1,0 +1,186 @@
+"""GPU parity of the lookup that keeps the per-shard top-k itself (ts_match_index_topk_kernel: the path
+tvz_match_topk / tvz_match_sharded take on an indexed corpus) against the oracle's restatement of
+db.find_duplicates (inspector/db.py:76-94) ordered as the streaming verdict needs it (earliest prefix
+first, inspector/app.py:238-245: ascending kth, then video_id), and against the unfused pipeline
+(tvz_match -> tvz_topk_shard).  Bit-exact rows, totals and padding."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle
+from tvidz_amd import _lib, corpus as tc, synth
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+NEVER = tc.KTH_NEVER
+
+
+@pytest.fixture()
+def dc():
+    c = tc.DeviceCorpus(0)
+    yield c
+    c.close()
+
+
+def _expected_rows(rows, queries, mm, excl=None):
+    ids, offs, keys = tc.rows_to_csr(rows)
+    out = []
+    for qi, q in enumerate(queries):
+        cnt, kth = oracle.match_kth_csr(np.asarray(q, dtype=np.float64), offs, keys, mm)
+        out.append([(int(ids[c]), int(cnt[c]), int(kth[c])) for c in range(len(ids))
+                    if cnt[c] >= mm and (excl is None or ids[c] != excl[qi])])
+    return out
+
+
+def _check_topk(dc, exp_rows, queries, mm, k, cap, excl=None, algo=_lib.ALGO_AUTO):
+    d_q, d_off, max_len = tc.pack_queries(queries, DEV)
+    Q = len(queries)
+    d_ex = torch.tensor(excl, dtype=torch.int32, device=DEV) if excl is not None else None
+    ws = torch.empty(tc.workspace_bytes(Q, max_len, cap, k), dtype=torch.uint8, device=DEV)
+    out = dc.match_topk(d_q, d_off, max_len, mm, cap, k, d_exclude_ids=d_ex, workspace=ws, algo=algo)
+    torch.cuda.synchronize()
+    out = out.cpu().numpy()
+    for qi in range(Q):
+        rows = exp_rows[qi]
+        assert tuple(out[qi, k][[0, 2]]) == (-1, NEVER)
+        tot = int(out[qi, k, 1])
+        got = [tuple(int(x) for x in r) for r in out[qi, :k]]
+        exp = sorted(rows, key=lambda h: (h[2], h[0], h[1]))[:k]
+        exp += [(-1, 0, NEVER)] * (k - len(exp))
+        if len(rows) <= cap:
+            assert tot == len(rows), (qi, tot, len(rows))
+            assert got == exp, (mm, k, cap, qi)
+        else:
+            # the contract of a truncated hit list: the total is negated and the rows are real hits
+            # (the fused lookup has no list to truncate: its rows are still the exact k best)
+            assert tot == -len(rows), (qi, tot, len(rows))
+            assert set(r for r in got if r[0] >= 0) <= set(rows)
+    return out
+
+
+@pytest.mark.parametrize("C,mean_len,Q", [(3000, 200, 40), (400, 30, 9)])
+def test_fused_topk_equals_oracle(dc, C, mean_len, Q):
+    ids, offs, keys = synth.synth_timestamp_corpus(C, seed=C + 1, mean_len=mean_len, dup_frac=0.05, frag_frac=0.05)
+    rows = [(int(ids[r]), keys[offs[r]:offs[r + 1]].tolist()) for r in range(C)]
+    dc.upload(rows)
+    assert dc.index_stats()["indexed_rows"] == C
+    queries = synth.synth_queries(ids, offs, keys, Q, seed=Q, mean_len=mean_len)
+    queries[0] = np.concatenate([queries[0], queries[0][:7]])        # multiplicity
+    queries[1] = np.array([float("nan"), -0.0, 0.0] + queries[1][:5].tolist())
+    queries[2] = np.zeros(0)                                         # empty query: padding + total 0
+    excl = [int(ids[(7 * i) % C]) for i in range(Q)]
+    for mm in (1, 2, 3, 5):
+        exp = _expected_rows(rows, queries, mm)
+        exp_x = _expected_rows(rows, queries, mm, excl)
+        for k in (1, 16, 64):
+            _check_topk(dc, exp, queries, mm, k, C)
+            _check_topk(dc, exp_x, queries, mm, k, C, excl=excl, algo=_lib.ALGO_INDEX)
+        _check_topk(dc, exp, queries, mm, 16, 5)                      # tiny cap: totals negated where they exceed it
+        _check_topk(dc, exp, queries, mm, 100, C)                     # k > 64: the unfused pipeline, same answer
+
+
+def test_fused_topk_with_huge_ties_and_late_first_hits(dc):
+    """The rare paths of the in-block selection: ~3000 hits in ONE kth bin (more than the 128-entry
+    list holds: reduced by rank counting, fed in rounds), hits whose kth is all beyond the histogram's
+    exact bins (the first 70 query positions match nothing), duplicate video ids (identical rows)."""
+    C = 6000
+    rng = np.random.default_rng(21)
+    grid = np.arange(1, 2001) / 8.0
+    rows = []
+    for c in range(C):
+        r = rng.choice(grid, size=int(rng.integers(5, 40)), replace=False)
+        if rng.random() < 0.5:
+            r = np.append(r, 777.125)                      # half the rows share one key
+        rows.append((c + 1 if c % 50 else 7, r.tolist()))  # video id 7 owns 120 rows
+    dc.upload(rows)
+    Q = 12
+    queries = [rng.choice(grid, size=int(rng.integers(20, 160)), replace=False) for _ in range(Q)]
+    queries[1] = np.array([777.125] * 3)                   # every hit has kth == 0
+    queries[2] = np.concatenate([np.arange(70) + 5000.5, queries[2]])       # nothing matches before position 70
+    queries[3] = np.concatenate([np.arange(70) + 5000.5, [777.125], queries[3]])
+    queries[4] = np.zeros(0)
+    excl = [int(rows[(5 * i) % C][0]) for i in range(Q)]
+    for mm in (1, 2, 4):
+        exp = _expected_rows(rows, queries, mm)
+        assert mm > 1 or (len(exp[1]) > 2500 and len({r[2] for r in exp[1]}) == 1)
+        exp_x = _expected_rows(rows, queries, mm, excl)
+        for k, cap in ((16, C), (1, C), (64, C), (16, 300), (8, 512)):
+            _check_topk(dc, exp, queries, mm, k, cap)
+            _check_topk(dc, exp_x, queries, mm, k, cap, excl=excl)
+
+
+def test_fused_topk_over_several_sub_indexes_and_a_delta_table(dc):
+    """40k rows = 3 sub-indexes; then upserts (replaced indexed rows = dead postings + delta rows, new
+    rows): the lookup's block and the delta sweep's block are merged; equal to the unfused pipeline
+    and the oracle before and after."""
+    C = 40_000
+    rng = np.random.default_rng(9)
+    alphabet = np.arange(1, 30_001) / 4.0
+    rows = [(c + 1, rng.choice(alphabet, size=int(rng.integers(3, 9)), replace=False).tolist()) for c in range(C)]
+    dc.upload(rows)
+    st = dc.index_stats()
+    assert st["indexed_rows"] == C and st["delta_rows"] == 0
+    queries = [rng.choice(alphabet, size=n, replace=False) for n in (40, 200, 300, 500, 64, 1, 0)]
+    queries.append(np.asarray(rows[123][1] + rows[30_000][1]))
+    Q = len(queries)
+    excl = [int(rows[(11 * i) % C][0]) for i in range(Q)]
+
+    def both(mm):
+        exp = _expected_rows(rows, queries, mm)
+        exp_x = _expected_rows(rows, queries, mm, excl)
+        for k in (16, 64):
+            out = _check_topk(dc, exp, queries, mm, k, 4096)
+            _check_topk(dc, exp_x, queries, mm, k, 4096, excl=excl)
+            # the unfused pipeline on the same handle (tvz_match -> tvz_topk_shard)
+            d_q, d_off, max_len = tc.pack_queries(queries, DEV)
+            hits, n = dc.match(d_q, d_off, max_len, mm, 4096, algo=_lib.ALGO_INDEX)
+            blk = tc.topk_shard(hits, n, k)
+            torch.cuda.synchronize()
+            assert (blk.cpu().numpy() == out).all()
+
+    for mm in (1, 2, 3):
+        both(mm)
+    for i in range(300):                                    # below the rebuild trigger: rows stay in the delta table
+        if i % 3 == 0:
+            v, ts = C + 1 + i, rng.choice(alphabet, size=5, replace=False).tolist()
+            rows.append((v, ts))
+        else:
+            r = int(rng.integers(0, C))
+            v, ts = rows[r][0], (queries[1][:6].tolist() if i % 2 else rng.choice(alphabet, size=4).tolist())
+            rows[r] = (v, ts)
+        dc.upsert(v, ts)
+    st = dc.index_stats()
+    assert 280 <= st["delta_rows"] <= 300 and st["builds"] == 1
+    for mm in (1, 2, 3):
+        both(mm)
+
+
+def test_sharded_call_uses_the_fused_lookup_and_matches_the_oracle(dc):
+    """tvz_match_sharded with a one-rank communicator would need RCCL in this process; the same
+    pipeline without the collective: per-shard fused blocks of an 8-way split, stacked as the
+    all-gather delivers them, merged - equal to the oracle's global top-k."""
+    C, R, k = 24_000, 8, 16
+    ids, offs, keys = synth.synth_timestamp_corpus(C, seed=77, mean_len=40, dup_frac=0.03, frag_frac=0.03)
+    rows = [(int(ids[r]), keys[offs[r]:offs[r + 1]].tolist()) for r in range(C)]
+    queries = synth.synth_queries(ids, offs, keys, 96, seed=5, mean_len=40)
+    d_q, d_off, max_len = tc.pack_queries(queries, DEV)
+    shards, blocks = [], []
+    try:
+        for r in range(R):
+            s = tc.DeviceCorpus(0)
+            s.upload(rows[r * C // R:(r + 1) * C // R])
+            shards.append(s)
+            ws = torch.empty(tc.workspace_bytes(len(queries), max_len, 4096, k), dtype=torch.uint8, device=DEV)
+            blocks.append(s.match_topk(d_q, d_off, max_len, 2, 4096, k, workspace=ws))
+        merged, totals = tc.topk_merge(torch.stack(blocks).contiguous(), k)
+        torch.cuda.synchronize()
+    finally:
+        for s in shards:
+            s.close()
+    merged, totals = merged.cpu().numpy(), totals.cpu().numpy()
+    exp = _expected_rows(rows, queries, 2)
+    for qi in range(len(queries)):
+        want = sorted(exp[qi], key=lambda h: (h[2], h[0], h[1]))[:k]
+        want += [(-1, 0, NEVER)] * (k - len(want))
+        assert [tuple(int(x) for x in r) for r in merged[qi]] == want
+        assert int(totals[qi]) == len(exp[qi])

@@ -104,7 +104,8 @@ def _check_batch(dc, ids, offs, keys, queries, min_match, excl=None, cap=None, a
 
 
 @pytest.mark.parametrize("C,mean_len,Q,mm", [(300, 40, 9, 2), (2000, 200, 16, 2), (500, 200, 5, 1),
-                                             (64, 12, 7, 3), (1000, 200, 4, 5), (17, 5, 3, 0)])
+                                             (64, 12, 7, 3), (1000, 200, 4, 5), (17, 5, 3, 0),
+                                             (1500, 200, 12, 6), (600, 200, 6, 9), (800, 200, 5, 40)])
 def test_batched_match_vs_oracle(dc, C, mean_len, Q, mm):
     ids, offs, keys = synth.synth_timestamp_corpus(C, seed=C + mm, mean_len=mean_len, dup_frac=0.05,
                                                    frag_frac=0.05)
@@ -116,6 +117,10 @@ def test_batched_match_vs_oracle(dc, C, mean_len, Q, mm):
     _check_batch(dc, ids, offs, keys, queries, mm)
     excl = [int(ids[(7 * i) % C]) for i in range(Q)]
     _check_batch(dc, ids, offs, keys, queries, mm, excl=excl)
+    if mm >= 1:       # an indexed handle answers EVERY min_match >= 1 from the index (> 5: count + kth fix-up)
+        assert dc.index_stats()["indexed_rows"] == C
+        _, n = _check_batch(dc, ids, offs, keys, queries, mm, excl=excl, algo=_lib.ALGO_INDEX)
+        assert mm < 6 or int(n.max()) >= 1            # the duplicates of the synthetic corpus reach min_match
     # every sweep kernel gives the same hits (the per-call `algo` never changes results)
     for algo in (_lib.ALGO_Q1, _lib.ALGO_TILE, _lib.ALGO_JOIN):
         _check_batch(dc, ids, offs, keys, queries, mm, excl=excl, algo=algo)
@@ -195,7 +200,7 @@ def test_batches_with_queries_longer_than_a_tile(dc):
             assert (got == e) if n[qi] <= cap else (len(got) == cap and set(got) <= set(e)), (mm, algo, qi)
     for mm in (0, 1, 2, 5, 7):
         exp = expected(rows, mm)
-        for algo in (_lib.ALGO_AUTO, _lib.ALGO_TILE, _lib.ALGO_JOIN, _lib.ALGO_Q1) + ((_lib.ALGO_INDEX,) if 1 <= mm <= 5 else ()):
+        for algo in (_lib.ALGO_AUTO, _lib.ALGO_TILE, _lib.ALGO_JOIN, _lib.ALGO_Q1) + ((_lib.ALGO_INDEX,) if mm >= 1 else ()):
             check(exp, mm, algo, False, len(rows))
             check(exp, mm, algo, True, 40)
     # rows replaced / added since the index build (delta table) are found by the long queries too

@@ -623,25 +623,52 @@ __device__ unsigned long long g_ix_stamps[16];
 #define TVZ_STAMP(i) do { } while (0)
 #endif
 
-// dynamic LDS: [bm1][bm2][tcnt][ttop][elist][cache][lst u64 x waves x 64][lbits][e_cur x L][rank u16]
-// [e_len u16 x L x nsb] (nsb = sub-indexes this block walks, rounded up to even): 33.5 KiB + 20 B per
-// query position at 7..8 sub-indexes - FOUR blocks (32 waves) per CU for queries of up to ~320
-// timestamps.
+// fused per-shard top-k (TOPK): the block keeps the k best hits of its query by (kth, video_id, count)
+constexpr int kIxTkCap = 128;              // candidate entries (8 B each) held between compactions
+constexpr int kIxTkMaxK = 64;              // k up to this (kIxTkCap >= 2 k)
+constexpr int kIxTkBins = 64;              // kth histogram: bins 0..62 exact, bin 63 = "63 or later"
+constexpr size_t kIxTkBytes = (size_t)kIxTkCap * 8 + (size_t)kIxTkBins * 4 + 8;
+
+// dynamic LDS: [bm1][bm2][tcnt][ttop][cache][lst u64 x waves x 64][lbits][top-k: entries, histogram,
+// fill][e_cur x L][elist u16][rank u16][e_len u16 x L x nsb] (nsb = sub-indexes this block walks,
+// rounded up to even): 32.5 KiB (+ 1.3 KiB with the fused top-k) + 20 B per query position at 7..8
+// sub-indexes - FOUR blocks (32 waves) per CU for queries of up to ~300 timestamps.
 inline int ix_nsb_padded(int spb) { return (spb + 1) & ~1; }
-inline size_t ix_lds_bytes(int max_len, int spb) {
+inline size_t ix_lds_bytes(int max_len, int spb, bool topk = false) {
     const size_t L = (size_t)(max_len > 0 ? max_len : 1);
-    return (size_t)2 * kIxWords * 4 + (size_t)kIxSlots * 16 + (size_t)kIxCache * 4 + (size_t)kIxWaves * 64 * 8 +
-           (size_t)kIxWaves * kIxLW * 4 + (L + 1) * 4 + (size_t)kIxWords * 2 + L * 2 * (size_t)ix_nsb_padded(spb) + 16;
+    return (size_t)2 * kIxWords * 4 + (size_t)kIxSlots * 14 + (size_t)kIxCache * 4 + (size_t)kIxWaves * 64 * 8 +
+           (size_t)kIxWaves * kIxLW * 4 + (topk ? kIxTkBytes : 0) + (L + 1) * 4 + (size_t)kIxWords * 2 +
+           L * 2 * (size_t)ix_nsb_padded(spb) + 16;
 }
 
-// TOP5 = false (min_match 1..2): a slot keeps the two smallest positions in two atomicMin words -
-// two plain LDS atomics per candidate posting instead of the 5 x 12-bit CAS loop (min_match 3..5).
+// MODE (how a candidate's slot accounts for its postings):
+//   kIxM2    (min_match 1..2): the two smallest positions in two atomicMin words - two plain LDS atomics
+//            per candidate posting instead of the 5 x 12-bit CAS loop;
+//   kIxTop5  (min_match 3..5): the five smallest positions in one 64-bit CAS word;
+//   kIxCount (min_match > 5): the count alone; a hit leaves with kth = -2 - row and ts_kth_fixup_kernel
+//            resolves it (the walk the sweeps use for min_match > 5), so that an indexed corpus never
+//            falls back to sweeping every row.
 // grid = (Q, groups): block (q, g) walks sub-indexes [g * spb, min(n_sub, (g + 1) * spb)).
 //   HOSTOUT (tvz_find_duplicates): hits = pinned host memory [n_sub][kSubRows][3], hits_n[sub] = the
 //            sub-index's hit count (every sub-index has its own region: no atomics, any grouping).
 //   else   : hits = [Q][cap][3].  groups == 1: the block owns the query's list - it appends without
 //            atomics and STORES hits_n[q] at the end (the caller need not zero it).  groups > 1: the
 //            blocks of a query share the list through atomicAdd on hits_n[q] (zeroed by the caller).
+//   TOPK   (tvz_match_topk / tvz_match_sharded, groups == 1, k <= kIxTkMaxK): NO hit list at all.  The
+//            block keeps the k best hits of its query - ascending (kth, video_id, count), the order of
+//            the top-k kernels - and writes hits = [Q][k + 1][3]: k rows + the totals row
+//            (-1, n, NEVER), n negated when n > cap (the contract of the unfused path, whose list
+//            would have been truncated).  A hit is one 64-bit word kth << 44 | video_id << 12 | count.
+//            Every hit bumps its kth's bin in a per-query histogram (LDS); after each part's barrier
+//            every wave scans the 64 bins (one per lane) for b* = the first bin whose prefix reaches
+//            k: hits of later bins can never make the top-k and are dropped, the others (k + the
+//            ties of one bin + what b* let through while it was still large: ~50 per query at
+//            config 4) are appended to a 128-entry list by an LDS atomic.  If a part's keepers might
+//            not fit (known without a barrier: the fill before the part + min(the part's hits, the
+//            histogram's prefix at b*)), the list is first reduced to its k best by rank counting,
+//            which also yields an exact 64-bit cut-off.  The final k rows are written by rank.
+//            Removes 12 B per hit of HBM writes (102 MB per 4096 x 100k batch), their re-read, and
+//            the two top-k launches behind every batch.
 //
 // Who does what.  Query position i belongs to wave (i mod waves), lane (i / waves): a wave owns the
 // posting lists of ITS positions and walks them on its own - compaction, list-start masks, pass A
@@ -650,41 +677,69 @@ inline size_t ix_lds_bytes(int max_len, int spb) {
 // done, emit scan); every LDS array is reset inside the phases by the threads that used it last.
 // (Profiled with s_memtime stamps, profiles/ix_stamps.py: with block-wide compaction 55 % of a
 // block's cycles were barrier waits.)
-template <bool HOSTOUT, bool TOP5>
+constexpr int kIxM2 = 0, kIxTop5 = 1, kIxCount = 2;
+
+// The loops over a long query's later chunks (more than 512 timestamps: rare) address LDS from the lane
+// number; hoisted out of the sub-index loop those addresses were live across the whole kernel - at the
+// 64-VGPR cap that was a scratch spill per value.  An opaque copy keeps the arithmetic inside the loop.
+__device__ __forceinline__ int ix_opaque(int v) {
+    asm volatile("" : "+v"(v));
+    return v;
+}
+
+__device__ __forceinline__ unsigned long long ix_tk_pack(int32_t kth, int32_t vid, uint32_t cnt) {
+    return ((unsigned long long)(uint32_t)kth << 44) | ((unsigned long long)(uint32_t)vid << 12) | cnt;
+}
+
+template <bool HOSTOUT, int MODE, bool TOPK>
 __device__ __forceinline__ void ix_lookup_body(
     const unsigned char *__restrict__ dir, int dir_bits, int ks, const uint16_t *__restrict__ post,
     const int32_t *__restrict__ ivid, int64_t n_indexed, int32_t n_sub, int32_t spb,
     const double *__restrict__ queries, const int64_t *__restrict__ q_offsets, int32_t max_len,
     int32_t min_match, const int32_t *__restrict__ exclude_ids, int32_t exclude_one, int32_t cap,
-    int32_t *__restrict__ hits, int32_t *__restrict__ hits_n, int32_t ns, const QByVal &qv, const int q,
-    const int group, const int n_groups) {
+    int32_t *__restrict__ hits, int32_t *__restrict__ hits_n, int32_t ns, const QByVal *qv, const int q,
+    const int group, const int n_groups, const int32_t tk_k = 0) {
+    static_assert(!(TOPK && (HOSTOUT || MODE == kIxCount)), "the fused top-k needs kth in the block and a device list");
+    constexpr bool TOP5 = MODE == kIxTop5;
     const int dir_log2 = dir_bits & 0xff;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t *bm1 = reinterpret_cast<uint32_t *>(smem);
     uint32_t *bm2 = bm1 + kIxWords;
     uint32_t *tcnt = bm2 + kIxWords;
     unsigned long long *ttop = reinterpret_cast<unsigned long long *>(tcnt + kIxSlots);
-    uint32_t *m1 = reinterpret_cast<uint32_t *>(ttop), *m2 = m1 + kIxSlots;   // !TOP5: the same 8 B per slot
-    uint32_t *elist = reinterpret_cast<uint32_t *>(ttop + kIxSlots);    // row (in the sub-index) of slot k
-    uint32_t *pcache_all = elist + kIxSlots;                            // cached postings: row | position << kSubLog2
+    uint32_t *m1 = reinterpret_cast<uint32_t *>(ttop), *m2 = m1 + kIxSlots;   // kIxM2: the same 8 B per slot
+    uint32_t *pcache_all = reinterpret_cast<uint32_t *>(ttop + kIxSlots);  // cached postings: row | position << kSubLog2
     const int L = max_len > 0 ? max_len : 1;
     uint2 *lst_all = reinterpret_cast<uint2 *>(pcache_all + kIxCache);  // per wave: non-empty list j = {first posting - local start, position}
     uint32_t *lbits_all = reinterpret_cast<uint32_t *>(lst_all + kIxWaves * 64);   // per wave: bit t = a list starts at local posting t
-    uint32_t *e_cur = lbits_all + kIxWaves * kIxLW;                     // [L] first posting of position i in the CURRENT sub-index
-    uint16_t *rank = reinterpret_cast<uint16_t *>(e_cur + L + 1);       // candidates before bitmap word j
+    unsigned long long *tkb = reinterpret_cast<unsigned long long *>(lbits_all + kIxWaves * kIxLW);   // TOPK: kept hits
+    uint32_t *kh = reinterpret_cast<uint32_t *>(tkb + kIxTkCap);        // TOPK: hits per kth bin, all sub-indexes so far
+    uint32_t *tk_n = kh + kIxTkBins;                                    // TOPK: entries in tkb (+ one pad word)
+    uint32_t *e_cur = TOPK ? tk_n + 2 : reinterpret_cast<uint32_t *>(tkb);   // [L] first posting of position i in the CURRENT sub-index
+    uint16_t *elist = reinterpret_cast<uint16_t *>(e_cur + L + 1);      // row (in the sub-index) of slot k
+    uint16_t *rank = elist + kIxSlots;                                  // candidates before bitmap word j
     uint16_t *e_len = rank + kIxWords;                                  // [L][nsb] postings of position i per sub-index
     __shared__ uint32_t s_wb[kIxWaves], s_wc[kIxWaves];
     __shared__ uint32_t s_bcast;
+    __shared__ uint32_t s_tk[TOPK ? kIxWaves : 1];
+    __shared__ unsigned long long s_tkT;
 
     const int sub_lo = group * spb;
     const int sub_hi = sub_lo + spb < n_sub ? sub_lo + spb : n_sub;
     const int nsb = (spb + 1) & ~1;
     const bool alone = n_groups == 1;                  // this block owns the query's hit list
-    const bool byval = q_offsets == nullptr;
+    const bool byval = !TOPK && q_offsets == nullptr;      // (the query travels in the kernel arguments)
     const int64_t qo = byval ? 0 : q_offsets[q];
-    const int64_t n64 = byval ? qv.n : q_offsets[q + 1] - qo;
+    const int64_t n64 = byval ? qv->n : q_offsets[q + 1] - qo;
     if (n64 > max_len) {       // max_query_len was not an upper bound (the LDS arrays are sized from it)
-        if (HOSTOUT) { for (int s = sub_lo + threadIdx.x; s < sub_hi; s += kIxBlock) hits_n[s] = INT32_MIN; }
+        if (TOPK) {            // what the top-k kernels make of a refused query: padding + the poisoned total
+            int32_t *o = hits + (int64_t)q * (tk_k + 1) * 3;
+            for (int i = threadIdx.x; i <= tk_k; i += kIxBlock) {
+                o[i * 3 + 0] = -1;
+                o[i * 3 + 1] = i == tk_k ? INT32_MIN : 0;
+                o[i * 3 + 2] = TVZ_KTH_NEVER;
+            }
+        } else if (HOSTOUT) { for (int s = sub_lo + threadIdx.x; s < sub_hi; s += kIxBlock) hits_n[s] = INT32_MIN; }
         else if (threadIdx.x == 0) hits_n[(size_t)q * ns] = INT32_MIN;
         return;
     }
@@ -700,11 +755,15 @@ __device__ __forceinline__ void ix_lookup_body(
     uint32_t *lbits = lbits_all + wave * kIxLW;
     auto reset_slot = [&](uint32_t k) {
         tcnt[k] = 0;
-        if (TOP5) ttop[k] = kTopNone; else { m1[k] = 0xffffffffu; m2[k] = 0xffffffffu; }
+        if (TOP5) ttop[k] = kTopNone; else if (MODE == kIxM2) { m1[k] = 0xffffffffu; m2[k] = 0xffffffffu; }
     };
     for (int i = threadIdx.x; i < kIxWords; i += kIxBlock) { bm1[i] = 0; bm2[i] = 0; }
     for (int i = threadIdx.x; i < kIxWaves * kIxLW; i += kIxBlock) lbits_all[i] = 0;
     for (int i = threadIdx.x; i < kIxSlots; i += kIxBlock) reset_slot((uint32_t)i);
+    if (TOPK) {
+        for (int i = threadIdx.x; i < kIxTkBins + 2; i += kIxBlock) kh[i] = 0;      // histogram, fill, pad
+    }
+    unsigned long long tk_cut = ~0ull;                     // TOPK: hits >= this cannot make the top-k (block-uniform)
 
     // ---- directory: ONE probe per query position; the counts of this block's sub-indexes to LDS ----
     const uint32_t smask = (1u << (dir_bits >> 8)) - 1u;   // probes wrap inside the directory slice
@@ -713,7 +772,7 @@ __device__ __forceinline__ void ix_lookup_body(
         uint32_t base = 0, total = 0;
         const unsigned char *ent = nullptr;
         int64_t k;
-        if (canon_key(byval ? qv.k[i] : queries[qo + i], k)) {           // NaN never matches
+        if (canon_key(byval ? qv->k[i] : queries[qo + i], k)) {           // NaN never matches
             uint32_t s = ix_slot(k, dir_log2);
             for (int probes = 0; probes < kIxMaxProbe; ++probes) {
                 const unsigned char *e = dir + (size_t)s * es;
@@ -863,14 +922,14 @@ __device__ __forceinline__ void ix_lookup_body(
                 walk_lists(__ballot(first < len0), off0, len0, first, (uint32_t)(lane * kIxWaves + wave), f);
             }
             for (int c = 1; c < n_chunks; ++c) {
-                const int i = c * kIxBlock + lane * kIxWaves + wave;
+                const int i = c * kIxBlock + ix_opaque(lane) * kIxWaves + wave;
                 const uint32_t len = i < n ? e_len[(size_t)i * nsb + (sub - sub_lo)] : 0u;
                 const uint32_t off = i < n ? e_cur[i] - len : 0u;         // (e_cur was advanced below)
                 walk_lists(__ballot(len != 0u), off, len, 0u, (uint32_t)i, f);
             }
         };
         for (int c = 1; c < n_chunks; ++c) {               // advance the later chunks' cursors (once per sub-index)
-            const int i = c * kIxBlock + lane * kIxWaves + wave;
+            const int i = c * kIxBlock + ix_opaque(lane) * kIxWaves + wave;
             if (i < n) e_cur[i] += e_len[(size_t)i * nsb + (sub - sub_lo)];
         }
         if (tw > (uint32_t)kIxPW || n_chunks > 1) each_uncached([&](uint32_t r, uint32_t) { touch(r); });
@@ -958,7 +1017,7 @@ __device__ __forceinline__ void ix_lookup_body(
                         if (old == seen) break;
                         seen = old;
                     }
-                } else {
+                } else if constexpr (MODE == kIxM2) {
                     const uint32_t o = atomicMin(&m1[idx], pos);             // positions of one row are distinct
                     atomicMin(&m2[idx], o > pos ? o : pos);                  // larger of two hits >= 2nd smallest
                 }
@@ -1005,12 +1064,28 @@ __device__ __forceinline__ void ix_lookup_body(
 #endif
             // emit: one slot per thread and round; the slots that reached min_match and are live hits get
             // a place by a block-wide scan - one reservation per block, none when the block owns the list
+            auto kth_of = [&](uint32_t k) -> int32_t {
+                if constexpr (MODE == kIxCount) return -2 - (int32_t)(row0 + elist[k]);   // ts_kth_fixup_kernel resolves it
+                else if constexpr (TOP5) return (int32_t)((uint32_t)(ttop[k] >> (12 * (min_match - 1))) & 0xfffu);
+                else return (int32_t)(min_match == 1 ? m1[k] : m2[k]);
+            };
             uint32_t mine = 0;
+            unsigned long long ek[kIxSlots / kIxBlock];    // TOPK: this thread's hits as sortable words
+            uint32_t tk_before = 0;                        // TOPK: kept hits before this part (its appends are
+            if constexpr (TOPK) tk_before = *tk_n;         // behind >= 1 barrier: the same value in every thread)
 #pragma unroll
             for (int u = 0; u < kIxSlots / kIxBlock; ++u) {
                 const uint32_t k = (uint32_t)u * kIxBlock + threadIdx.x;
                 if (vid[u] >= 0 && (int32_t)tcnt[k] < min_match) vid[u] = -1;
                 mine += vid[u] >= 0 ? 1u : 0u;
+                if constexpr (TOPK) {
+                    ek[u] = ~0ull;
+                    if (vid[u] >= 0) {
+                        const int32_t kth = kth_of(k);
+                        ek[u] = ix_tk_pack(kth, vid[u], tcnt[k]);
+                        atomicAdd(&kh[kth < kIxTkBins - 1 ? kth : kIxTkBins - 1], 1u);
+                    }
+                }
             }
             const uint32_t incl = wave_scan_incl(mine);
             if (lane == 63) s_wc[wave] = incl;
@@ -1031,6 +1106,90 @@ __device__ __forceinline__ void ix_lookup_body(
                 if (x < wave) base += a;
                 all += a;
             }
+            if constexpr (TOPK) {
+                emitted += all;
+                if (all) {                                 // block-uniform
+                    // b* = the first kth bin whose prefix reaches k; every wave scans the 64 bins itself (the
+                    // histogram does not change before the next part's emit: same result in all of them)
+                    const uint32_t hincl = wave_scan_incl(kh[lane]);
+                    const unsigned long long reach = __ballot(hincl >= (uint32_t)tk_k);
+                    const int bfirst = __builtin_amdgcn_readfirstlane(reach ? __ffsll((long long)reach) - 1 : kIxTkBins);
+                    uint32_t bound = all;                  // this part's keepers, at most
+                    unsigned long long cut = tk_cut;
+                    if (bfirst < kIxTkBins - 1) {          // (the last bin is "63 or later": no bound from it)
+                        const uint32_t cum = (uint32_t)__builtin_amdgcn_readlane((int)hincl, bfirst);
+                        bound = cum < all ? cum : all;
+                        const unsigned long long bc = (unsigned long long)(bfirst + 1) << 44;
+                        cut = bc < cut ? bc : cut;
+                    }
+                    if (tk_before + bound <= (uint32_t)kIxTkCap) {
+#pragma unroll
+                        for (int u = 0; u < kIxSlots / kIxBlock; ++u)
+                            if (ek[u] < cut) tkb[atomicAdd(tk_n, 1u)] = ek[u];
+                    } else {
+                        // rare: hundreds of hits in the threshold bin (true duplicates share their kth) or
+                        // none of the first k hits below position 63.  Reduce the list to its k best - which
+                        // gives the exact cut-off - and feed the part's keepers in rounds of what fits.
+                        auto reduce = [&](uint32_t N) -> uint32_t {
+                            unsigned long long e = ~0ull;
+                            uint32_t r = 0;
+                            if (threadIdx.x < N) {
+                                e = tkb[threadIdx.x];
+                                for (uint32_t i = 0; i < N; ++i) {
+                                    const unsigned long long o = tkb[i];
+                                    r += (o < e || (o == e && i < threadIdx.x)) ? 1u : 0u;
+                                }
+                            }
+                            __syncthreads();
+                            if (threadIdx.x < N && r < (uint32_t)tk_k) tkb[r] = e;
+                            if (threadIdx.x < N && r == (uint32_t)tk_k - 1u) s_tkT = e;
+                            const uint32_t left = N < (uint32_t)tk_k ? N : (uint32_t)tk_k;
+                            if (threadIdx.x == 0) *tk_n = left;
+                            __syncthreads();
+                            if (N >= (uint32_t)tk_k) { const unsigned long long t = s_tkT; tk_cut = t < tk_cut ? t : tk_cut; }
+                            return left;
+                        };
+                        uint32_t nb = reduce(tk_before);
+                        while (true) {                     // block-uniform
+                            cut = tk_cut < cut ? tk_cut : cut;
+                            uint32_t c = 0;
+#pragma unroll
+                            for (int u = 0; u < kIxSlots / kIxBlock; ++u) c += ek[u] < cut ? 1u : 0u;
+                            const uint32_t ci = wave_scan_incl(c);
+                            if (lane == 63) s_tk[wave] = ci;
+                            __syncthreads();
+                            uint32_t before = 0, tot = 0;
+#pragma unroll
+                            for (int x = 0; x < kIxWaves; ++x) {
+                                const uint32_t a = s_tk[x];
+                                if (x < wave) before += a;
+                                tot += a;
+                            }
+                            if (tot == 0) break;
+                            const uint32_t room = (uint32_t)kIxTkCap - nb;
+                            uint32_t off = before + ci - c;
+#pragma unroll
+                            for (int u = 0; u < kIxSlots / kIxBlock; ++u) {
+                                if (ek[u] < cut) {
+                                    if (off < room) { tkb[nb + off] = ek[u]; ek[u] = ~0ull; }
+                                    ++off;
+                                }
+                            }
+                            const uint32_t placed = tot < room ? tot : room;
+                            if (threadIdx.x == 0) *tk_n = nb + placed;
+                            __syncthreads();
+                            nb += placed;
+                            if (tot <= room) break;
+                            nb = reduce(nb);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < kIxSlots / kIxBlock; ++u) {
+                    const uint32_t k = (uint32_t)u * kIxBlock + threadIdx.x;
+                    if (k < n_list) reset_slot(k);         // this thread was the slot's last reader
+                }
+            } else {
             uint32_t start = emitted;
             if (!HOSTOUT && !alone && all) {               // block-uniform: the blocks of a query share its list
                 if (threadIdx.x == 0) s_bcast = (uint32_t)atomicAdd(out_n, (int32_t)all);
@@ -1050,8 +1209,7 @@ __device__ __forceinline__ void ix_lookup_body(
                     if ((int64_t)o < room) {
 #endif
                         int32_t *hp = out_hits + (int64_t)o * 3;
-                        const int32_t kth = TOP5 ? (int32_t)((uint32_t)(ttop[k] >> (12 * (min_match - 1))) & 0xfffu)
-                                                 : (int32_t)(min_match == 1 ? m1[k] : m2[k]);
+                        const int32_t kth = kth_of(k);
                         // streaming stores: 100 MB of hits per batch would otherwise push the posting
                         // lines a block comes back to in its next sub-index out of the XCD's 4 MB L2
                         // (HBM reads per launch 559 -> 507 MB, profiles/r3_match_pmc.txt)
@@ -1063,6 +1221,7 @@ __device__ __forceinline__ void ix_lookup_body(
                 }
                 if (k < n_list) reset_slot(k);             // this thread was the slot's last reader
             }
+            }
             if (lo + kIxSlots < n_cand) __syncthreads();   // the next part rewrites elist and refills the slots
         }
         if (n_cand == 0) {                                 // no part ran (pass A touched rows, none twice): reset here,
@@ -1073,7 +1232,31 @@ __device__ __forceinline__ void ix_lookup_body(
         if (HOSTOUT && threadIdx.x == 0) *out_n = (int32_t)emitted;
         TVZ_STAMP(9);
     }
-    if (!HOSTOUT && alone && threadIdx.x == 0) hits_n[(size_t)q * ns] = (int32_t)emitted;
+    if constexpr (TOPK) {
+        // the k best of the kept hits, each written to the row of its rank; padding; the totals row
+        __syncthreads();                                   // the last part's appends
+        const uint32_t N = *tk_n;
+        int32_t *o = hits + (int64_t)q * (tk_k + 1) * 3;
+        if (threadIdx.x < N) {
+            const unsigned long long e = tkb[threadIdx.x];
+            uint32_t r = 0;
+            for (uint32_t i = 0; i < N; ++i) {
+                const unsigned long long x = tkb[i];
+                r += (x < e || (x == e && i < threadIdx.x)) ? 1u : 0u;
+            }
+            if (r < (uint32_t)tk_k) {
+                o[r * 3 + 0] = (int32_t)(uint32_t)(e >> 12);
+                o[r * 3 + 1] = (int32_t)((uint32_t)e & 0xfffu);
+                o[r * 3 + 2] = (int32_t)(e >> 44);
+            }
+        }
+        const uint32_t have = N < (uint32_t)tk_k ? N : (uint32_t)tk_k;
+        for (uint32_t i = have + threadIdx.x; i <= (uint32_t)tk_k; i += kIxBlock) {
+            o[i * 3 + 0] = -1;
+            o[i * 3 + 1] = i == (uint32_t)tk_k ? ((int64_t)emitted > (int64_t)cap ? -(int32_t)emitted : (int32_t)emitted) : 0;
+            o[i * 3 + 2] = TVZ_KTH_NEVER;
+        }
+    } else if (!HOSTOUT && alone && threadIdx.x == 0) hits_n[(size_t)q * ns] = (int32_t)emitted;
 #ifdef TVZ_IX_STAMP
     if (threadIdx.x == 0) {
         for (int i = 0; i < 10; ++i) atomicAdd(&g_ix_stamps[i], st_acc[i]);
@@ -1082,16 +1265,30 @@ __device__ __forceinline__ void ix_lookup_body(
 #endif
 }
 
-template <bool HOSTOUT, bool TOP5>
+template <bool HOSTOUT, int MODE>
 __global__ __launch_bounds__(kIxBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) void ts_match_index_kernel(
     const unsigned char *__restrict__ dir, int dir_bits, int ks, const uint16_t *__restrict__ post,
     const int32_t *__restrict__ ivid, int64_t n_indexed, int32_t n_sub, int32_t spb,
     const double *__restrict__ queries, const int64_t *__restrict__ q_offsets, int32_t max_len,
     int32_t min_match, const int32_t *__restrict__ exclude_ids, int32_t exclude_one, int32_t cap,
     int32_t *__restrict__ hits, int32_t *__restrict__ hits_n, int32_t ns, const QByVal qv) {
-    ix_lookup_body<HOSTOUT, TOP5>(dir, dir_bits, ks, post, ivid, n_indexed, n_sub, spb, queries, q_offsets, max_len,
-                                  min_match, exclude_ids, exclude_one, cap, hits, hits_n, ns, qv, (int)blockIdx.x,
-                                  (int)blockIdx.y, (int)gridDim.y);
+    ix_lookup_body<HOSTOUT, MODE, false>(dir, dir_bits, ks, post, ivid, n_indexed, n_sub, spb, queries, q_offsets,
+                                         max_len, min_match, exclude_ids, exclude_one, cap, hits, hits_n, ns, &qv,
+                                         (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.y);
+}
+
+// the lookup with the per-shard top-k in its epilogue: grid = (Q), one block per query over ALL
+// sub-indexes; topk = [Q][k + 1][3] (k best + totals row), no hit list, no counters
+template <int MODE>
+__global__ __launch_bounds__(kIxBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) void ts_match_index_topk_kernel(
+    const unsigned char *__restrict__ dir, int dir_bits, int ks, const uint16_t *__restrict__ post,
+    const int32_t *__restrict__ ivid, int64_t n_indexed, int32_t n_sub,
+    const double *__restrict__ queries, const int64_t *__restrict__ q_offsets, int32_t max_len,
+    int32_t min_match, const int32_t *__restrict__ exclude_ids, int32_t cap, int32_t k,
+    int32_t *__restrict__ topk) {
+    ix_lookup_body<false, MODE, true>(dir, dir_bits, ks, post, ivid, n_indexed, n_sub, n_sub, queries, q_offsets,
+                                      max_len, min_match, exclude_ids, -1, cap, topk, nullptr, 1, nullptr,
+                                      (int)blockIdx.x, 0, 1, k);
 }
 
 // tvz_find_duplicates on an indexed corpus with rows in the delta table - the streaming driver's call:
@@ -1108,9 +1305,9 @@ __global__ __launch_bounds__(kIxBlock) __attribute__((amdgpu_waves_per_eu(8, 8))
     const Row *__restrict__ delta_rows, int64_t n_delta, const int64_t *__restrict__ keys, int32_t s_log2,
     HostOut ho, const QByVal qv) {
     if ((int)blockIdx.x < n_groups)
-        ix_lookup_body<true, TOP5>(dir, dir_bits, ks, post, ivid, n_indexed, n_sub, spb, queries, q_offsets, max_len,
-                                   min_match, nullptr, exclude_one, 0, ix_hits, ix_hits_n, 1, qv, 0, (int)blockIdx.x,
-                                   n_groups);
+        ix_lookup_body<true, TOP5 ? kIxTop5 : kIxM2, false>(dir, dir_bits, ks, post, ivid, n_indexed, n_sub, spb, queries,
+                                                            q_offsets, max_len, min_match, nullptr, exclude_one, 0, ix_hits,
+                                                            ix_hits_n, 1, &qv, 0, (int)blockIdx.x, n_groups);
     else
         q1_body<TOP5 ? kQ1ModeTop5 : kQ1ModeM2, true, kIxBlock>(delta_rows, n_delta, keys, queries, q_offsets, min_match,
                                                                nullptr, exclude_one, 0, nullptr, nullptr, 1, s_log2, ho,

@@ -741,6 +741,7 @@ struct WsLayout {
     int32_t *local = nullptr;       // [Q][k+1][3]
     int32_t *gathered = nullptr;    // [n_ranks][Q][k+1][3]
     int32_t *flags = nullptr;       // [Q] queries the one-wave top-k left to the block kernels
+    int32_t *pair = nullptr;        // [2][Q][k+1][3] fused lookup: the index's block + the delta sweep's, merged into `local`
     size_t total = 0;
 };
 
@@ -768,6 +769,10 @@ WsLayout ws_layout(void *base, int32_t Q, int32_t max_query_len, int32_t cap, in
         p += al256((size_t)(n_ranks > 1 ? n_ranks : 1) * (size_t)Q * (size_t)(k + 1) * 12);
         w.flags = reinterpret_cast<int32_t *>(p);
         p += al256((size_t)Q * 4);
+        if (k <= kIxTkMaxK) {
+            w.pair = reinterpret_cast<int32_t *>(p);
+            p += al256((size_t)2 * (size_t)Q * (size_t)(k + 1) * 12);
+        }
     }
     w.total = (size_t)(p - p0) + 256;
     return w;
@@ -930,9 +935,10 @@ int launch_scan(tvz_corpus *c, RowSpan span, int a, bool zero_counts, const doub
     return TVZ_OK;
 }
 
-// the index answers min_match 1..5 (the five smallest query positions per candidate give kth)
+// the index answers every min_match >= 1: 1..5 from the smallest query positions kept per candidate,
+// more than 5 by count + the kth fix-up walk (min_match <= 0 makes every row a hit: a sweep's job)
 bool index_usable(const tvz_corpus *c, int32_t min_match) {
-    return c->ix.valid && min_match >= 1 && min_match <= kTop;
+    return c->ix.valid && min_match >= 1;
 }
 
 
@@ -961,13 +967,48 @@ int launch_index(tvz_corpus *c, const double *d_queries, const int64_t *d_q_offs
     if (!HOSTOUT && groups > 1)
         if (int rc = launch_prep(d_hits_n, ns, Q, nullptr, 0, nullptr, 0, st)) return rc;
     const size_t lds = ix_lds_bytes(max_query_len, spb);
-#define TVZ_IX(TOP5)                                                                                        \
-    hipLaunchKernelGGL((ts_match_index_kernel<HOSTOUT, TOP5>), dim3((unsigned)Q, (unsigned)groups),          \
+#define TVZ_IX(MODE)                                                                                        \
+    hipLaunchKernelGGL((ts_match_index_kernel<HOSTOUT, MODE>), dim3((unsigned)Q, (unsigned)groups),          \
                        dim3(kIxBlock), lds, st, ix.dir.p, ix.dir_bits(), ix.ks, ix.post.p, ix.ivid.p, ix.n_main, \
                        ix.n_sub, spb, d_queries, d_q_offsets, max_query_len, min_match, d_exclude_ids,        \
                        exclude_one, cap, d_hits, d_hits_n, ns, byval ? *byval : kNoQuery)
-    if (min_match <= 2) TVZ_IX(false); else TVZ_IX(true);
+    if (min_match <= 2) TVZ_IX(kIxM2);
+    else if (min_match <= kTop) TVZ_IX(kIxTop5);
+    else if constexpr (!HOSTOUT) TVZ_IX(kIxCount);
+    else return tvz::fail(TVZ_ERR_UNSUPPORTED, "internal: min_match > 5 straight to host memory");
 #undef TVZ_IX
+    TVZ_HIP(hipGetLastError());
+    if (!HOSTOUT && min_match > kTop) {
+        // the hits left with kth = -2 - row (a row of the MAIN table: unchanged since the build, or it
+        // would be dead in the index); resolved here, before a delta sweep appends codes of its own table
+        hipLaunchKernelGGL(ts_kth_fixup_kernel, dim3((unsigned)Q), dim3(kBlock), 0, st, c->rows.p, c->keys.p,
+                           d_queries, d_q_offsets, min_match, cap, d_hits, d_hits_n, ns);
+        TVZ_HIP(hipGetLastError());
+    }
+    return TVZ_OK;
+}
+
+// Can the lookup keep the per-shard top-k itself (ts_match_index_topk_kernel)?  One block per query
+// over all sub-indexes, kth known inside the block (min_match 1..5), k <= 64.
+bool index_topk_usable(const tvz_corpus *c, int32_t Q, int32_t max_query_len, int32_t min_match, int32_t k) {
+    if (!c->ix.valid || min_match < 1 || min_match > kTop || k < 1 || k > kIxTkMaxK || Q < 1) return false;
+    if (max_query_len > kMaxQueryLen) return false;
+    const IndexBuf &ix = c->ix.now();
+    if (index_subs_per_block(Q, ix.n_sub, max_query_len, false) != ix.n_sub) return false;   // a query over several blocks
+    return ix_lds_bytes(max_query_len, ix.n_sub, true) <= (size_t)kIxMaxLds;
+}
+
+int launch_index_topk(tvz_corpus *c, const double *d_queries, const int64_t *d_q_offsets, int32_t Q,
+                      int32_t max_query_len, int32_t min_match, const int32_t *d_exclude_ids, int32_t cap,
+                      int32_t k, int32_t *d_block, hipStream_t st) {
+    const IndexBuf &ix = c->ix.now();
+    const size_t lds = ix_lds_bytes(max_query_len, ix.n_sub, true);
+#define TVZ_IXK(MODE)                                                                                       \
+    hipLaunchKernelGGL((ts_match_index_topk_kernel<MODE>), dim3((unsigned)Q), dim3(kIxBlock), lds, st,        \
+                       ix.dir.p, ix.dir_bits(), ix.ks, ix.post.p, ix.ivid.p, ix.n_main, ix.n_sub, d_queries,   \
+                       d_q_offsets, max_query_len, min_match, d_exclude_ids, cap, k, d_block)
+    if (min_match <= 2) TVZ_IXK(kIxM2); else TVZ_IXK(kIxTop5);
+#undef TVZ_IXK
     TVZ_HIP(hipGetLastError());
     return TVZ_OK;
 }
@@ -1096,7 +1137,7 @@ int launch_match_short(tvz_corpus *c, const double *d_queries, const int64_t *d_
     bool zero_counts = true;
     if (algo == TVZ_ALGO_INDEX && !index_usable(c, min_match))
         return tvz::fail(TVZ_ERR_UNSUPPORTED, "TVZ_ALGO_INDEX: %s", c->ix.valid
-                             ? "the index answers min_match 1..5 only" : "this corpus has no index (tvz_corpus_build_index)");
+                             ? "the index answers min_match >= 1 only" : "this corpus has no index (tvz_corpus_build_index)");
     if ((algo == TVZ_ALGO_AUTO || algo == TVZ_ALGO_INDEX) && index_usable(c, min_match) && Q > 0) {
         // unchanged rows through the index, rows added or replaced since its build through a sweep
         // of the delta table - a row is in exactly one of the two
@@ -1189,6 +1230,30 @@ int tvz_match_topk_local(tvz_corpus *c, const double *d_queries, const int64_t *
     DeviceGuard dg(c->device);
     hipStream_t st = reinterpret_cast<hipStream_t>(hip_stream);
     std::shared_lock<std::shared_mutex> lk(c->mu);
+    if ((algo == TVZ_ALGO_AUTO || algo == TVZ_ALGO_INDEX) && index_topk_usable(c, Q, max_query_len, min_match, k)) {
+        // the lookup keeps the k best itself: no hit list, no top-k launch.  Rows added or replaced since
+        // the build are swept as usual; their block and the lookup's are merged (k + 1 rows each).
+        if (int rc = wait_mutations(c, st)) return rc;
+        const int64_t n_delta = c->ix.n_delta;
+        int32_t *blk = n_delta ? w.pair : d_out;
+        if (int rc = launch_index_topk(c, d_queries, d_q_offsets, Q, max_query_len, min_match, d_exclude_ids, cap, k,
+                                       blk, st))
+            return rc;
+        if (n_delta) {
+            const RowSpan span{c->ix.now().drows.p, n_delta};
+            int a = pick_algo(TVZ_ALGO_AUTO, Q, span.n, max_query_len, min_match);
+            if (int rc = launch_scan(c, span, a, true, d_queries, d_q_offsets, Q, max_query_len, min_match,
+                                     d_exclude_ids, cap, w.hits, w.counters, kCountStride, w.join, w.join_bytes, st))
+                return rc;
+            int32_t *blk2 = w.pair + (size_t)Q * (size_t)(k + 1) * 3;
+            if (int rc = launch_topk_local(w.hits, w.counters, kCountStride, Q, cap, k, blk2, 1, w.flags, st)) return rc;
+            hipLaunchKernelGGL(ts_topk_wave_kernel, dim3((unsigned)tvz::ceil_div(Q, kBlock / 64)), dim3(kBlock), 0, st,
+                               w.pair, nullptr, /* mode 3: ns = the hit capacity */ cap, 2, Q, k + 1, k, d_out, 3,
+                               nullptr, nullptr);
+            TVZ_HIP(hipGetLastError());
+        }
+        return record(c, st);
+    }
     // the sweeps count into one-counter-per-line scratch; the select kernel reads it as it is
     if (int rc = launch_match(c, d_queries, d_q_offsets, Q, max_query_len, min_match, d_exclude_ids,
                               cap, w.hits, w.counters, kCountStride, w.join, w.join_bytes, algo, st))
@@ -1244,11 +1309,16 @@ static int tvz_corpus_create_impl(tvz_corpus **out, int device) {
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)kTileLds));
     TVZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(ts_match_join_kernel),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)kJoinLds));
-#define TVZ_IX_ATTR(H, T)                                                                          \
-    TVZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(ts_match_index_kernel<H, T>),           \
+#define TVZ_IX_ATTR(H, M)                                                                          \
+    TVZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(ts_match_index_kernel<H, M>),           \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, kIxMaxLds))
-    TVZ_IX_ATTR(false, false); TVZ_IX_ATTR(false, true); TVZ_IX_ATTR(true, false); TVZ_IX_ATTR(true, true);
+    TVZ_IX_ATTR(false, kIxM2); TVZ_IX_ATTR(false, kIxTop5); TVZ_IX_ATTR(false, kIxCount);
+    TVZ_IX_ATTR(true, kIxM2); TVZ_IX_ATTR(true, kIxTop5);
 #undef TVZ_IX_ATTR
+    TVZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(ts_match_index_topk_kernel<kIxM2>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, kIxMaxLds));
+    TVZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(ts_match_index_topk_kernel<kIxTop5>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, kIxMaxLds));
     TVZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(ix_slice_count_kernel),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)kIxSliceBytesMax));
     TVZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(ix_slice_fill_kernel),

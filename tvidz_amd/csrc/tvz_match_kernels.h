@@ -1378,7 +1378,8 @@ template <int E>
 __device__ __forceinline__ void wave_topk_body(
     uint32_t *h, const int lane, const int q, const int n, const int32_t total_row,
     const int32_t *__restrict__ lists, int32_t n_lists, int32_t Q, int32_t cap, int32_t k,
-    int32_t *__restrict__ topk, int32_t mode, int32_t *__restrict__ totals, int32_t *__restrict__ flags) {
+    int32_t *__restrict__ topk, int32_t mode, int32_t *__restrict__ totals, int32_t *__restrict__ flags,
+    int32_t hit_cap) {
     uint64_t key[E];
     int32_t cnt[E];
     int bin[E];
@@ -1390,7 +1391,7 @@ __device__ __forceinline__ void wave_topk_body(
         bin[e] = -1;                           // -1: no entry
         if (i < n) {
             const int32_t *src;
-            if (mode == 2) {
+            if (mode >= 2) {
                 const int l = i / (cap - 1), j = i - l * (cap - 1);
                 src = lists + (((int64_t)l * Q + q) * cap + j) * 3;
             } else {
@@ -1529,7 +1530,7 @@ __device__ __forceinline__ void wave_topk_body(
             }
         }
     }
-    const int orows = (mode == 1) ? k + 1 : k;
+    const int orows = (mode == 1 || mode == 3) ? k + 1 : k;
     if (lane < k) {
         int32_t *o = topk + ((int64_t)q * orows + lane) * 3;
         if (mk == ~0ULL) {
@@ -1544,8 +1545,9 @@ __device__ __forceinline__ void wave_topk_body(
         int32_t *o = topk + ((int64_t)q * orows + k) * 3;
         o[0] = -1; o[1] = total_row; o[2] = TVZ_KTH_NEVER;
     }
-    if (mode == 2 && totals) {
+    if ((mode == 2 && totals) || mode == 3) {
         // every gathered list ends with (-1, n, NEVER): |n| summed, negated if any shard overflowed
+        // (mode 3: or if the sum exceeds hit_cap - the one list an unfused match would have filled)
         long long sum = 0;
         bool over = false;
         for (int l = lane; l < n_lists; l += 64) {
@@ -1555,11 +1557,16 @@ __device__ __forceinline__ void wave_topk_body(
         }
 #pragma unroll
         for (int d = 32; d > 0; d >>= 1) sum += __shfl_xor(sum, d);
-        over = __ballot(over) != 0ULL;
+        over = __ballot(over) != 0ULL || (mode == 3 && sum > (long long)hit_cap);
         if (lane == 0) {
             int32_t t = sum > 0x7fffffffLL ? 0x7fffffff : (int32_t)sum;
             if (over) t = (t == 0) ? INT32_MIN : -t;
-            totals[q] = t;
+            if (mode == 3) {
+                int32_t *o = topk + ((int64_t)q * orows + k) * 3;
+                o[0] = -1; o[1] = t; o[2] = TVZ_KTH_NEVER;
+            } else {
+                totals[q] = t;
+            }
         }
     }
 }
@@ -1575,7 +1582,7 @@ __global__ __launch_bounds__(kBlock) void ts_topk_wave_kernel(
     uint32_t *h = s_hist[threadIdx.x >> 6];
     int n;                                     // entries to look at
     int32_t total_row = 0;                     // mode 1: the shard's hit count (negated on overflow)
-    if (mode == 2) {
+    if (mode >= 2) {                           // 2: merge of gathered blocks -> topk[Q][k] + totals[Q]; 3: -> one block [Q][k+1]
         n = n_lists * (cap - 1);               // cap = k + 1 rows per gathered list, the last one = totals
     } else {
         const int32_t total = lists_n ? lists_n[(size_t)q * ns] : cap;
@@ -1587,11 +1594,11 @@ __global__ __launch_bounds__(kBlock) void ts_topk_wave_kernel(
         return;
     }
     if (n <= 64 * 4)
-        wave_topk_body<4>(h, lane, q, n, total_row, lists, n_lists, Q, cap, k, topk, mode, totals, flags);
+        wave_topk_body<4>(h, lane, q, n, total_row, lists, n_lists, Q, cap, k, topk, mode, totals, flags, ns);
     else if (n <= 64 * 8)
-        wave_topk_body<8>(h, lane, q, n, total_row, lists, n_lists, Q, cap, k, topk, mode, totals, flags);
+        wave_topk_body<8>(h, lane, q, n, total_row, lists, n_lists, Q, cap, k, topk, mode, totals, flags, ns);
     else
-        wave_topk_body<kWsE>(h, lane, q, n, total_row, lists, n_lists, Q, cap, k, topk, mode, totals, flags);
+        wave_topk_body<kWsE>(h, lane, q, n, total_row, lists, n_lists, Q, cap, k, topk, mode, totals, flags, ns);
 }
 
 // ---- small helpers launched around the sweeps ------------------------------------------------

@@ -121,7 +121,9 @@ class Store:
         # HBM row + queued SQL write of add_timestamps_async happen as one step with respect to a
         # reload of the mirror (sync_if_stale): a reload in between would drop the HBM row for good
         self._mirror_lock = threading.RLock()
-        # video_id -> digest of the row SQL holds as far as this process knows (audit())
+        # video_timestamps.id -> digest of the row SQL holds as far as this process knows (audit());
+        # by PRIMARY KEY: the table has no UNIQUE(video_id), and the reference's older insert-per-cut
+        # code left several rows per video, every one of which find_duplicates reads (db.py:83-91)
         self._sql_digest = {}
         self.audit_interval = float(os.environ.get("TVZ_AUDIT_INTERVAL", "0") if audit_interval is None
                                     else audit_interval)
@@ -156,7 +158,7 @@ class Store:
             self.corpus.upload_csr(ids, offs, keys)
         else:                                       # (test doubles and the sharded front end take row lists)
             self.corpus.upload([(v, a.tolist()) for v, a in live])
-        self._sql_digest = {v: hash(a.tobytes()) for v, a in live}
+        self._sql_digest = {int(r[0]): _digest(r[2] or ()) for r in fetched if r[1] is not None}
         self._census = census
         self._dirty = False
         return len(live)
@@ -165,9 +167,8 @@ class Store:
         """Reload the mirror if `video_timestamps` gained or lost rows that this process did not
         write (another worker, plain SQL), or if a device upsert or a write-behind commit failed.
         `min_interval` > 0 skips the census when one ran less than that many seconds ago (the
-        driver asks once per upload; a burst of uploads shares one census).  Raises what flush()
-        raises (a failed write-behind of some upload, once); the reload is then done by the next
-        call."""
+        driver asks once per upload; a burst of uploads shares one census).  Failed write-behinds of
+        OTHER uploads are not raised here: they stay with their owners (flush(video_id))."""
         from sqlalchemy import func
         import time as _time
         now = _time.monotonic()
@@ -182,7 +183,11 @@ class Store:
                 session.close()
             stale = self._dirty or (int(cnt or 0), int(mx or 0)) != self._census
         if stale:
-            self.flush()                    # our own write-behind first: its rows must be in SQL
+            # our own write-behind first: its rows must be in SQL.  Only WAIT here - a failed write
+            # belongs to the upload that owns the row (its next add_timestamps_async / flush(video_id)
+            # raises it); collecting it here would fail whichever upload happened to find the census
+            # stale and tell the owner nothing.
+            self._wait_write_behind()
             with self._mirror_lock:         # no add_timestamps_async between the reload and the replay
                 with self._write_lock:
                     self.reload_corpus()
@@ -197,13 +202,17 @@ class Store:
 
     def audit(self, chunk_rows: int = 4096) -> int:
         """One pass over `video_timestamps` in id order: every row whose content is not what this
-        process last read or wrote for that video was UPDATEd in place by another writer (the
-        census of sync_if_stale cannot see that) - its HBM row is replaced by the SQL content.
-        Rows of uploads with a queued or in-flight write-behind are this process's own and are
-        skipped (HBM is ahead of SQL there by design).  Returns the number of rows repaired.
-        The write lock is held per CHUNK, so uploads interleave with a long audit."""
+        process last read or wrote for that ROW (by primary key) was UPDATEd in place by another
+        writer (the census of sync_if_stale cannot see that) - its HBM row is replaced by the SQL
+        content.  Rows of uploads with a queued or in-flight write-behind are this process's own and
+        are skipped (HBM is ahead of SQL there by design).  Returns the number of rows repaired.
+        Locks: a chunk is READ under the write lock alone (uploads interleave with a long audit);
+        a differing row is repaired under mirror lock -> write lock, the order sync_if_stale takes
+        them in (the other order deadlocked an upload's sync against the audit thread), after
+        re-reading the row: an add_timestamps in between has made it ours again."""
         repaired, last_id = 0, 0
         while True:
+            suspects = []
             with self._write_lock:
                 session = self.SessionLocal()
                 try:
@@ -217,20 +226,44 @@ class Store:
                 last_id = int(rows[-1][0])
                 with self._wb_cv:
                     own = set(self._pending) | set(self._inflight)
-                for _id, vid, ts in rows:
+                for rid, vid, ts in rows:
                     if vid is None or int(vid) in own:
                         continue
-                    ts = [float(x) for x in (ts or [])]
-                    d = _digest(ts)
-                    if self._sql_digest.get(int(vid)) != d:
-                        with self._mirror_lock:
-                            self.corpus.upsert(int(vid), ts)
-                        self._sql_digest[int(vid)] = d
-                        repaired += 1
+                    if self._sql_digest.get(int(rid)) != _digest([float(x) for x in (ts or [])]):
+                        suspects.append((int(rid), int(vid)))
+            for rid, vid in suspects:
+                repaired += self._repair_row(rid, vid)
             if len(rows) < int(chunk_rows):
                 break
         self.audit_repairs += repaired
         return repaired
+
+    def _repair_row(self, rid: int, vid: int) -> int:
+        """audit(): SQL row `rid` of video `vid` differed from what this process knows.  Re-read it
+        under mirror lock -> write lock and bring the mirror in line: one SQL row for the video -> its
+        HBM row is upserted; several (no UNIQUE(video_id)) -> an upsert would replace only the FIRST
+        device row, so the mirror is marked dirty and reloaded whole by the next sync_if_stale."""
+        with self._mirror_lock:
+            with self._write_lock:
+                with self._wb_cv:
+                    if vid in self._pending or vid in self._inflight:
+                        return 0                         # an upload took the video over: HBM is ahead by design
+                session = self.SessionLocal()
+                try:
+                    sib = (session.query(VideoTimestamps.id, VideoTimestamps.timestamps)
+                           .filter_by(video_id=vid).order_by(VideoTimestamps.id).all())
+                finally:
+                    session.close()
+                cur = {int(i): [float(x) for x in (t or [])] for i, t in sib}
+                if rid not in cur or self._sql_digest.get(rid) == _digest(cur[rid]):
+                    return 0                             # deleted (the census sees that) or ours again
+                for i, t in cur.items():
+                    self._sql_digest[i] = _digest(t)
+                if len(cur) > 1:
+                    self._dirty = True
+                    return 1
+                self.corpus.upsert(vid, cur[rid])
+                return 1
 
     def _audit_loop(self) -> None:
         while not self._audit_stop.wait(self.audit_interval):
@@ -268,7 +301,7 @@ class Store:
                     session.add(ts_row)
                     session.commit()
                     self._census = (self._census[0] + 1, max(self._census[1], int(ts_row.id)))
-                self._sql_digest[int(video_id)] = _digest(ts)
+                self._sql_digest[int(ts_row.id)] = _digest(ts)
             finally:
                 session.close()
             try:
@@ -289,7 +322,7 @@ class Store:
             session.add(ts_row)
             session.flush()
             self._census = (self._census[0] + 1, max(self._census[1], int(ts_row.id)))
-        self._sql_digest[int(video_id)] = _digest(ts)   # (a failed commit marks the mirror dirty: reloaded)
+        self._sql_digest[int(ts_row.id)] = _digest(ts)  # (a failed commit marks the mirror dirty: reloaded)
 
     def add_timestamps_async(self, video_id, timestamps) -> None:
         """add_timestamps for the streaming driver: the HBM row - what the NEXT find_duplicates of
@@ -336,6 +369,12 @@ class Store:
                     if err is not None:
                         raise err
                     return
+                self._wb_cv.wait(timeout=0.5)
+
+    def _wait_write_behind(self) -> None:
+        """Block until the write-behind queue is empty WITHOUT taking anybody's error (sync_if_stale)."""
+        with self._wb_cv:
+            while self._pending or self._inflight:
                 self._wb_cv.wait(timeout=0.5)
 
     def _write_behind(self) -> None:
