@@ -135,3 +135,65 @@ class OracleBackend:
         return out, totals
 
 
+
+
+# ---- the N-rank service on a CPU box (tests/test_service_launch_cpu.py) --------------------------
+class CutReader:
+    """What the CPU driver's frame source returns: the cut timestamps of an upload, delivered in
+    micro-batches (the GPU driver gets them from the scene kernels; that half has its own -m gpu tests)."""
+
+    def __init__(self, cuts, per_batch=3, frames=300):
+        self.cuts, self.per_batch, self.total_frames = list(cuts), int(per_batch), int(frames)
+        self.H, self.W, self.time_base, self.bitdepth = 8, 8, (1, 30), 8
+        self.closed = False
+
+    def close(self):
+        self.closed = True
+
+
+def cut_inspector(store, **kw):
+    """inspector.Inspector with the scene half replaced: the reference's per-cut body (app.py:231-255,
+    Inspector._after_cuts) runs unchanged over the reader's cut list."""
+    from tvidz_amd import inspector as insp
+
+    class CutListInspector(insp.Inspector):
+        def _run(self, analysis_key, video_id, reader):
+            scene_timestamps, dups = [], []
+            try:
+                for b in range(0, len(reader.cuts), reader.per_batch):
+                    grew = False
+                    for ts in reader.cuts[b:b + reader.per_batch]:
+                        if not scene_timestamps or ts != scene_timestamps[-1]:        # app.py:231
+                            scene_timestamps.append(ts)
+                            grew = True
+                    frames_done = min(reader.total_frames, (b + reader.per_batch) * 10)
+                    if grew:
+                        scene_timestamps, stop = self._after_cuts(analysis_key, video_id, scene_timestamps,
+                                                                  frames_done, reader.total_frames, dups)
+                        if stop:
+                            break
+                    self._progress(analysis_key, scene_timestamps, frames_done, reader.total_frames, dups)
+            finally:
+                self.store.flush(video_id)
+            return scene_timestamps, dups
+    return CutListInspector(store, **kw)
+
+
+def cuts_of_key(key: str):
+    """The synthetic upload named by an S3 key: `.../<digits>-<name>__<c0>_<c1>_...` carries its cut list
+    (tenths of seconds) in the name, so every rank process derives the same clip from the key alone."""
+    name = key.split("/")[-1]
+    body = name.rsplit(".", 1)[0].split("__", 1)[1]
+    return [int(x) / 10.0 for x in body.split("_")]
+
+
+def cpu_rank_parts(rank, world, group, a):
+    """service.py `--parts tests.fakes:cpu_rank_parts`: a rank made of the oracle (shard + matcher
+    backend) on gloo; the tick exchange, the store, the driver body and the routes are the product's."""
+    from tvidz_amd import sharded
+    shard = OracleCorpus()
+    matcher = sharded.ShardedMatcher(OracleBackend(live=shard), k=a.k, cap=max(a.cap, a.k), group=group)
+    return dict(shard=shard, matcher=matcher, xdev="cpu",
+                inspector=lambda store: cut_inspector(
+                    store, device="cuda:0", max_workers=a.workers,
+                    frame_source=lambda bucket, key, filename, uid: (CutReader(cuts_of_key(key)), None)))

@@ -35,8 +35,7 @@ def _worker(rank, world, port, out):
         # default group, and two threads must not interleave collectives on one group
         g = dist.new_group(backend="gloo")
         matcher = sharded.ShardedMatcher(OracleBackend(live=shard), k=8, cap=64, group=g)
-        wide = sharded.ShardedMatcher(OracleBackend(live=shard), k=64, cap=64, group=g)
-        rc = service.RankCorpus(shard, matcher, group=g, xdev="cpu", tick_s=0.002, wide_k_matcher=wide)
+        rc = service.RankCorpus(shard, matcher, group=g, xdev="cpu", tick_s=0.002)
         rc.upload(table)
         assert sorted(v for v, _ in shard.rows) == [v for v, _ in table if v % world == rank]
         dist.barrier()
@@ -84,7 +83,30 @@ def _worker(rank, world, port, out):
                 break
         assert (seen, dups) == (list(exp_ts), sorted(exp_dups)), (rank, seen, dups, exp_ts, exp_dups)
         dist.barrier()
-        assert rc.busy_ticks >= 3
+        # (4) never an error because ties exceed k (db.py:85-91 returns EVERY row, app.py:238-245
+        # reports all rows of the earliest prefix): 24 copies spread over both ranks share kth 1 with k = 8
+        copy_ts = [8000.25 + i for i in range(6)]
+        for j in range(12):
+            rc.upsert(20000 + 2 * j + rank, copy_ts)              # 12 rows ingested on each rank
+        dist.barrier()
+        full2 = full + [(20000 + i, copy_ts) for i in range(24)]
+        before = rc.exact_asks
+        got = rc.find_duplicates(copy_ts, 2, exclude_id=20000 + rank, with_kth=True)
+        exp = _whole_table_hits(full2, copy_ts, 2, excl=20000 + rank)
+        assert len(exp) == 23 and got == exp and all(h[2] == 1 for h in got), (rank, got, exp)
+        assert rc.exact_asks == before + 1                        # the top-k said "may continue": answered exactly
+        # db.find_duplicates' shape (every row with its count) beyond k, and through db.Store's call
+        pairs = rc.find_duplicates(copy_ts, 2)
+        assert pairs == sorted((v, c) for v, c, _ in _whole_table_hits(full2, copy_ts, 2, excl=-1)) and len(pairs) == 24
+        # a query of more than 4095 timestamps and a min_match outside 1..5: the exact exchange, not an error
+        longq = [-1.0 - i for i in range(4200)] + copy_ts     # (negative: in no row)
+        got = rc.find_duplicates(longq, 2, exclude_id=-1, with_kth=True)
+        assert got == _whole_table_hits(full2, longq, 2, excl=-1) and len(got) == 24
+        got = rc.find_duplicates(copy_ts, 6, exclude_id=-1, with_kth=True)
+        assert got == _whole_table_hits(full2, copy_ts, 6, excl=-1) and len(got) == 24
+        assert rc.find_duplicates([1.5], 1) == [] and rc.find_duplicates([], 2, with_kth=True) == []
+        dist.barrier()
+        assert rc.busy_ticks >= 3 and rc.broken is None
         out.put((rank, "ok"))
     except Exception as e:  # pragma: no cover
         out.put((rank, repr(e)))

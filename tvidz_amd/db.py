@@ -76,8 +76,12 @@ class Store:
     `video_timestamps`.  Thread-safe: one short session per call, like the reference."""
 
     def __init__(self, url: Optional[str] = None, device: int = 0, corpus=None,
-                 audit_interval: Optional[float] = None):
+                 audit_interval: Optional[float] = None, census: bool = True):
+        """`census=False`: the other writers of the table are this service's own sibling ranks (one
+        process per GPU, service.py): their rows live in THEIR shards, so a changed row count is not
+        a reason to reload this rank's mirror; sync_if_stale then reloads only after a failed write."""
         self.url = url or os.environ.get("POSTGRES_URL", DEFAULT_URL)
+        self.census = bool(census)
         kw = {}
         if self.url.startswith("sqlite") and (":memory:" in self.url or self.url in ("sqlite://", "sqlite:///")):
             kw = dict(connect_args={"check_same_thread": False}, poolclass=StaticPool)
@@ -172,6 +176,8 @@ class Store:
         from sqlalchemy import func
         import time as _time
         now = _time.monotonic()
+        if not self.census and not self._dirty:
+            return False
         if min_interval > 0 and not self._dirty and now - getattr(self, "_census_at", -1e9) < min_interval:
             return False
         self._census_at = now
@@ -501,6 +507,29 @@ class Store:
             self._audit_thread.join(timeout=5)
         self.corpus.close()
         self.engine.dispose()
+
+
+def create_schema(url: Optional[str] = None) -> None:
+    """db.py:30 (`Base.metadata.create_all`) on its own: the parent of the N-rank service makes the
+    tables once, before the rank processes open the same database side by side."""
+    url = url or os.environ.get("POSTGRES_URL", DEFAULT_URL)
+    eng = create_engine(url)
+    try:
+        Base.metadata.create_all(eng)
+    finally:
+        eng.dispose()
+
+
+def video_filenames(url: Optional[str] = None) -> dict:
+    """{video id: file name} of `videos` (the N-rank service routes by file name: service.owner_rank)."""
+    from sqlalchemy import select
+    url = url or os.environ.get("POSTGRES_URL", DEFAULT_URL)
+    eng = create_engine(url)
+    try:
+        with eng.connect() as c:
+            return {int(i): f for i, f in c.execute(select(Video.id, Video.filename))}
+    finally:
+        eng.dispose()
 
 
 # ---- module-level functions, as the reference exports them (app.py:10) --------------------

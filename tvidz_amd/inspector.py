@@ -251,27 +251,11 @@ class Inspector:
                         scene_timestamps.append(ts)
                         grew = True
                 if grew:
-                    # one match over the whole current list; kth tells on which prefix the
-                    # reference's per-cut loop (app.py:234-238) would have stopped
-                    hits = self.store.find_duplicates_kth(scene_timestamps, self.min_match,
-                                                          exclude_id=video_id)            # :235-237
-                    t = self._phase("match", t)
-                    hits = [h for h in hits if h[2] < KTH_NEVER]
-                    if hits:
-                        kstar = min(h[2] for h in hits)
-                        dup_ids = [h[0] for h in hits if h[2] == kstar]
-                        scene_timestamps = scene_timestamps[:max(kstar, 0) + 1]
-                        self._persist(video_id, scene_timestamps)                         # :234
-                        self.store.update_duplicates(video_id, dup_ids)                   # :239
-                        for dup_id in dup_ids:                                            # :241-245
-                            dup_video = self.store.get_video_by_id(dup_id)
-                            if dup_video:
-                                dups_to_report.append(dup_video.filename)
-                        self._progress(analysis_key, scene_timestamps, frames_done, total_frames,
-                                       dups_to_report)
+                    scene_timestamps, stop = self._after_cuts(analysis_key, video_id, scene_timestamps, frames_done,
+                                                              total_frames, dups_to_report)
+                    t = time.perf_counter()                # (phases "match" / "persist" are timed inside)
+                    if stop:
                         break                                                             # :249-255
-                    self._persist(video_id, scene_timestamps)                             # :234
-                    t = self._phase("persist", t)
                 self._progress(analysis_key, scene_timestamps, frames_done, total_frames, dups_to_report)
                 t = self._phase("progress", t)
         finally:
@@ -283,6 +267,32 @@ class Inspector:
                 self.store.flush(video_id)                 # the SQL row is committed before `done`
             self._phase("flush_sql", t)
         return scene_timestamps, dups_to_report
+
+    def _after_cuts(self, analysis_key, video_id, scene_timestamps, frames_done, total_frames, dups_to_report):
+        """The reference's per-cut body (app.py:234-255) for a micro-batch that grew the cut list:
+        one match over the whole current list - kth tells on which prefix the per-cut loop would
+        have stopped -, persist, and on the first hit: truncate, record the duplicates, stop.
+        -> (scene_timestamps, stop).  `dups_to_report` is extended in place."""
+        t = time.perf_counter()
+        hits = self.store.find_duplicates_kth(scene_timestamps, self.min_match, exclude_id=video_id)   # :235-237
+        t = self._phase("match", t)
+        hits = [h for h in hits if h[2] < KTH_NEVER]
+        if hits:
+            kstar = min(h[2] for h in hits)
+            dup_ids = [h[0] for h in hits if h[2] == kstar]
+            scene_timestamps = scene_timestamps[:max(kstar, 0) + 1]
+            self._persist(video_id, scene_timestamps)                                 # :234
+            self.store.update_duplicates(video_id, dup_ids)                           # :239
+            for dup_id in dup_ids:                                                    # :241-245
+                dup_video = self.store.get_video_by_id(dup_id)
+                if dup_video:
+                    dups_to_report.append(dup_video.filename)
+            self._progress(analysis_key, scene_timestamps, frames_done, total_frames, dups_to_report)
+            self._phase("persist", t)
+            return scene_timestamps, True
+        self._persist(video_id, scene_timestamps)                                     # :234
+        self._phase("persist", t)
+        return scene_timestamps, False
 
     def _persist(self, video_id: int, scene_timestamps) -> None:
         """app.py:234: the growing prefix goes to the device corpus at once (the next match of any

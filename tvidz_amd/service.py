@@ -27,6 +27,8 @@ Two forms of the same composition:
 """
 from __future__ import annotations
 
+import os
+import sys
 import threading
 import time
 from concurrent.futures import Future
@@ -218,40 +220,65 @@ class ShardedCorpus:
         return [(merged[i], int(totals[i])) for i in range(Q)]
 
 
+ASK_TOPK, ASK_EXACT = 0, 1
+
+
 class RankCorpus:
     """One process per GPU: this rank's shard + the tick exchange.  Every rank runs the same loop
     at the same cadence (the exchange is collective): gather how many asks each rank has, gather the
-    padded asks, answer ALL of them against the own shard through `matcher` (sharded.ShardedMatcher
-    or RcclShardedMatcher: local match -> per-shard top-k -> one all-gather -> merge, identical on
-    every rank) and keep the answers to the own asks.
+    padded asks (ONE collective: keys and the per-ask fields travel in one float64 block), answer ALL
+    of them against the own shard and keep the answers to the own asks.  Two kinds of ask:
+
+      ASK_TOPK   the driver's per-micro-batch question (app.py:235-238): through `matcher`
+                 (sharded.ShardedMatcher or RcclShardedMatcher: local match -> per-shard top-k -> one
+                 all-gather -> merge, identical on every rank); the k best rows by (kth, video_id) hold
+                 the verdict unless the rows sharing the earliest prefix may continue past k;
+      ASK_EXACT  every row that reaches min_match, as db.find_duplicates returns them (db.py:85-91):
+                 each rank asks its own shard (`shard.find_duplicates`, any query length, any min_match),
+                 the per-rank hit counts are all-gathered, then the variable-length hit lists (padded to
+                 the longest).  Taken by db.find_duplicates-shaped calls whose answer does not fit k, by a
+                 top-k ask whose tie set may exceed k (the reference reports ALL rows of the earliest
+                 prefix: an upload never fails because of k), by queries of more than 4095 timestamps
+                 and by min_match outside 1..5.
 
     `shard`: this rank's DeviceCorpus (or a stand-in with upload/upsert/clear/find_duplicates);
     `matcher.match_topk(d_q, d_off, max_len, min_match, d_excl) -> (merged [Q,k,3], totals [Q])`;
     `xdev`: where the exchanged tensors live ("cpu" for gloo, the GPU for RCCL);
     `group`: a process group used by NOTHING else (the tick thread issues collectives on it
-    concurrently with whatever the other threads of the process do on theirs)."""
+    concurrently with whatever the other threads of the process do on theirs);
+    `owner_fn(video_id) -> rank` decides which rank keeps a row of the initial table (default
+    video_id mod world; the N-rank service routes by file name and passes its own).
+
+    A failure of the tick thread (a collective that errors, the local matcher, an allocation) cannot be
+    repaired from inside: the other ranks are in the same collective.  It marks the corpus BROKEN - every
+    pending and later ask raises it - and the next meta exchange carries the flag, so the ranks that are
+    still exchanging stop together; the service process then exits non-zero (service main)."""
 
     def __init__(self, shard, matcher, group=None, xdev="cpu", tick_s: float = 0.0005, max_batch: int = 1024,
-                 wide_k_matcher=None):
+                 owner_fn: Optional[Callable[[int], int]] = None):
         self.shard, self.matcher, self.group = shard, matcher, group
-        self.wide = wide_k_matcher              # a matcher with a larger k for tie sets that exceed k (optional)
         self.xdev = torch.device(xdev)
         inited = dist.is_available() and dist.is_initialized()
         self.world = dist.get_world_size(group) if inited else 1
         self.rank = dist.get_rank(group) if inited else 0
+        self.owner_fn = owner_fn
         self.tick_s, self.max_batch = float(tick_s), int(max_batch)
         self._cv = threading.Condition()
         self._pending: List[tuple] = []
         self._stop = False
+        self.broken: Optional[BaseException] = None
         self.ticks = 0
         self.busy_ticks = 0
+        self.exact_asks = 0
+        self.tick_host_s = 0.0              # host time of the busy ticks (profiles/tick_cost.py)
         self._thread = threading.Thread(target=self._loop, name="tvz-rank-tick", daemon=True)
         self._thread.start()
 
     # ---- rows ----
     def upload(self, rows) -> None:
-        """The initial table: this rank keeps video_id mod world == rank."""
-        self.shard.upload([(int(v), list(t)) for v, t in rows if int(v) % self.world == self.rank])
+        """The initial table: this rank keeps the rows `owner_fn` gives it (video_id mod world)."""
+        own = self.owner_fn or (lambda v: int(v) % self.world)
+        self.shard.upload([(int(v), list(t)) for v, t in rows if own(int(v)) % self.world == self.rank])
 
     def upsert(self, video_id: int, timestamps) -> None:
         self.shard.upsert(int(video_id), timestamps)         # ingested here: lives here
@@ -263,28 +290,32 @@ class RankCorpus:
         return self.shard.stats()
 
     # ---- matches ----
-    def find_duplicates(self, new_timestamps, min_match: int = 5, exclude_id: int = -1, with_kth: bool = False):
-        q = np.ascontiguousarray(np.asarray(new_timestamps, dtype=np.float64))
-        if q.size > MAX_BATCH_LEN or not 1 <= int(min_match) <= 5:
-            raise RuntimeError("RankCorpus answers asks of up to 4095 timestamps with min_match 1..5")
+    def _ask(self, q, min_match, exclude_id, kind):
         fut: Future = Future()
         with self._cv:
+            if self.broken is not None:
+                raise RuntimeError(f"rank corpus is broken: {self.broken!r}")
             if self._stop:
                 raise RuntimeError("rank corpus is closed")
-            self._pending.append((q, int(min_match), int(exclude_id), 0, fut))
+            self._pending.append((q, int(min_match), int(exclude_id), int(kind), fut))
             self._cv.notify()
-        rows, total = fut.result()
-        hits, exact = _hits_from_topk(rows, total)
-        if not exact and self.wide is not None:
-            fut = Future()
-            with self._cv:
-                self._pending.append((q, int(min_match), int(exclude_id), 1, fut))
-            rows, total = fut.result()
+        return fut.result()
+
+    def find_duplicates(self, new_timestamps, min_match: int = 5, exclude_id: int = -1, with_kth: bool = False):
+        """with_kth (the driver): the rows that decide the verdict - the merged top-k when it is
+        conclusive, every matching row otherwise.  Without (db.find_duplicates, db.py:76-94): every
+        matching row with its count, sorted by video_id."""
+        q = np.ascontiguousarray(np.asarray(new_timestamps, dtype=np.float64))
+        if q.size <= MAX_BATCH_LEN and 1 <= int(min_match) <= 5:
+            rows, total = self._ask(q, min_match, exclude_id, ASK_TOPK)
             hits, exact = _hits_from_topk(rows, total)
-        if not exact:
-            raise RuntimeError("more rows share the verdict's prefix than the exchanged top-k holds; "
-                               "raise k (sharded matcher) for this corpus")
-        return hits if with_kth else sorted((v, c) for v, c, _ in hits)
+            if with_kth and exact:
+                return hits
+            if not with_kth and 0 <= total <= len(hits):          # the k best ARE all of them
+                return sorted((v, c) for v, c, _ in hits)
+        self.exact_asks += 1
+        hits = self._ask(q, min_match, exclude_id, ASK_EXACT)
+        return hits if with_kth else [(v, c) for v, c, _ in hits]
 
     def _gather(self, t: torch.Tensor) -> torch.Tensor:
         """[...] -> [world, ...] (dim-0 concatenation is the layout RCCL and gloo both accept)."""
@@ -295,60 +326,102 @@ class RankCorpus:
         dist.all_gather_into_tensor(out, t, group=self.group)
         return out.view((self.world,) + tuple(t.shape))
 
+    def _fail(self, err: BaseException, take=()) -> None:
+        with self._cv:
+            if self.broken is None:
+                self.broken = err
+            pend, self._pending = self._pending, []
+        for p in list(take) + pend:
+            if not p[4].done():
+                p[4].set_exception(RuntimeError(f"rank corpus is broken: {err!r}"))
+
     def _loop(self):
-        while True:
-            with self._cv:
-                stop = self._stop
-                take = self._pending[: self.max_batch]
-                self._pending = self._pending[len(take):]
-            # 1) who has how much (and does anybody want to stop: all ranks leave together)
-            meta = torch.tensor([len(take), max((len(p[0]) for p in take), default=0), 1 if stop else 0],
-                                dtype=torch.int64, device=self.xdev)
-            allmeta = self._gather(meta).cpu().numpy()
-            self.ticks += 1
-            if int(allmeta[:, 0].sum()) == 0:
-                if int(allmeta[:, 2].min()) == 1:            # every rank is closing and nothing is pending anywhere
-                    return
-                time.sleep(self.tick_s)
-                continue
-            self.busy_ticks += 1
-            try:
+        take = []
+        try:
+            while True:
+                with self._cv:
+                    stop = self._stop
+                    take = self._pending[: self.max_batch]
+                    self._pending = self._pending[len(take):]
+                # 1) who has how much; does anybody want to stop (all ranks leave together); is anybody broken
+                meta = torch.tensor([len(take), max((len(p[0]) for p in take), default=0), 1 if stop else 0,
+                                     1 if self.broken is not None else 0], dtype=torch.int64, device=self.xdev)
+                allmeta = self._gather(meta).cpu().numpy()
+                self.ticks += 1
+                if int(allmeta[:, 3].max()) == 1:
+                    bad = [int(r) for r in np.flatnonzero(allmeta[:, 3])]
+                    raise RuntimeError(f"the tick loop of rank(s) {bad} failed: the sharded service stops")
+                if int(allmeta[:, 0].sum()) == 0:
+                    if int(allmeta[:, 2].min()) == 1:        # every rank is closing and nothing is pending anywhere
+                        return
+                    time.sleep(self.tick_s)
+                    continue
+                self.busy_ticks += 1
+                t0 = time.perf_counter()
                 self._exchange_and_answer(take, allmeta)
-            except BaseException as e:
-                for p in take:
-                    if not p[4].done():
-                        p[4].set_exception(e)
+                self.tick_host_s += time.perf_counter() - t0
+                take = []
+        except BaseException as e:                           # noqa: BLE001 - every waiting upload must see it
+            self._fail(e, take)
 
     def _exchange_and_answer(self, take, allmeta):
         Qcap, Lcap = int(allmeta[:, 0].max()), max(int(allmeta[:, 1].max()), 1)
-        # 2) the asks, padded to the largest rank's block: keys [Qcap, Lcap] + (len, exclude, min_match, wide)
-        keys = np.zeros((Qcap, Lcap), dtype=np.float64)
-        info = np.zeros((Qcap, 4), dtype=np.int64)
-        for i, (q, mm, ex, wide, _) in enumerate(take):
-            keys[i, :len(q)] = q
-            info[i] = (len(q), ex, mm, wide)
-        g_keys = self._gather(torch.from_numpy(keys).to(self.xdev)).cpu().numpy()
-        g_info = self._gather(torch.from_numpy(info).to(self.xdev)).cpu().numpy()
-        # the global batch, in the same order on every rank: rank-major, then (min_match, wide) groups
-        asks = [(r, i) for r in range(self.world) for i in range(int(allmeta[r, 0]))]
-        groups = sorted({(int(g_info[r, i, 2]), int(g_info[r, i, 3])) for r, i in asks})
-        for mm, wide in groups:
-            sel = [(r, i) for r, i in asks if (int(g_info[r, i, 2]), int(g_info[r, i, 3])) == (mm, wide)]
-            qs = [g_keys[r, i, :int(g_info[r, i, 0])] for r, i in sel]
-            lens = np.array([len(x) for x in qs], dtype=np.int64)
-            offs = np.zeros(len(qs) + 1, dtype=np.int64)
+        # 2) the asks, padded to the largest rank's block, as ONE float64 block per rank:
+        #    [Qcap, 4 + Lcap] = (len, exclude, min_match, kind | keys...); small integers are exact in float64
+        blk = np.zeros((Qcap, 4 + Lcap), dtype=np.float64)
+        for i, (q, mm, ex, kind, _) in enumerate(take):
+            blk[i, 0], blk[i, 1], blk[i, 2], blk[i, 3] = len(q), ex, mm, kind
+            blk[i, 4:4 + len(q)] = q
+        g = self._gather(torch.from_numpy(blk).to(self.xdev)).cpu().numpy()       # [world, Qcap, 4 + Lcap]
+        g_info = g[:, :, :4].astype(np.int64)
+        g_keys = g[:, :, 4:]
+        # the global batch, in the same order on every rank: rank-major; rows past a rank's count are padding
+        valid = np.arange(Qcap)[None, :] < allmeta[:, 0][:, None]                  # [world, Qcap]
+        rr, ii = np.nonzero(valid)
+        lens_all, excl_all, mm_all, kind_all = (g_info[rr, ii, c] for c in range(4))
+        mine = rr == self.rank
+        mdev = getattr(self.matcher, "dev", torch.device("cpu"))
+        # 3) top-k asks, one batched sharded match per min_match (vectorised un-padding: no per-ask Python)
+        for mm in sorted(set(int(m) for m in mm_all[kind_all == ASK_TOPK])):
+            sel = np.flatnonzero((kind_all == ASK_TOPK) & (mm_all == mm))
+            lens = lens_all[sel]
+            offs = np.zeros(len(sel) + 1, dtype=np.int64)
             np.cumsum(lens, out=offs[1:])
-            flat = np.concatenate(qs) if int(offs[-1]) else np.zeros(1)
-            mdev = getattr(self.matcher, "dev", torch.device("cpu"))
+            keys2d = g_keys[rr[sel], ii[sel]]                                      # [n, Lcap]
+            flat = keys2d[np.arange(Lcap)[None, :] < lens[:, None]]                # row-major: ask after ask
+            if flat.size == 0:
+                flat = np.zeros(1)
             d_q = torch.from_numpy(np.ascontiguousarray(flat, dtype=np.float64)).to(mdev)
             d_off = torch.from_numpy(offs).to(mdev)
-            d_ex = torch.tensor([int(g_info[r, i, 1]) for r, i in sel], dtype=torch.int32, device=mdev)
-            m = self.wide if wide and self.wide is not None else self.matcher
-            merged, totals = m.match_topk(d_q, d_off, int(lens.max()) if len(lens) else 0, mm, d_ex)
-            merged, totals = merged.cpu().numpy(), totals.cpu().numpy()
-            for j, (r, i) in enumerate(sel):
-                if r == self.rank:
-                    take[i][4].set_result((merged[j].copy(), int(totals[j])))
+            d_ex = torch.from_numpy(excl_all[sel].astype(np.int32)).to(mdev)
+            merged, totals = self.matcher.match_topk(d_q, d_off, int(lens.max()) if len(lens) else 0, mm, d_ex)
+            Qn, k = merged.shape[0], merged.shape[1]
+            # ONE device-to-host copy per batch: rows and totals together
+            both = torch.cat([merged.reshape(Qn, k * 3), totals.reshape(Qn, 1).to(merged.dtype)], dim=1).cpu().numpy()
+            for j in np.flatnonzero(mine[sel]):
+                a = int(sel[j])
+                take[int(ii[a])][4].set_result((both[j, :k * 3].reshape(k, 3).copy(), int(both[j, k * 3])))
+        # 4) exact asks: every rank asks its own shard, counts and padded hit lists are all-gathered
+        sel = np.flatnonzero(kind_all == ASK_EXACT)
+        if len(sel):
+            local = []
+            for a in sel:
+                q = g_keys[rr[a], ii[a], :int(lens_all[a])]
+                local.append(self.shard.find_duplicates(q, int(mm_all[a]), exclude_id=int(excl_all[a]), with_kth=True))
+            counts = torch.tensor([len(h) for h in local], dtype=torch.int64, device=self.xdev)
+            allcounts = self._gather(counts).cpu().numpy()                         # [world, n]
+            width = int(allcounts.max())
+            if width:
+                pad = np.full((len(sel), width, 3), -1, dtype=np.int32)
+                for j, h in enumerate(local):
+                    if h:
+                        pad[j, :len(h)] = np.asarray(h, dtype=np.int32)
+                allhits = self._gather(torch.from_numpy(pad).to(self.xdev)).cpu().numpy()   # [world, n, width, 3]
+            for j in np.flatnonzero(mine[sel]):
+                a = int(sel[j])
+                rows = [allhits[r, j, :int(allcounts[r, j])] for r in range(self.world) if allcounts[r, j]] if width else []
+                hits = sorted((int(v), int(c), int(k)) for v, c, k in np.concatenate(rows)) if rows else []
+                take[int(ii[a])][4].set_result(hits)
 
     def close(self) -> None:
         """Collective: every rank calls it; the loops leave together once nothing is pending."""
@@ -356,5 +429,299 @@ class RankCorpus:
             self._stop = True
             self._cv.notify_all()
         self._thread.join(timeout=60)
+        if self._thread.is_alive():
+            # still exchanging (another rank has not closed): closing the shard under it would free
+            # memory its matches read
+            raise RuntimeError("rank corpus: the tick thread did not stop (close() is collective)")
         if hasattr(self.shard, "close"):
             self.shard.close()
+
+
+# ==================================================================================================
+# configs[4] as a COMMAND:  python -m tvidz_amd.service --ranks N [--port 5000] [--db URL]
+#
+# A parent that never touches a GPU spawns one fresh child per device (a child is started as a new
+# program: nothing that has initialised the GPU is ever exec'ed over) and serves a thin FRONT on
+# --port; each child is the whole one-GPU service - db.Store + inspector.Inspector + the Flask routes
+# of the reference (inspector/app.py:31-115) - over RankCorpus(RcclShardedMatcher): its own shard of
+# the table, the tick exchange with its siblings.  The front keeps the reference's surface:
+#   POST /notify                 -> the rank that owns the upload (crc32 of the clean file name mod N:
+#                                   the key the reference stores in `videos.filename`, app.py:122-150),
+#                                   so an upload's add_timestamps never leave its GPU (app.py:234);
+#   GET  /status/<f>             -> the owning rank's record (the others are asked too when it has none:
+#                                   the reference also accepts an analysis key here, app.py:56);
+#   GET  /status/stream/<f>      -> the owning rank's SSE stream, relayed chunk by chunk (app.py:64-115).
+# A child that dies (or whose tick loop broke) takes the service down with a non-zero exit: the other
+# ranks would wait for it in the next collective.
+# UNMEASURED ON HARDWARE for N > 1 (no box here has two GPUs): tests/test_service_launch_cpu.py drives
+# two ranks on gloo through the front's HTTP surface, tests/test_service_gpu.py one rank on the GPU.
+# ==================================================================================================
+def owner_rank(clean_filename: str, world: int) -> int:
+    import zlib
+    return zlib.crc32(str(clean_filename).encode("utf-8", "surrogatepass")) % max(int(world), 1)
+
+
+def clean_name(name_or_key: str) -> str:
+    """The name `videos.filename` holds for an upload (inspector.split_filenames, app.py:122-130)."""
+    from .inspector import split_filenames
+    return split_filenames(name_or_key)[1]
+
+
+class FilenameOwner:
+    """owner_fn for RankCorpus.upload: a row of the initial table belongs to the rank its video's file
+    name routes to - the rank that would have ingested it."""
+
+    def __init__(self, url: str, world: int):
+        self.url, self.world = url, int(world)
+        self.names: dict = {}
+
+    def __call__(self, video_id: int) -> int:
+        if int(video_id) not in self.names:
+            from . import db
+            self.names = db.video_filenames(self.url)           # (one SELECT per reload, not per row)
+        name = self.names.get(int(video_id))
+        return owner_rank(name, self.world) if name is not None else int(video_id) % self.world
+
+
+def _load_hook(spec: str):
+    import importlib
+    mod, _, fn = spec.partition(":")
+    return getattr(importlib.import_module(mod), fn)
+
+
+def _hip_parts(rank: int, world: int, group, a):
+    """What a rank is made of on an MI355X: its DeviceCorpus, the RCCL matcher behind the C ABI, the
+    real driver.  (`--parts module:function` swaps this for test doubles on a CPU box.)"""
+    from . import corpus as tc, sharded
+    from .inspector import Inspector
+    shard = tc.DeviceCorpus(a.device)
+    comm = sharded.make_comm(a.device)                          # rank 0's 128-byte id over the default group
+    matcher = sharded.RcclShardedMatcher(shard, comm, k=a.k, cap=a.cap)
+    return dict(shard=shard, matcher=matcher, xdev=f"cuda:{a.device}",
+                inspector=lambda store: Inspector(store, device=f"cuda:{a.device}", max_workers=a.workers))
+
+
+def _child_main(a) -> int:
+    """One rank: process group, shard, tick exchange, store, driver, routes."""
+    from . import db
+    from .inspector import create_app
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ["MASTER_PORT"] = str(a.master_port)
+    if a.backend == "nccl":
+        torch.cuda.set_device(a.device)
+    dist.init_process_group(a.backend, rank=a.rank, world_size=a.ranks,
+                            init_method=f"tcp://127.0.0.1:{a.master_port}")
+    group = dist.new_group(backend=a.backend)                   # the tick thread's own (see RankCorpus)
+    parts = (_load_hook(a.parts) if a.parts else _hip_parts)(a.rank, a.ranks, group, a)
+    rc = RankCorpus(parts["shard"], parts["matcher"], group=group, xdev=parts["xdev"], tick_s=a.tick_s,
+                    owner_fn=FilenameOwner(a.db, a.ranks))
+    store = db.Store(a.db, corpus=rc, census=False)
+    inspector = parts["inspector"](store)
+    app = create_app(inspector)
+
+    @app.route("/rank-info", methods=["GET"])
+    def rank_info():                                            # what the front's readiness probe and the tests read
+        from flask import jsonify
+        rows, keys, _ = rc.stats()
+        return jsonify({"rank": a.rank, "ranks": a.ranks, "rows": rows, "keys": keys, "ticks": rc.ticks,
+                        "busy_ticks": rc.busy_ticks, "exact_asks": rc.exact_asks,
+                        "tick_host_s": rc.tick_host_s, "broken": repr(rc.broken) if rc.broken else None})
+
+    def watchdog():
+        while True:
+            time.sleep(0.2)
+            if rc.broken is not None:
+                sys.stderr.write(f"[tvidz rank {a.rank}] tick loop broke: {rc.broken!r}\n")
+                os._exit(3)
+            if os.getppid() == 1:                               # the parent is gone: so is the service
+                os._exit(4)
+    threading.Thread(target=watchdog, name="tvz-watchdog", daemon=True).start()
+    app.run(host="127.0.0.1", port=a.http_port, threaded=True, use_reloader=False)
+    return 0
+
+
+def create_front(urls: List[str], timeout: float = 30.0):
+    """The thin front: routes by file name, relays bodies untouched."""
+    import requests
+    from flask import Flask, Response, jsonify, request
+
+    app = Flask("tvidz-front")
+    N = len(urls)
+
+    def cors(resp):                                             # app.py:15-19
+        resp.headers["Access-Control-Allow-Origin"] = "*"
+        resp.headers["Access-Control-Allow-Methods"] = "GET, POST, OPTIONS"
+        resp.headers["Access-Control-Allow-Headers"] = "Content-Type"
+        return resp
+
+    app.after_request(cors)
+
+    def relay(r):
+        return Response(r.content, status=r.status_code, mimetype=r.headers.get("Content-Type", "application/json"))
+
+    @app.route("/notify", methods=["POST"])                     # app.py:31-44
+    def notify():
+        data = request.get_json(silent=True)
+        try:
+            key = data["Records"][0]["s3"]["object"]["key"]
+            data["Records"][0]["s3"]["bucket"]["name"]
+        except Exception as e:
+            return jsonify({"error": "Invalid event format", "details": str(e)}), 400
+        r = owner_rank(clean_name(key), N)
+        return relay(requests.post(f"{urls[r]}/notify", json=data, timeout=timeout))
+
+    @app.route("/status/<filename>", methods=["GET"])           # app.py:46-62
+    def status(filename):
+        first = owner_rank(clean_name(filename), N)
+        for r in [first] + [x for x in range(N) if x != first]:
+            resp = requests.get(f"{urls[r]}/status/{filename}", timeout=timeout)
+            try:
+                pending = resp.json().get("status") == "pending"
+            except Exception:
+                pending = False
+            if not pending:
+                return relay(resp)
+        return jsonify({"status": "pending"})
+
+    @app.route("/status/stream/<filename>", methods=["OPTIONS"])    # app.py:23-25
+    def status_stream_options(filename):
+        return cors(Response())
+
+    @app.route("/status/stream/<filename>")                     # app.py:64-115
+    def status_stream(filename):
+        r = owner_rank(clean_name(filename), N)
+        up = requests.get(f"{urls[r]}/status/stream/{filename}", stream=True, timeout=(timeout, None))
+
+        def pump():
+            try:
+                for chunk in up.iter_content(chunk_size=None):
+                    if chunk:
+                        yield chunk
+            finally:
+                up.close()
+        return cors(Response(pump(), mimetype="text/event-stream"))
+
+    @app.route("/admin/clear-db", methods=["POST"])             # app.py:325-333: every rank drops its shard
+    def clear_db():
+        for u in urls:
+            requests.post(f"{u}/admin/clear-db", timeout=timeout)
+        return jsonify({"status": "cleared"})
+
+    @app.route("/ranks", methods=["GET"])
+    def ranks():
+        return jsonify({"ranks": [requests.get(f"{u}/rank-info", timeout=timeout).json() for u in urls]})
+
+    @app.route("/<path:rest>", methods=["GET", "POST"])          # /build-info, /debug/*: rank 0 answers
+    def other(rest):
+        fn = requests.post if request.method == "POST" else requests.get
+        kw = {"json": request.get_json(silent=True)} if request.method == "POST" else {}
+        return relay(fn(f"{urls[0]}/{rest}", timeout=timeout, **kw))
+
+    return app
+
+
+class RankService:
+    """The parent's side: spawn the rank processes, wait until they answer, watch them, stop them.
+    Used by main() and by the tests (which talk to the front through Flask's test client or HTTP)."""
+
+    def __init__(self, ranks: int, db_url: str, base_port: int = 5000, backend: str = "nccl", parts: str = "",
+                 devices: Optional[List[int]] = None, k: int = 64, cap: int = 4096, workers: int = 16,
+                 tick_s: float = 0.0005, env: Optional[dict] = None, ready_timeout: float = 300.0):
+        import socket
+        import subprocess
+        from . import db
+        self.ranks = int(ranks)
+        db.create_schema(db_url)                                # once, before N processes open it side by side
+        with socket.socket() as s:                              # a free rendezvous port
+            s.bind(("127.0.0.1", 0))
+            master_port = s.getsockname()[1]
+        self.urls = [f"http://127.0.0.1:{base_port + 1 + r}" for r in range(self.ranks)]
+        devices = devices or list(range(self.ranks))
+        self.procs = []
+        for r in range(self.ranks):
+            cmd = [sys.executable, "-m", "tvidz_amd.service", "--child", "--rank", str(r), "--ranks", str(self.ranks),
+                   "--master-port", str(master_port), "--http-port", str(base_port + 1 + r), "--db", db_url,
+                   "--backend", backend, "--device", str(devices[r]), "--k", str(k), "--cap", str(cap),
+                   "--workers", str(workers), "--tick-s", str(tick_s)] + (["--parts", parts] if parts else [])
+            e = dict(os.environ)
+            e.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: RCCL between processes needs it here
+            e.update(env or {})
+            self.procs.append(subprocess.Popen(cmd, env=e))
+        self._wait_ready(ready_timeout)
+
+    def _wait_ready(self, timeout: float) -> None:
+        import requests
+        deadline = time.time() + timeout
+        pending = set(range(self.ranks))
+        while pending:
+            dead = self.dead()
+            if dead:
+                self.stop()
+                raise RuntimeError(f"rank process(es) {dead} exited during start-up")
+            if time.time() > deadline:
+                self.stop()
+                raise RuntimeError(f"ranks {sorted(pending)} did not come up within {timeout:.0f} s")
+            for r in list(pending):
+                try:
+                    if requests.get(f"{self.urls[r]}/rank-info", timeout=2).status_code == 200:
+                        pending.discard(r)
+                except Exception:
+                    pass
+            time.sleep(0.2)
+
+    def dead(self) -> List[int]:
+        return [r for r, p in enumerate(self.procs) if p.poll() is not None]
+
+    def stop(self) -> None:
+        for p in self.procs:
+            if p.poll() is None:
+                p.terminate()
+        for p in self.procs:
+            try:
+                p.wait(timeout=10)
+            except Exception:
+                p.kill()
+
+
+def main(argv=None) -> int:  # pragma: no cover - exercised through subprocesses by the tests
+    import argparse
+    ap = argparse.ArgumentParser(prog="python -m tvidz_amd.service",
+                                 description="the inspector service over a corpus sharded across N GPUs (one process each)")
+    ap.add_argument("--ranks", type=int, default=1)
+    ap.add_argument("--port", type=int, default=5000, help="the front; rank r listens on port + 1 + r (loopback)")
+    ap.add_argument("--db", default=os.environ.get("POSTGRES_URL", "postgresql://tvidz:tvidz@postgres:5432/tvidz"))
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"])
+    ap.add_argument("--parts", default="", help="module:function building a rank's shard/matcher/driver (tests)")
+    ap.add_argument("--k", type=int, default=64)
+    ap.add_argument("--cap", type=int, default=4096)
+    ap.add_argument("--workers", type=int, default=16)
+    ap.add_argument("--tick-s", type=float, default=0.0005)
+    ap.add_argument("--child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--rank", type=int, default=0, help=argparse.SUPPRESS)
+    ap.add_argument("--master-port", type=int, default=29500, help=argparse.SUPPRESS)
+    ap.add_argument("--http-port", type=int, default=5001, help=argparse.SUPPRESS)
+    ap.add_argument("--device", type=int, default=0, help=argparse.SUPPRESS)
+    a = ap.parse_args(argv)
+    if a.child:
+        return _child_main(a)
+    svc = RankService(a.ranks, a.db, base_port=a.port, backend=a.backend, parts=a.parts, k=a.k, cap=a.cap,
+                      workers=a.workers, tick_s=a.tick_s)
+
+    def monitor():
+        while True:
+            time.sleep(0.5)
+            dead = svc.dead()
+            if dead:
+                sys.stderr.write(f"[tvidz] rank process(es) {dead} exited: stopping the service\n")
+                svc.stop()
+                os._exit(1)
+    threading.Thread(target=monitor, name="tvz-monitor", daemon=True).start()
+    try:
+        create_front(svc.urls).run(host="0.0.0.0", port=a.port, threaded=True, use_reloader=False)
+    finally:
+        svc.stop()
+    return 0
+
+
+if __name__ == "__main__":  # pragma: no cover
+    sys.exit(main())
