@@ -87,7 +87,8 @@ int main(void) {
     const int n_quiet = n_lat;
     /* upserts far from the probe's keys (> 2500 s): none of them can become a hit */
     double row[LEN], max_upsert_us = 0;
-    double win0[64], win1[64];            /* the upsert calls that rebuilt the index: [start, end] since t_start */
+    enum { MAXWIN = 512 };
+    static double win0[MAXWIN], win1[MAXWIN];   /* the upsert calls that rebuilt the index: [start, end] since t_start */
     int n_win = 0;
     for (int v = 0; v < NEW_ROWS; ++v) {
         for (int j = 0; j < LEN; ++j) row[j] = 2500.0 + (double)(rnd() % 100000) / 7.0;
@@ -103,7 +104,7 @@ int main(void) {
         nanosleep(&gap, NULL);
         int64_t b = 0;
         CHECK(tvz_corpus_index_stats(corpus, NULL, NULL, NULL, NULL, &b));
-        if (b != builds_now && n_win < 64) { win0[n_win] = t0 - t_start; win1[n_win] = t0 - t_start + dt; n_win++; }
+        if (b != builds_now && n_win < MAXWIN) { win0[n_win] = t0 - t_start; win1[n_win] = t0 - t_start + dt; n_win++; }
         builds_now = b;
     }
     stop_flag = 1;
@@ -124,8 +125,21 @@ int main(void) {
         if (k < min_inside) min_inside = k;
         rebuild_us += win1[w] - win0[w];
     }
-    for (int i = n_quiet; i < n_lat; ++i)
-        if (lat[i] > 500.f) fprintf(stderr, "slow lookup: %.0f us, returned at %.0f us (builds then: %lld)\n", lat[i], lat_at[i], (long long)lat_builds[i]);
+    /* every lookup is either OVERLAPPING a rebuild window (it ran, at least partly, while the upsert call that
+     * rebuilt the index was in progress) or OUTSIDE all of them: the two maxima are reported apart, so that a
+     * slow lookup can be attributed - a reader stalled by a rebuild shows up in the first, a hiccup of the
+     * shared host in either */
+    float max_in = 0.f, max_out = 0.f;
+    int n_overlap = 0;
+    for (int i = n_quiet; i < n_lat; ++i) {
+        const double a = lat_at[i] - lat[i], b = lat_at[i];
+        int in = 0;
+        for (int w = 0; w < n_win && !in; ++w) in = a < win1[w] && b > win0[w];
+        if (in) { n_overlap++; if (lat[i] > max_in) max_in = lat[i]; }
+        else if (lat[i] > max_out) max_out = lat[i];
+        if (lat[i] > 500.f) fprintf(stderr, "slow lookup: %.0f us, returned at %.0f us (builds then: %lld, %s a rebuild window)\n",
+                                    lat[i], lat_at[i], (long long)lat_builds[i], in ? "overlapping" : "outside");
+    }
     float *q = malloc(n_quiet * sizeof *q), *w = malloc((n_busy > 0 ? n_busy : 1) * sizeof *w);
     memcpy(q, lat, n_quiet * sizeof *q);
     memcpy(w, lat + n_quiet, n_busy * sizeof *w);
@@ -135,11 +149,12 @@ int main(void) {
            "\"lookups_quiet\": %d, \"quiet_median_us\": %.1f, \"quiet_max_us\": %.1f, "
            "\"lookups_during_upserts\": %d, \"median_us\": %.1f, \"p99_us\": %.1f, \"p999_us\": %.1f, \"max_us\": %.1f, "
            "\"max_upsert_us\": %.1f, \"rebuild_calls_us_mean\": %.1f, \"lookups_completed_inside_rebuilds\": %d, "
-           "\"min_lookups_inside_one_rebuild\": %d, \"wrong_results\": %d}\n",
+           "\"min_lookups_inside_one_rebuild\": %d, \"rebuild_windows\": %d, \"lookups_overlapping_rebuilds\": %d, "
+           "\"max_us_inside_rebuild\": %.1f, \"max_us_outside\": %.1f, \"wrong_results\": %d}\n",
            ROWS, NEW_ROWS, (long long)(b1 - b0), (long long)n_ix, (long long)n_delta, n_quiet, q[n_quiet / 2],
            q[n_quiet - 1], n_busy, n_busy ? w[n_busy / 2] : 0.f, n_busy ? w[(int)(n_busy * 0.99)] : 0.f,
            n_busy ? w[(int)(n_busy * 0.999)] : 0.f, n_busy ? w[n_busy - 1] : 0.f, max_upsert_us,
-           n_win ? rebuild_us / n_win : 0.0, inside, n_win ? min_inside : 0, wrong);
+           n_win ? rebuild_us / n_win : 0.0, inside, n_win ? min_inside : 0, n_win, n_overlap, max_in, max_out, wrong);
     CHECK(tvz_corpus_destroy(corpus));
     return wrong ? 1 : 0;
 }

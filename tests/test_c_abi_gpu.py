@@ -28,8 +28,10 @@ def test_rebuilds_do_not_stall_lookups(tmp_path):
     of the index, ~1 ms of GPU work each), a thread timing every tvz_find_duplicates call from C (no
     GIL in the picture).  Every result is right; lookups START AND FINISH while a rebuild is running
     (none could if readers were drained for rebuilds, as they were in round 2: 5 ms at 100k rows);
-    the 99th percentile stays at the quiet level.  The maximum is reported, not asserted: a shared
-    host stalls lookups and upserts alike for a few milliseconds now and then, rebuild or not."""
+    the 99th percentile stays at the quiet level.  The maximum is split: of the
+    lookups that OVERLAP a rebuild window (the only ones a rebuild could stall) it is asserted
+    (<= 1 ms: a lookup that shares the GPU with the build kernels takes 100-200 us); of the others it
+    is reported - a shared host stalls lookups and upserts alike now and then, rebuild or not."""
     import json
     from tvidz_amd import build
     build.build()
@@ -46,3 +48,5 @@ def test_rebuilds_do_not_stall_lookups(tmp_path):
     assert res["lookups_during_upserts"] > 1000, res
     assert res["min_lookups_inside_one_rebuild"] >= 3, res      # readers ran THROUGH every rebuild (sharing the GPU with it)
     assert res["p99_us"] < 300.0, res
+    assert res["rebuild_windows"] >= 2 and res["lookups_overlapping_rebuilds"] >= 6, res
+    assert res["max_us_inside_rebuild"] <= 1000.0, res          # no reader was stalled by a rebuild

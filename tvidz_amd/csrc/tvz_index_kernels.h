@@ -691,87 +691,15 @@ __device__ __forceinline__ unsigned long long ix_tk_pack(int32_t kth, int32_t vi
     return ((unsigned long long)(uint32_t)kth << 44) | ((unsigned long long)(uint32_t)vid << 12) | cnt;
 }
 
-// ---- the batch's directory probes as ONE pass in front of the lookup (ix_probe_kernel) -------------
-// A lookup block used to start with a chain of three dependent loads - query offsets -> keys ->
-// directory entry, the last one a random 128-byte line per query position - before it could touch a
-// posting; on a 1/8 shard (one sub-index per query) that prologue was 48 % of a block's cycles
-// (profiles/r3_ix_stamps.txt), every rank of a sharded match repeats it for every query, and the
-// 818 k random lines of a 4096-query batch (105 MB for 13-26 MB of entries) were half of the lookup's
-// HBM traffic.  Now one kernel probes all positions of the batch with every load independent and
-// leaves, per query position, a RECORD {first posting, postings per sub-index} in the workspace at
-// a FIXED stride per query: rec[q][word][position], word 0 = first posting, then the uint16 counts two
-// per word (one sub-index: word 1 = the total).  The lookup block reads its records as coalesced runs
-// whose address depends on blockIdx alone - issued together with the load of the query's offsets: one
-// round trip instead of three.
-// The probe pass is laid out for the XCDs' private L2s: the directory is cut into 8 slices by the
-// top bits of the slot, and the blocks that share an XCD (equal blockIdx % 8 - a speed assumption,
-// never correctness) probe only the positions whose slot falls into "their" slice.  Every XCD reads
-// all keys of the batch (coalesced, 6.5 MB) but keeps only 1/8 of the directory (2-4 MB) in its L2:
-// a directory line then comes in from memory once per batch instead of once per probe.
-constexpr int kIxProbeBlock = 256;
-constexpr int kIxProbeQueries = 8;         // queries per probe block (and slice)
-constexpr int kIxProbeParts = 8;           // directory slices = XCDs
-constexpr int kIxPreMinQ = 128;            // smaller batches probe inside the lookup (one launch less)
-inline int ix_rec_words(int ks) { return ks ? 1 + ks / 2 : 2; }
-
-__global__ __launch_bounds__(kIxProbeBlock) void ix_probe_kernel(
-    const unsigned char *__restrict__ dir, int dir_bits, int ks, const double *__restrict__ queries,
-    const int64_t *__restrict__ q_offsets, int32_t Q, int32_t stride, int32_t parts, uint32_t *__restrict__ rec) {
-    const int dir_log2 = dir_bits & 0xff;
-    const uint32_t smask = (1u << (dir_bits >> 8)) - 1u;
-    const int es = 16 + 2 * ks;
-    const int rw = ks ? 1 + ks / 2 : 2;
-    const uint32_t label = parts > 1 ? blockIdx.x % (uint32_t)parts : 0u;
-    const int q0 = (int)(blockIdx.x / (uint32_t)parts) * kIxProbeQueries;
-    const int pshift = dir_log2 >= 3 ? dir_log2 - 3 : 0;
-    for (int q = q0; q < q0 + kIxProbeQueries && q < Q; ++q) {
-        const int64_t qo = q_offsets[q];
-        int64_t n64 = q_offsets[q + 1] - qo;
-        if (n64 > stride) n64 = stride;                 // (the lookup flags such a query; nothing is read past the stride)
-        uint32_t *rq = rec + (size_t)q * rw * stride;
-        for (int i = threadIdx.x; i < (int)n64; i += kIxProbeBlock) {
-            int64_t k;
-            const bool ok = canon_key(queries[qo + i], k);
-            uint32_t s = ok ? ix_slot(k, dir_log2) : 0u;
-            if (parts > 1 && ((s >> pshift) & 7u) != label) continue;      // another XCD's slice of the directory
-            uint32_t base = 0, total = 0;
-            const unsigned char *ent = nullptr;
-            if (ok) {
-                for (int probes = 0; probes < kIxMaxProbe; ++probes) {
-                    const unsigned char *e = dir + (size_t)s * es;
-                    const int4 h = *reinterpret_cast<const int4 *>(e);
-                    const int64_t ek = (int64_t)(((uint64_t)(uint32_t)h.y << 32) | (uint32_t)h.x);
-                    if (ek == k) { base = (uint32_t)h.z; total = (uint32_t)h.w; ent = e; break; }
-                    if (ek == kEmpty) break;
-                    s = (s & ~smask) | ((s + 1) & smask);
-                }
-            }
-            rq[i] = base;
-            if (ks == 0) {
-                rq[stride + i] = total;
-            } else {
-                for (int c = 0; c < ks / 8; ++c) {
-                    const uint4 v = ent ? *reinterpret_cast<const uint4 *>(ent + 16 + 16 * c) : make_uint4(0, 0, 0, 0);
-                    rq[(size_t)(1 + 4 * c) * stride + i] = v.x;
-                    rq[(size_t)(2 + 4 * c) * stride + i] = v.y;
-                    rq[(size_t)(3 + 4 * c) * stride + i] = v.z;
-                    rq[(size_t)(4 + 4 * c) * stride + i] = v.w;
-                }
-            }
-        }
-    }
-}
-
-template <bool HOSTOUT, int MODE, bool TOPK, bool PRE = false>
+template <bool HOSTOUT, int MODE, bool TOPK>
 __device__ __forceinline__ void ix_lookup_body(
     const unsigned char *__restrict__ dir, int dir_bits, int ks, const uint16_t *__restrict__ post,
     const int32_t *__restrict__ ivid, int64_t n_indexed, int32_t n_sub, int32_t spb,
     const double *__restrict__ queries, const int64_t *__restrict__ q_offsets, int32_t max_len,
     int32_t min_match, const int32_t *__restrict__ exclude_ids, int32_t exclude_one, int32_t cap,
     int32_t *__restrict__ hits, int32_t *__restrict__ hits_n, int32_t ns, const QByVal *qv, const int q,
-    const int group, const int n_groups, const int32_t tk_k = 0, const uint32_t *__restrict__ rec = nullptr) {
+    const int group, const int n_groups, const int32_t tk_k = 0) {
     static_assert(!(TOPK && (HOSTOUT || MODE == kIxCount)), "the fused top-k needs kth in the block and a device list");
-    static_assert(!PRE || TOPK, "probe records are read by the kernels whose block owns the query (one group)");
     constexpr bool TOP5 = MODE == kIxTop5;
     const int dir_log2 = dir_bits & 0xff;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -801,22 +729,6 @@ __device__ __forceinline__ void ix_lookup_body(
     const int nsb = (spb + 1) & ~1;
     const bool alone = n_groups == 1;                  // this block owns the query's hit list
     const bool byval = !TOPK && q_offsets == nullptr;      // (the query travels in the kernel arguments)
-    // PRE: this thread's records of the query's first 512 positions - their address depends on
-    // blockIdx alone, so the loads go out together with the offsets' (a position past the query's
-    // end reads a stale record inside the region, which is dropped below)
-    const int rw = ks ? 1 + ks / 2 : 2;
-    uint32_t r_base = 0, r_cnt[4] = {0, 0, 0, 0};
-    if constexpr (PRE) {
-        const uint32_t *rq = rec + (size_t)q * rw * max_len;
-        if ((int)threadIdx.x < max_len) {
-            r_base = rq[threadIdx.x];
-            if (ks == 0) r_cnt[0] = rq[max_len + threadIdx.x];
-            else if (ks == 8) {
-#pragma unroll
-                for (int w = 0; w < 4; ++w) r_cnt[w] = rq[(size_t)(1 + w) * max_len + threadIdx.x];
-            }
-        }
-    }
     const int64_t qo = byval ? 0 : q_offsets[q];
     const int64_t n64 = byval ? qv->n : q_offsets[q + 1] - qo;
     if (n64 > max_len) {       // max_query_len was not an upper bound (the LDS arrays are sized from it)
@@ -853,25 +765,6 @@ __device__ __forceinline__ void ix_lookup_body(
     }
     unsigned long long tk_cut = ~0ull;                     // TOPK: hits >= this cannot make the top-k (block-uniform)
 
-    if constexpr (PRE) {
-        // ---- records of ix_probe_kernel: first posting + the counts of all sub-indexes (this block walks
-        // them all) straight into e_cur / e_len ----
-        uint32_t *el32 = reinterpret_cast<uint32_t *>(e_len);       // nsb is even: nsb / 2 words per position
-        const int nw = nsb / 2;
-        const uint32_t *rq = rec + (size_t)q * rw * max_len;
-        for (int i = threadIdx.x; i < n; i += kIxBlock) {
-            const bool first = i == (int)threadIdx.x;               // loaded ahead of the offsets
-            e_cur[i] = first ? r_base : rq[i];
-            if (ks == 0) {
-                el32[i] = (first ? r_cnt[0] : rq[max_len + i]) & 0xffffu;
-            } else if (ks == 8 && first) {
-#pragma unroll
-                for (int w = 0; w < 4; ++w) if (w < nw) el32[(size_t)i * nw + w] = r_cnt[w];
-            } else {
-                for (int w = 0; w < nw; ++w) el32[(size_t)i * nw + w] = rq[(size_t)(1 + w) * max_len + i];
-            }
-        }
-    } else {
     // ---- directory: ONE probe per query position; the counts of this block's sub-indexes to LDS ----
     const uint32_t smask = (1u << (dir_bits >> 8)) - 1u;   // probes wrap inside the directory slice
     const int es = 16 + 2 * ks;
@@ -912,7 +805,6 @@ __device__ __forceinline__ void ix_lookup_body(
             }
         }
         e_cur[i] = base;
-    }
     }
     __syncthreads();
     TVZ_STAMP(0);
@@ -1387,16 +1279,16 @@ __global__ __launch_bounds__(kIxBlock) __attribute__((amdgpu_waves_per_eu(8, 8))
 
 // the lookup with the per-shard top-k in its epilogue: grid = (Q), one block per query over ALL
 // sub-indexes; topk = [Q][k + 1][3] (k best + totals row), no hit list, no counters
-template <int MODE, bool PRE>
+template <int MODE>
 __global__ __launch_bounds__(kIxBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) void ts_match_index_topk_kernel(
     const unsigned char *__restrict__ dir, int dir_bits, int ks, const uint16_t *__restrict__ post,
     const int32_t *__restrict__ ivid, int64_t n_indexed, int32_t n_sub,
     const double *__restrict__ queries, const int64_t *__restrict__ q_offsets, int32_t max_len,
     int32_t min_match, const int32_t *__restrict__ exclude_ids, int32_t cap, int32_t k,
-    int32_t *__restrict__ topk, const uint32_t *__restrict__ rec) {
-    ix_lookup_body<false, MODE, true, PRE>(dir, dir_bits, ks, post, ivid, n_indexed, n_sub, n_sub, queries, q_offsets,
-                                           max_len, min_match, exclude_ids, -1, cap, topk, nullptr, 1, nullptr,
-                                           (int)blockIdx.x, 0, 1, k, rec);
+    int32_t *__restrict__ topk) {
+    ix_lookup_body<false, MODE, true>(dir, dir_bits, ks, post, ivid, n_indexed, n_sub, n_sub, queries, q_offsets,
+                                      max_len, min_match, exclude_ids, -1, cap, topk, nullptr, 1, nullptr,
+                                      (int)blockIdx.x, 0, 1, k);
 }
 
 // tvz_find_duplicates on an indexed corpus with rows in the delta table - the streaming driver's call:

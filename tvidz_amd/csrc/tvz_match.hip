@@ -742,18 +742,8 @@ struct WsLayout {
     int32_t *gathered = nullptr;    // [n_ranks][Q][k+1][3]
     int32_t *flags = nullptr;       // [Q] queries the one-wave top-k left to the block kernels
     int32_t *pair = nullptr;        // [2][Q][k+1][3] fused lookup: the index's block + the delta sweep's, merged into `local`
-    uint32_t *rec = nullptr;        // probe records of the batch (ix_probe_kernel): [Q][words][max_query_len]
-    size_t rec_bytes = 0;
     size_t total = 0;
 };
-
-// the record region: room for directory entries of up to 16 sub-indexes (262k rows on this handle),
-// at most 64 MiB - a batch or a corpus beyond that probes inside the lookup blocks as before
-constexpr size_t kRecMaxBytes = (size_t)64 << 20;
-size_t rec_region_bytes(int32_t Q, int32_t max_query_len) {
-    const size_t want = (size_t)Q * (size_t)std::max(max_query_len, 0) * 4 * 9;
-    return std::min(want, kRecMaxBytes);
-}
 
 size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
 
@@ -782,9 +772,6 @@ WsLayout ws_layout(void *base, int32_t Q, int32_t max_query_len, int32_t cap, in
         if (k <= kIxTkMaxK) {
             w.pair = reinterpret_cast<int32_t *>(p);
             p += al256((size_t)2 * (size_t)Q * (size_t)(k + 1) * 12);
-            w.rec = reinterpret_cast<uint32_t *>(p);
-            w.rec_bytes = rec_region_bytes(Q, max_query_len);
-            p += al256(w.rec_bytes);
         }
     }
     w.total = (size_t)(p - p0) + 256;
@@ -1011,30 +998,19 @@ bool index_topk_usable(const tvz_corpus *c, int32_t Q, int32_t max_query_len, in
     return ix_lds_bytes(max_query_len, ix.n_sub, true) <= (size_t)kIxMaxLds;
 }
 
-// `rec` / `rec_bytes`: the workspace's record region.  A batch of kIxPreMinQ+ queries whose records fit
-// it is probed by ONE pass in front of the lookup (ix_probe_kernel); the lookup blocks then start from
-// coalesced records instead of a chain of dependent loads.
+// (A separate probe pass in front of this kernel - every directory probe of the batch in one launch, the
+// lookup blocks starting from coalesced records - was measured in round 4 and lost: the lookup got 10.7 us
+// faster on a 1/8 shard, the probe pass cost 27 us: profiles/r4_probe_prepass.txt.)
 int launch_index_topk(tvz_corpus *c, const double *d_queries, const int64_t *d_q_offsets, int32_t Q,
                       int32_t max_query_len, int32_t min_match, const int32_t *d_exclude_ids, int32_t cap,
-                      int32_t k, int32_t *d_block, uint32_t *rec, size_t rec_bytes, hipStream_t st) {
+                      int32_t k, int32_t *d_block, hipStream_t st) {
     const IndexBuf &ix = c->ix.now();
     const size_t lds = ix_lds_bytes(max_query_len, ix.n_sub, true);
-    static const int pre_mode = getenv("TVZ_IX_PRE") ? atoi(getenv("TVZ_IX_PRE")) : 8;   // 0 = off, 1 = unsliced, 8 = per XCD (diagnostics)
-    const size_t need = (size_t)Q * (size_t)ix_rec_words(ix.ks) * (size_t)max_query_len * 4;
-    const bool pre = pre_mode > 0 && rec != nullptr && Q >= kIxPreMinQ && max_query_len > 0 && need <= rec_bytes;
-    if (pre) {
-        const int parts = pre_mode >= 8 ? kIxProbeParts : 1;
-        const unsigned blocks = (unsigned)(tvz::ceil_div(Q, kIxProbeQueries) * parts);
-        hipLaunchKernelGGL(ix_probe_kernel, dim3(blocks), dim3(kIxProbeBlock), 0, st, ix.dir.p, ix.dir_bits(), ix.ks,
-                           d_queries, d_q_offsets, Q, max_query_len, parts, rec);
-        TVZ_HIP(hipGetLastError());
-    }
-#define TVZ_IXK(MODE, PRE)                                                                                  \
-    hipLaunchKernelGGL((ts_match_index_topk_kernel<MODE, PRE>), dim3((unsigned)Q), dim3(kIxBlock), lds, st,   \
+#define TVZ_IXK(MODE)                                                                                       \
+    hipLaunchKernelGGL((ts_match_index_topk_kernel<MODE>), dim3((unsigned)Q), dim3(kIxBlock), lds, st,        \
                        ix.dir.p, ix.dir_bits(), ix.ks, ix.post.p, ix.ivid.p, ix.n_main, ix.n_sub, d_queries,   \
-                       d_q_offsets, max_query_len, min_match, d_exclude_ids, cap, k, d_block, rec)
-    if (min_match <= 2) { if (pre) TVZ_IXK(kIxM2, true); else TVZ_IXK(kIxM2, false); }
-    else { if (pre) TVZ_IXK(kIxTop5, true); else TVZ_IXK(kIxTop5, false); }
+                       d_q_offsets, max_query_len, min_match, d_exclude_ids, cap, k, d_block)
+    if (min_match <= 2) TVZ_IXK(kIxM2); else TVZ_IXK(kIxTop5);
 #undef TVZ_IXK
     TVZ_HIP(hipGetLastError());
     return TVZ_OK;
@@ -1264,7 +1240,7 @@ int tvz_match_topk_local(tvz_corpus *c, const double *d_queries, const int64_t *
         const int64_t n_delta = c->ix.n_delta;
         int32_t *blk = n_delta ? w.pair : d_out;
         if (int rc = launch_index_topk(c, d_queries, d_q_offsets, Q, max_query_len, min_match, d_exclude_ids, cap, k,
-                                       blk, w.rec, w.rec_bytes, st))
+                                       blk, st))
             return rc;
         if (n_delta) {
             const RowSpan span{c->ix.now().drows.p, n_delta};
@@ -1342,11 +1318,10 @@ static int tvz_corpus_create_impl(tvz_corpus **out, int device) {
     TVZ_IX_ATTR(false, kIxM2); TVZ_IX_ATTR(false, kIxTop5); TVZ_IX_ATTR(false, kIxCount);
     TVZ_IX_ATTR(true, kIxM2); TVZ_IX_ATTR(true, kIxTop5);
 #undef TVZ_IX_ATTR
-#define TVZ_IXK_ATTR(M, P)                                                                         \
-    TVZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(ts_match_index_topk_kernel<M, P>),      \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, kIxMaxLds))
-    TVZ_IXK_ATTR(kIxM2, false); TVZ_IXK_ATTR(kIxM2, true); TVZ_IXK_ATTR(kIxTop5, false); TVZ_IXK_ATTR(kIxTop5, true);
-#undef TVZ_IXK_ATTR
+    TVZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(ts_match_index_topk_kernel<kIxM2>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, kIxMaxLds));
+    TVZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(ts_match_index_topk_kernel<kIxTop5>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, kIxMaxLds));
     TVZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(ix_slice_count_kernel),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)kIxSliceBytesMax));
     TVZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(ix_slice_fill_kernel),

@@ -503,7 +503,9 @@ __global__ __launch_bounds__(kJoinBlock, 8) void ts_match_join_kernel(
     int32_t min_match, const int32_t *__restrict__ exclude_ids, int32_t cap,
     int32_t *__restrict__ hits, int32_t *__restrict__ hits_n, int32_t ns) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // the wave index in an SGPR: the row counter of the sweep below is wave-uniform, and as a 64-bit VGPR
+    // pair at the 64-register cap it was spilled to scratch and reloaded once per row
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     uint32_t *w0 = reinterpret_cast<uint32_t *>(smem) + wave * kJoinSlots;                     // (q+1) << 20 | count
     uint32_t *m1 = reinterpret_cast<uint32_t *>(smem) + (kJoinWaves + wave) * kJoinSlots;      // smallest position
     uint32_t *m2 = reinterpret_cast<uint32_t *>(smem) + (2 * kJoinWaves + wave) * kJoinSlots;  // second smallest
