@@ -184,11 +184,17 @@ def bench_match(args, rank, world, dev):
     C = args.corpus
     Q = args.queries
     ids, offs, keys = synth.synth_timestamp_corpus(C, seed=synth.CORPUS_SEED)
-    queries = synth.synth_queries(ids, offs, keys, Q, seed=synth.CORPUS_SEED + 1)
+    # NB distinct query batches ROTATE through every timed loop below (a loop that
+    # replays one batch measures directory lines and postings that are already in the caches)
+    NB = 8
+    q_sets = [synth.synth_queries(ids, offs, keys, Q, seed=synth.CORPUS_SEED + 1 + b) for b in range(NB)]
+    queries = q_sets[0]
     s_ids, s_offs, s_keys = sharded.shard_csr(ids, offs, keys, rank, world)
     dc = tc.DeviceCorpus(dev.index)
     dc.upload_csr(s_ids, s_offs, s_keys)
-    d_q, d_off, max_len = tc.pack_queries(queries, dev)
+    batches = [tc.pack_queries(qs, dev) for qs in q_sets]
+    max_len = max(b[2] for b in batches)
+    d_q, d_off, _ = batches[0]
     K_TOP = 16          # per-shard top-k travelling in the all-gather: [Q,17,3] int32 per rank
     CAP = 16384         # per-shard hit-list capacity per query (synthetic corpora: ~2,100 hits per
     #                     query at min_match=2 over 100k videos; overflows are counted below)
@@ -197,20 +203,35 @@ def bench_match(args, rank, world, dev):
     # ships the 128-byte RCCL id
     comm = sharded.make_comm(dev.index)
     sm = sharded.RcclShardedMatcher(dc, comm, k=K_TOP, cap=CAP)
-    for _ in range(20):
-        merged, totals = sm.match_topk(d_q, d_off, max_len, 2)
+    # the very first batch this handle ever answers: nothing of the index is in any cache
+    torch.cuda.synchronize()
+    tc0 = time.perf_counter()
+    merged, totals = sm.match_topk(batches[NB - 1][0], batches[NB - 1][1], max_len, 2)
+    torch.cuda.synchronize()
+    first_batch_ms = (time.perf_counter() - tc0) * 1e3
+    for i in range(20):
+        merged, totals = sm.match_topk(batches[i % NB][0], batches[i % NB][1], max_len, 2)
     barrier_sync(world)
     t0 = time.perf_counter()
     # a stream of query batches over two HIP streams: the all-gather + merge of batch i overlap the
     # sweep of batch i+1; every batch is fully merged inside the timed region
-    ticket = sm.submit(d_q, d_off, max_len, 2, inputs_ready=True)
-    for _ in range(args.match_steps - 1):
-        nxt = sm.submit(d_q, d_off, max_len, 2, inputs_ready=True)
+    ticket = sm.submit(batches[0][0], batches[0][1], max_len, 2, inputs_ready=True)
+    for i in range(1, args.match_steps):
+        nxt = sm.submit(batches[i % NB][0], batches[i % NB][1], max_len, 2, inputs_ready=True)
         merged, totals = sm.finish(ticket, host=True)
         ticket = nxt
     merged, totals = sm.finish(ticket, host=True)
     barrier_sync(world)
     wall = max_over_ranks(time.perf_counter() - t0, world, dev)
+    # the same loop replaying ONE batch (what rounds 1-3 timed), for the record
+    t0 = time.perf_counter()
+    ticket = sm.submit(d_q, d_off, max_len, 2, inputs_ready=True)
+    for i in range(1, args.match_steps):
+        nxt = sm.submit(d_q, d_off, max_len, 2, inputs_ready=True)
+        sm.finish(ticket, host=True)
+        ticket = nxt
+    sm.finish(ticket, host=True)
+    replay_ms = (time.perf_counter() - t0) * 1e3 / args.match_steps
     pairs = Q * C * args.match_steps
     mean_len = float(offs[-1]) / C
     bytes_per_pair = 8.0 * mean_len + 8.0
@@ -221,11 +242,23 @@ def bench_match(args, rank, world, dev):
     # shard; every launch of one tvz_match call): once as the service runs it (AUTO: inverted-index
     # lookup, the delta table is empty here) and once forced onto the corpus sweep (hash join)
     st = torch.cuda.Stream(dev)
-    ws = torch.empty(tc.workspace_bytes(Q, max_len), dtype=torch.uint8, device=dev)
+    ws = torch.empty(tc.workspace_bytes(Q, max_len, CAP, K_TOP), dtype=torch.uint8, device=dev)
     hits = torch.empty((Q, CAP, 3), dtype=torch.int32, device=dev)
     n_h = torch.empty(Q, dtype=torch.int32, device=dev)
-    index_ms = kernel_ms(lambda: dc.match(d_q, d_off, max_len, 2, CAP, out_hits=hits, out_n=n_h, stream=st,
-                                          workspace=ws), st)
+    blk = torch.empty((Q, K_TOP + 1, 3), dtype=torch.int32, device=dev)
+    rot = {"i": 0}
+
+    def fused_call(handle):
+        def f():
+            b = batches[rot["i"] % NB]
+            rot["i"] += 1
+            handle.match_topk(b[0], b[1], max_len, 2, CAP, K_TOP, out=blk, workspace=ws, stream=st)
+        return f
+    # the kernel a batch spends its time in: the lookup with the top-k in its epilogue (one launch per call)
+    index_ms = kernel_ms(fused_call(dc), st, reps=28, skip=4)
+    # the unfused lookup (tvz_match: full hit lists + counter gather), for comparison and for the hit count
+    unfused_ms = kernel_ms(lambda: dc.match(d_q, d_off, max_len, 2, CAP, out_hits=hits, out_n=n_h, stream=st,
+                                            workspace=ws), st)
     n_hits = int(n_h.clamp(min=0).sum().item())
     sweep_ms = kernel_ms(lambda: dc.match(d_q, d_off, max_len, 2, CAP, out_hits=hits, out_n=n_h, stream=st,
                                           workspace=ws, algo=_lib.ALGO_JOIN), st)
@@ -234,10 +267,18 @@ def bench_match(args, rank, world, dev):
     corpus_bytes = 16.0 * shard_rows + 8.0 * shard_keys
     # postings the batch walks on this shard: for every query element, the rows that hold its key
     uk, uc = np.unique(s_keys.view(np.int64), return_counts=True)
-    qk = np.concatenate([np.asarray(q, dtype=np.float64) for q in queries]).view(np.int64)
-    pos = np.searchsorted(uk, qk)
-    pos[pos >= len(uk)] = 0
-    postings = int(uc[pos][uk[pos] == qk].sum())
+    qks = [np.concatenate([np.asarray(q, dtype=np.float64) for q in qs]).view(np.int64) for qs in q_sets]
+    qk = qks[0]
+
+    def postings_of(uk_, uc_):                        # mean over the rotating batches
+        tot = 0
+        for qk_ in qks:
+            pos = np.searchsorted(uk_, qk_)
+            pos[pos >= len(uk_)] = 0
+            tot += int(uc_[pos][uk_[pos] == qk_].sum())
+        return tot / len(qks)
+    postings = postings_of(uk, uc)
+    n_elems = float(np.mean([len(x) for x in qks]))
     n_sub = -(-shard_rows // 16384)
     # tvz_match.hip join_shape(): tiles of <= 1024 queries whose elements fit a 2 MiB table at load 0.55
     q_per_tile = max(1, min(1024, int(0.55 * (1 << 19)) // max(max_len, 1), Q))
@@ -246,60 +287,61 @@ def bench_match(args, rank, world, dev):
     out = {"value": pairs / wall, "unit": "pairs/s", "corpus_videos": C, "queries_per_batch": Q,
            "mean_cuts_per_video": round(mean_len, 1), "min_match": 2, "steps": args.match_steps,
            "ms_per_batch": wall * 1e3 / args.match_steps,
-           "algo": "AUTO = inverted-index lookup (one block per query and sub-index of 16384 rows) + sweep of the "
-                   "delta table (empty here); identical hits to the full sweep (tests/test_index_gpu.py)",
+           "ms_per_batch_one_batch_replayed": replay_ms, "first_batch_ms_cold": first_batch_ms,
+           "distinct_query_batches_rotating": NB,
+           "algo": "AUTO = inverted-index lookup, ONE block per query walking the query's sub-indexes of 16384 rows "
+                   "and keeping the per-shard top-k in its epilogue (no hit lists, no top-k launch) + sweep of the "
+                   "delta table (empty here); identical rows to the full sweep + top-k (tests/test_index_topk_gpu.py)",
            "index": ix,
            "collective": (f"tvz_match_sharded (C ABI): one ncclAllGather of [Q,{K_TOP + 1},3] int32 per batch "
                           f"(top-{K_TOP} + hit totals) over {world} rank(s), overlapped with the next batch's match"),
            "queries_with_hits": n_dups, "mean_hits_per_query": round(mean_hits, 1),
            "hit_list_capacity": CAP, "queries_with_overflowed_shard_lists": n_over,
            "scaling": "strong (the same corpus is sharded over the ranks)",
-           "match_ms_per_batch_rank0": index_ms, "sweep_ms_per_batch_rank0": sweep_ms,
-           "predicted_scaling": "profiles/r3_predicted_scaling.json (single-GPU shard timings; no multi-GPU box was available)"}
+           "match_ms_per_batch_rank0": index_ms, "unfused_lookup_ms_per_batch_rank0": unfused_ms,
+           "sweep_ms_per_batch_rank0": sweep_ms,
+           "predicted_scaling": "profiles/r4_predicted_scaling.json (single-GPU shard timings; no multi-GPU box was available)"}
     tag = f"C{C}_Q{Q}"
     # ---- roofline of the kernel the batch spends its time in: the index lookup ----
     # algorithmic bytes: every posting of the query's keys once (2 B), ONE directory entry
     # (16 B head + 2 B per sub-index, rounded up to 8 sub-indexes; 16 B on a one-sub-index shard) and the
     # 8-byte query key per query element, 12 B per hit
-    def ix_alg_bytes(n_sub_, postings_, n_hits_):
+    def ix_alg_bytes(n_sub_, postings_):
         entry = 16 + (0 if n_sub_ <= 1 else 2 * ((n_sub_ + 7) // 8 * 8))
-        return postings_ * 2.0 + len(qk) * (entry + 8.0) + n_hits_ * 12.0, entry
-    alg_ix, entry_bytes = ix_alg_bytes(n_sub, postings, n_hits)
-    t_ix, t_src = pmc_traffic("ts_match_index", tag=tag + "_index") if world == 1 else (None, None)
+        return postings_ * 2.0 + n_elems * (entry + 8.0) + Q * (K_TOP + 1) * 12.0, entry
+    alg_ix, entry_bytes = ix_alg_bytes(n_sub, postings)
+    t_ix, t_src = pmc_traffic("ts_match_index_topk", tag="topk") if world == 1 else (None, None)
     out["roofline"] = {
         "bound": "hbm",
-        "kernel": "ts_match_index_kernel (the event pair also covers the counter gather, < 2 % of it)",
+        "kernel": "ts_match_index_topk_kernel (one launch per batch; 8 query batches rotating)",
         "achieved": alg_ix / (index_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": alg_ix / (index_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
         "traffic": t_ix, "traffic_source": t_src,
         "algorithmic_bytes_per_launch": alg_ix, "avg_launch_ms": index_ms,
-        "algorithmic_bytes": f"{postings} postings x 2 B + one {entry_bytes} B directory entry and one 8 B query key per "
-                             f"query element ({len(qk)}) + {n_hits} hits x 12 B",
+        "algorithmic_bytes": f"{postings:.0f} postings x 2 B + one {entry_bytes} B directory entry and one 8 B query key per "
+                             f"query element ({n_elems:.0f}) + {Q} x {K_TOP + 1} output rows x 12 B (means over the rotating "
+                             f"batches; the {n_hits} hits of a batch are no longer written)",
         "limiter": "not HBM bandwidth: instruction issue and LDS latency inside a block (one block per query walks "
                    "its sub-indexes: per sub-index ~300 postings per wave through two LDS passes and five block "
-                   "barriers); s_memtime stamps in profiles/r3_ix_stamps.txt, counters in profiles/r3_match_pmc.txt"}
+                   "barriers); s_memtime stamps in profiles/r3_ix_stamps.txt, counters in profiles/r4_match_pmc.txt"}
     # ---- the same batch against rank 0's share of an 8-way sharded corpus: what every GPU of configs[3] runs ----
     if world == 1:
         s8 = sharded.shard_csr(ids, offs, keys, 0, 8)
         dc8 = tc.DeviceCorpus(dev.index)
         dc8.upload_csr(*s8)
-        ms8 = kernel_ms(lambda: dc8.match(d_q, d_off, max_len, 2, CAP, out_hits=hits, out_n=n_h, stream=st,
-                                          workspace=ws), st)
-        hits8 = int(n_h.clamp(min=0).sum().item())
+        ms8 = kernel_ms(fused_call(dc8), st, reps=28, skip=4)
         uk8, uc8 = np.unique(s8[2].view(np.int64), return_counts=True)
-        pos8 = np.searchsorted(uk8, qk)
-        pos8[pos8 >= len(uk8)] = 0
-        post8 = int(uc8[pos8][uk8[pos8] == qk].sum())
+        post8 = postings_of(uk8, uc8)
         rows8 = dc8.stats()[0]
-        alg8, entry8 = ix_alg_bytes(-(-rows8 // 16384), post8, hits8)
-        t8, t8_src = pmc_traffic("ts_match_index", tag=f"C{rows8}_Q{Q}")
+        alg8, entry8 = ix_alg_bytes(-(-rows8 // 16384), post8)
+        t8, t8_src = pmc_traffic("ts_match_index_topk", tag="shard8")        # (keyed by workload: the r3 line looked up a row count)
         out["shard8_roofline"] = {
-            "bound": "hbm", "kernel": f"ts_match_index_kernel on rank 0's 1/8 shard ({rows8} rows), the same {Q} queries",
+            "bound": "hbm", "kernel": f"ts_match_index_topk_kernel on rank 0's 1/8 shard ({rows8} rows), the same rotating batches of {Q} queries",
             "achieved": alg8 / (ms8 * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": alg8 / (ms8 * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": t8, "traffic_source": t8_src,
             "algorithmic_bytes_per_launch": alg8, "avg_launch_ms": ms8,
-            "limiter": "the per-query fixed chain (offsets -> keys -> directory probe -> postings) that does not "
-                       "shrink with the shard: 40 % of a block's cycles are the probe phase (profiles/r3_ix_stamps.txt)"}
+            "limiter": "instruction issue, as on the full corpus, plus the per-query part that does not shrink with the "
+                       "shard (offsets -> keys -> directory probe: 10.7 us net of the 60 us launch, profiles/r4_probe_prepass.txt)"}
         dc8.close()
     # ---- the same batch forced onto the corpus sweep (what AUTO runs without an index) ----
     alg = corpus_bytes * n_tiles + n_hits * 12.0
@@ -458,11 +500,15 @@ def bench_config0(dev, n_threads: int = 0):
     return res
 
 
-def bench_e2e(dev, n_uploads: int = 8, n_frames: int = 256):
+def bench_e2e(dev, rank: int = 0, world: int = 1, n_uploads: int = 8, n_frames: int = 256):
     """A bounded run of the whole driver (BASELINE.json configs[4]'s shape at 1080p): N concurrent
     uploads as mono Y4M files in RAM -> reader threads -> pinned slot pool -> H2D -> scene kernels ->
     one match per micro-batch -> write-behind SQL.  PCIe-inclusive; never part of `value`.  The 16 /
-    64-upload and 4K figures are in profiles/r3_e2e_service.txt (profiles/e2e_service.py)."""
+    64-upload and 4K figures are in profiles/r4_e2e_service.txt (profiles/e2e_service.py).
+    world > 1 (`--gpus N` under torch.distributed.run): every rank runs this leg over
+    service.RankCorpus(RcclShardedMatcher) - its shard of the table, the collective tick exchange with
+    the other ranks - on its own uploads; the figure is all ranks' frames over the slowest rank's time.
+    UNMEASURED ON HARDWARE for N > 1: no box of this project has had two GPUs."""
     import shutil
     import tempfile
     from tvidz_amd import db as tdb, feeder, inspector as insp
@@ -477,28 +523,60 @@ def bench_e2e(dev, n_uploads: int = 8, n_frames: int = 256):
             files[name] = os.path.join(tmp, name)
             feeder.write_y4m(files[name], fr.cpu().numpy(), fps=(30, 1), chroma="mono")
             del fr
-        store = tdb.Store(f"sqlite:///{tmp}/tvidz.db", device=dev.index)
         ids, offs, keys = synth.synth_timestamp_corpus(5000, seed=1)
-        store.corpus.upload_csr(ids + 100000, offs, keys)
+        lib_rows = [(int(ids[c]) + 100000, keys[offs[c]:offs[c + 1]].tolist()) for c in range(len(ids))]
+        rc = None
+        if world > 1:
+            from tvidz_amd import service
+            shard = tc.DeviceCorpus(dev.index)
+            group = dist.new_group(backend="nccl")                       # the tick thread's own
+            matcher = sharded.RcclShardedMatcher(shard, sharded.make_comm(dev.index), k=64, cap=4096)
+            rc = service.RankCorpus(shard, matcher, group=group, xdev=str(dev))
+            store = tdb.Store(f"sqlite:///{tmp}/tvidz.db", corpus=rc, census=False)   # this rank's partition of the table
+
+            def load():
+                store.clear()
+                # (separate SQLite files per rank: keep the video ids of the ranks apart, as one shared table would)
+                s_ = store.SessionLocal()
+                try:
+                    s_.add(tdb.Video(id=(rank + 1) * 1000000, filename=f"rank{rank}-floor"))
+                    s_.commit()
+                finally:
+                    s_.close()
+                rc.upload(lib_rows)                                      # video_id mod world == rank stay here
+        else:
+            store = tdb.Store(f"sqlite:///{tmp}/tvidz.db", device=dev.index)
+
+            def load():
+                store.clear()
+                store.corpus.upload_csr(ids + 100000, offs, keys)
+        load()
         ins = insp.Inspector(store, device=str(dev), frame_source=lambda b, k, f, u: (feeder.Y4MReader(files[k]), None),
                              batch=256, max_workers=n_uploads)
         [f.result() for f in [ins.submit("videos", k) for k in files]]          # warm-up: slots, scorers, SQL
         ok, dts = True, []
         for _ in range(3):               # three timed passes, the median reported: a 0.15 s run is at the host's mercy
-            store.clear()
-            store.corpus.upload_csr(ids + 100000, offs, keys)
+            load()
+            barrier_sync(world)
             t0 = time.perf_counter()
             res = [f.result() for f in [ins.submit("videos", k) for k in files]]
-            dts.append(time.perf_counter() - t0)
+            dts.append(max_over_ranks(time.perf_counter() - t0, world, dev))
             ok = ok and all(r["status"] == "done" for r in res)
         dt = float(np.median(dts))
         ins.close()
-        store.close()
-        return {"value": n_uploads * n_frames / dt, "unit": "frames/s", "uploads": n_uploads, "frames_per_upload": n_frames,
-                "height": H, "width": W, "all_done": ok, "GBps_luma": n_uploads * n_frames * FRAME_BYTES / dt / 1e9,
-                "passes_s": [round(x, 4) for x in dts],
+        tick = None
+        if rc is not None:
+            tick = {"ticks": rc.ticks, "busy_ticks": rc.busy_ticks, "exact_asks": rc.exact_asks,
+                    "host_us_per_busy_tick": round(rc.tick_host_s * 1e6 / max(rc.busy_ticks, 1), 1)}
+            barrier_sync(world)
+        store.close()                    # (RankCorpus.close is collective: every rank gets here)
+        total = world * n_uploads * n_frames
+        return {"value": total / dt, "unit": "frames/s", "uploads": world * n_uploads, "frames_per_upload": n_frames,
+                "ranks": world, "rank_tick": tick, "unmeasured_on_hardware_for_ranks_above_1": world > 1,
+                "height": H, "width": W, "all_done": ok, "GBps_luma": total * FRAME_BYTES / dt / 1e9,
+                "passes_s": [round(x, 4) for x in dts], "passes_fps": [round(total / x) for x in dts],
                 "note": "whole Python driver, PCIe-inclusive, files in RAM, no decoder; short clips: per-upload set-up "
-                        "(SQL insert, reader thread, first slot) is inside the wall time.  profiles/r3_e2e_service.txt: "
+                        "(SQL insert, reader thread, first slot) is inside the wall time.  profiles/r4_e2e_service.txt: "
                         "16 / 64 uploads x 512 frames 24 / 31 k fps (H2D bound 27.6 k at one copy in flight), 64 x 4K 5.6-5.8 k fps"}
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
@@ -623,11 +701,15 @@ def main():
     torch.cuda.empty_cache()
     if rank == 0 and world == 1 and not args.no_cpu:
         out["config0"] = bench_config0(dev, args.cpu_threads)
-    if rank == 0 and world == 1 and not args.no_e2e:
+    if not args.no_e2e:                   # every rank: the N-rank leg is collective (the tick exchange)
         try:
-            out["e2e"] = bench_e2e(dev)
+            e2e = bench_e2e(dev, rank, world)
         except Exception as e:            # the driver needs SQLAlchemy + a writable temp directory: report, don't die
-            out["e2e"] = {"error": repr(e)}
+            e2e = {"error": repr(e)}
+            if world > 1:
+                print(f"[bench] e2e leg failed on rank {rank}: {e!r}", file=sys.stderr)
+        if rank == 0:
+            out["e2e"] = e2e
         torch.cuda.empty_cache()
     if match_leg is not None:
         out["match"] = match_leg

@@ -71,6 +71,9 @@ try:
                       "cuts_total": sum(r["total_cuts"] for r in res), "dups_total": sum(len(r["duplicates"]) for r in res),
                       "phase_thread_seconds": {k: (round(v, 3) if isinstance(v, float) else v)
                                                for k, v in sorted(ins.phase_seconds.items()) if not k.startswith("n_")},
+                      "tick": ({"ticks": corpus.batcher.ticks, "asks": corpus.batcher.asks, "exact_asks": corpus.exact_asks,
+                                "tick_wall_s": round(corpus.tick_host_s, 4),
+                                "us_per_tick": round(corpus.tick_host_s * 1e6 / max(corpus.batcher.ticks, 1), 1)} if SHARDS else None),
                       "tmp": "shm" if root else "disk"}))
     store.close()
 finally:

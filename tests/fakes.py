@@ -197,3 +197,48 @@ def cpu_rank_parts(rank, world, group, a):
                 inspector=lambda store: cut_inspector(
                     store, device="cuda:0", max_workers=a.workers,
                     frame_source=lambda bucket, key, filename, uid: (CutReader(cuts_of_key(key)), None)))
+
+
+# ---- the N-rank service on the GPU at world size 1 (tests/test_service_gpu.py) --------------------
+class KeyedClipReader:
+    """A procedural clip named by its S3 key `<stamp>-<name>__<pts0>__<c0>_<c1>_...`: flat scenes whose
+    level changes by >= 45 at the listed frame numbers (what the scene filter selects) + 2-bit noise;
+    the reader protocol of tvidz_amd.feeder (H, W, time_base, total_frames, bitdepth, read_into, pts_of)."""
+    H, W, T = 96, 128, 64
+    LEVELS = [40, 130, 220, 85, 175, 30, 120, 210]
+
+    def __init__(self, key):
+        body = key.split("/")[-1].rsplit(".", 1)[0].split("__")
+        self.pts0 = int(body[1])
+        self.cuts = [int(x) for x in body[2].split("_")]
+        self.time_base, self.total_frames, self.bitdepth = (1, 30), self.T, 8
+        self.t, self.closed = 0, False
+        self.noise = np.random.default_rng(4).integers(0, 4, size=(self.H, self.W), dtype=np.uint8)
+
+    def read_into(self, out):
+        n = 0
+        while n < out.shape[0] and self.t < self.T and not self.closed:
+            level = self.LEVELS[sum(1 for c in self.cuts if c <= self.t) % len(self.LEVELS)]
+            np.add(self.noise, self.t & 3, out=out[n])
+            np.bitwise_and(out[n], 3, out=out[n])
+            out[n] += level
+            self.t += 1
+            n += 1
+        return n
+
+    def pts_of(self, n):
+        return self.pts0 + n
+
+    def close(self):
+        self.closed = True
+
+
+def gpu_rank_parts(rank, world, group, a):
+    """service.py `--parts tests.fakes:gpu_rank_parts`: the PRODUCT's rank (DeviceCorpus, RCCL matcher behind
+    the C ABI, the real driver with the HIP scene kernels) - only the frame source is synthetic."""
+    from tvidz_amd import service
+    parts = service._hip_parts(rank, world, group, a)
+    from tvidz_amd.inspector import Inspector
+    parts["inspector"] = lambda store: Inspector(store, device=f"cuda:{a.device}", max_workers=a.workers, batch=32,
+                                                 frame_source=lambda b, key, f, u: (KeyedClipReader(key), None))
+    return parts

@@ -95,3 +95,94 @@ def test_rank_corpus_on_one_gpu_through_the_rccl_path():
     finally:
         rc.close()
         comm.close()
+
+
+def test_rank_service_launcher_on_one_gpu(tmp_path):
+    """`python -m tvidz_amd.service --ranks 1` as the launcher runs it on an MI355X: a parent that never
+    touches the GPU, ONE fresh rank process (NCCL process group, DeviceCorpus, RcclShardedMatcher behind
+    the C ABI, the real driver with the HIP scene kernels), the front's HTTP surface.  Unique clips, a copy
+    of an earlier upload (flagged at its 2nd cut, app.py:238-255) and a burst of twins through /notify,
+    /status and the SSE stream; expected cut times from the oracle's pts_time text (app.py:230).
+    N > 1 ranks: the same code on gloo in tests/test_service_launch_cpu.py; never run on hardware."""
+    import json as _json
+    import os
+    import time
+    import requests
+    from werkzeug.serving import make_server
+
+    port = 6100 + os.getpid() % 200
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    svc = service.RankService(1, f"sqlite:///{tmp_path}/t.db", base_port=port, backend="nccl",
+                              parts="tests.fakes:gpu_rank_parts", k=16, cap=1024, workers=8, ready_timeout=240,
+                              env={"PYTHONPATH": root})
+    srv = make_server("127.0.0.1", port, service.create_front(svc.urls), threaded=True)
+    threading.Thread(target=srv.serve_forever, daemon=True).start()
+    base = f"http://127.0.0.1:{port}"
+    try:
+        def key(name, pts0, cuts, stamp=1700000000):
+            return f"videos/{stamp}-{name}__{pts0}__{'_'.join(map(str, cuts))}.y4m"
+
+        def notify(k):
+            r = requests.post(f"{base}/notify", timeout=30,
+                              json={"Records": [{"s3": {"bucket": {"name": "videos"}, "object": {"key": k}}}]})
+            assert r.status_code == 200, r.text
+
+        def wait(k, timeout=120):
+            fn, end = k.split("/")[-1], time.time() + timeout
+            while time.time() < end:
+                rec = requests.get(f"{base}/status/{fn}", timeout=30).json()
+                if rec.get("status") in ("done", "error"):
+                    return rec
+                time.sleep(0.05)
+            raise AssertionError(f"{fn} never finished")
+
+        def times(pts0, cuts):
+            return [oracle.pts_time_value(pts0 + c, 1, 30, 0) for c in cuts]
+
+        clips = {"a": (1000, [7, 19, 33, 50]), "b": (5000, [5, 21, 40]), "c": (9000, [11, 30, 47, 58])}
+        for name, (pts0, cuts) in clips.items():
+            k = key(name, pts0, cuts)
+            notify(k)
+            rec = wait(k)
+            assert rec["status"] == "done" and rec["scene_cuts"] == times(pts0, cuts) and rec["duplicates"] == [], rec
+        # a copy of "b" under another name: flagged at its 2nd cut, the original's clean name reported
+        k = key("b_again", 5000, clips["b"][1], stamp=1700000050)
+        notify(k)
+        rec = wait(k)
+        assert rec["status"] == "done" and rec["scene_cuts"] == times(5000, clips["b"][1])[:2], rec
+        assert rec["duplicates"] == [service.clean_name(key("b", 5000, clips["b"][1]))]
+        # a burst of four uploads of ONE new clip, all at once, watched over SSE: whoever persists first is the
+        # others' duplicate (the reference has the same race, app.py:234-238); every record ends `done`
+        twin = (20000, [9, 25, 44])
+        keys = [key(f"twin{i}", *twin, stamp=1700000100 + i) for i in range(4)]
+        last = {}
+
+        def sse(k):
+            fn = k.split("/")[-1]
+            with requests.get(f"{base}/status/stream/{fn}", stream=True, timeout=(10, 120)) as r:
+                for line in r.iter_lines():
+                    if line.startswith(b"data: "):
+                        last[fn] = _json.loads(line[6:])
+                        if last[fn].get("status") in ("done", "error"):
+                            break
+        watchers = [threading.Thread(target=sse, args=(k,)) for k in keys]
+        [w.start() for w in watchers]
+        th = [threading.Thread(target=notify, args=(k,)) for k in keys]
+        [t.start() for t in th]
+        [t.join(60) for t in th]
+        [w.join(120) for w in watchers]
+        names = {service.clean_name(k) for k in keys}
+        n_flagged = 0
+        for k in keys:
+            rec = wait(k)
+            assert rec == last[k.split("/")[-1]] and rec["status"] == "done", rec
+            assert set(rec["duplicates"]) <= names - {service.clean_name(k)}
+            assert rec["scene_cuts"] in (times(*twin), times(*twin)[:2])
+            n_flagged += bool(rec["duplicates"])
+        assert n_flagged >= 3                                   # at most one of them can have been first
+        info = requests.get(f"{base}/ranks", timeout=30).json()["ranks"][0]
+        assert info["rows"] == 8 and info["busy_ticks"] >= 8 and info["broken"] is None
+        assert svc.dead() == []
+    finally:
+        srv.shutdown()
+        svc.stop()

@@ -130,11 +130,14 @@ class ShardedCorpus:
         self.R = int(n_shards)
         self.k, self.cap = int(k), max(int(cap), int(k))
         self.shards = [tc.DeviceCorpus(self.device) for _ in range(self.R)]
-        self.streams = [torch.cuda.Stream(self.dev) for _ in range(self.R)]
+        self.stream = torch.cuda.Stream(self.dev)          # the tick thread's own (not the legacy default stream)
         self._owner = {}
         self._lock = threading.Lock()
         self._ws = [None] * self.R
+        self._pin = None
+        self._dstage = None
         self.exact_asks = 0
+        self.tick_host_s = 0.0              # wall time inside _run_batch (host work + the wait for the GPU)
         self.batcher = TickBatcher(self._run_batch, linger_s=linger_s)
 
     # ---- rows: a video's row stays in the shard of whoever ingested it ----
@@ -197,27 +200,55 @@ class ShardedCorpus:
         self.exact_asks += 1
         return self._exact(q, min_match, exclude_id, True)
 
-    def _run_batch(self, items):
-        tc = self._tc
-        queries = [q for q, _, _ in items]
-        mm = items[0][1]
+    def _stage(self, queries, excl):
+        """The tick's inputs in ONE pinned block and ONE host-to-device copy: [keys f64 | offsets i64 |
+        exclude ids i32] (three small copies and a fresh pinned allocation each were most of a tick's
+        host time at 64 asks)."""
         Q = len(queries)
-        cur = torch.cuda.current_stream(self.dev)
-        d_q, d_off, max_len = tc.pack_queries(queries, self.dev)
-        d_ex = torch.tensor([e for _, _, e in items], dtype=torch.int32, device=self.dev)
-        need = tc.workspace_bytes(Q, max_len, self.cap, self.k)
-        blocks = []
-        for r, (shard, st) in enumerate(zip(self.shards, self.streams)):
-            if self._ws[r] is None or self._ws[r].numel() < need:
-                self._ws[r] = torch.empty(need, dtype=torch.uint8, device=self.dev)
-            st.wait_stream(cur)
-            blocks.append(shard.match_topk(d_q, d_off, max_len, mm, self.cap, self.k, d_exclude_ids=d_ex,
-                                           stream=st, workspace=self._ws[r]))
-        for st in self.streams:
-            cur.wait_stream(st)
-        merged, totals = tc.topk_merge(torch.stack(blocks).contiguous(), self.k)     # as the all-gather delivers them
-        merged, totals = merged.cpu().numpy(), totals.cpu().numpy()
-        return [(merged[i], int(totals[i])) for i in range(Q)]
+        lens = np.fromiter((len(q) for q in queries), dtype=np.int64, count=Q)
+        nk = max(int(lens.sum()), 1)
+        need = 8 * nk + 8 * (Q + 1) + 4 * Q
+        if self._pin is None or self._pin.numel() < need:
+            self._pin = torch.empty(max(need, 1 << 16), dtype=torch.uint8).pin_memory()
+            self._dstage = torch.empty(self._pin.numel(), dtype=torch.uint8, device=self.dev)
+        h = self._pin.numpy()
+        keys = h[:8 * nk].view(np.float64)
+        offs = h[8 * nk:8 * nk + 8 * (Q + 1)].view(np.int64)
+        ex = h[8 * nk + 8 * (Q + 1):need].view(np.int32)
+        offs[0] = 0
+        np.cumsum(lens, out=offs[1:])
+        if int(lens.sum()):
+            np.concatenate(queries, out=keys[:int(lens.sum())])
+        ex[:] = excl
+        d = self._dstage
+        d[:need].copy_(self._pin[:need], non_blocking=True)
+        return (d[:8 * nk].view(torch.float64), d[8 * nk:8 * nk + 8 * (Q + 1)].view(torch.int64),
+                d[8 * nk + 8 * (Q + 1):need].view(torch.int32), int(lens.max()) if Q else 0)
+
+    def _run_batch(self, items):
+        """One tick: every shard's lookup (top-k kept in the lookup's epilogue) over the whole batch, the
+        blocks written where the merge reads them ([R, Q, k+1, 3], as an all-gather would deliver them),
+        the merge, ONE device-to-host copy.  All on the tick thread's stream, back to back: the shards
+        share one device, and a cross-stream wait per shard (12-30 us each on this system before the
+        waiting queue moves, profiles/r3_shard_pipeline.txt) cost more than the overlap gave."""
+        t0 = time.perf_counter()
+        tc = self._tc
+        mm = items[0][1]
+        Q = len(items)
+        with torch.cuda.device(self.dev), torch.cuda.stream(self.stream):
+            d_q, d_off, d_ex, max_len = self._stage([q for q, _, _ in items], [e for _, _, e in items])
+            need = tc.workspace_bytes(Q, max_len, self.cap, self.k)
+            if self._ws[0] is None or self._ws[0].numel() < need:
+                self._ws[0] = torch.empty(need, dtype=torch.uint8, device=self.dev)       # one workspace: the shards run in turn
+            blocks = torch.empty((self.R, Q, self.k + 1, 3), dtype=torch.int32, device=self.dev)
+            for r, shard in enumerate(self.shards):
+                shard.match_topk(d_q, d_off, max_len, mm, self.cap, self.k, d_exclude_ids=d_ex, out=blocks[r],
+                                 workspace=self._ws[0])
+            merged, totals = tc.topk_merge(blocks, self.k)
+            both = torch.cat([merged.reshape(Q, self.k * 3), totals.reshape(Q, 1)], dim=1).cpu().numpy()
+        self.tick_host_s += time.perf_counter() - t0
+        k3 = self.k * 3
+        return [(both[i, :k3].reshape(self.k, 3), int(both[i, k3])) for i in range(Q)]
 
 
 ASK_TOPK, ASK_EXACT = 0, 1
