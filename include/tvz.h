@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define TVZ_VERSION 300 /* 0.3.0 */
+#define TVZ_VERSION 400 /* 0.4.0: the index answers every min_match >= 1; tvz_match_topk keeps the top-k inside the lookup; tvz_match_topk_shards */
 
 typedef enum tvz_status {
     TVZ_OK = 0,
@@ -202,12 +202,13 @@ int tvz_corpus_index_stats(tvz_corpus *c, int64_t *n_indexed_rows, int64_t *n_de
  * ------------------------------------------------------------------------ */
 
 /* How the corpus is matched, PER CALL (there is no global knob); results never depend on it.
- *   AUTO : INDEX when the handle has one and min_match is 1..5.  Otherwise (and for the delta
+ *   AUTO : INDEX when the handle has one and min_match >= 1 (1..5: kth from the smallest positions kept per
+ *          candidate; more: count + a kth fix-up walk).  Otherwise (and for the delta
  *          table): one query (or <= 4 against a small corpus) -> Q1; >= 64 queries x >= 2,100 + 340,000 / Q rows
  *          with min_match 1..2 -> JOIN; else TILE
  *   INDEX: posting-list lookup - one block per query walks its sub-indexes (a small batch: one block per
  *          query and sub-index) - + a sweep of the delta table (error if the handle has no index or
- *          min_match is outside 1..5)
+ *          min_match < 1)
  *   Q1   : one corpus sweep per query, the query's keys in a small LDS table, per-lane counters
  *   TILE : one LDS hash table per tile of <= 16 queries
  *   JOIN : device-memory hash join per tile of <= 1024 queries (min_match 1..2; other values take TILE) */
@@ -246,7 +247,11 @@ int tvz_match(tvz_corpus *c, const double *d_queries, const int64_t *d_q_offsets
 /* Match + per-shard top-k behind ONE call (hit lists stay in the workspace):
  *   d_out : int32[Q][k+1][3] = the k best hits by (kth, video_id, count), padded with
  *           (-1, 0, TVZ_KTH_NEVER), + a row (-1, n_hits, TVZ_KTH_NEVER); n_hits is NEGATED when
- *           the hit list overflowed `cap` (the top-k may then be inexact: re-run with more). */
+ *           the hit list overflowed `cap` (the top-k may then be inexact: re-run with more).
+ * On an indexed handle (min_match 1..5, k <= 64, a batch large enough that a block owns its query) the
+ * lookup kernel keeps the k best ITSELF: no hit list is written, no top-k kernel runs; rows added or
+ * replaced since the index was built are swept and merged in.  The contract is unchanged (n_hits is
+ * still negated when it exceeds `cap`), the rows are then the exact k best nevertheless. */
 int tvz_match_topk(tvz_corpus *c, const double *d_queries, const int64_t *d_q_offsets,
                    int32_t Q, int32_t max_query_len, int32_t min_match,
                    const int32_t *d_exclude_ids, int32_t cap, int32_t k, int32_t *d_out,
@@ -281,6 +286,18 @@ int tvz_topk(const int32_t *d_lists, const int32_t *d_lists_n, int32_t n_lists, 
  * a larger cap). */
 int tvz_topk_shard(const int32_t *d_hits, const int32_t *d_hits_n, int32_t Q, int32_t cap,
                    int32_t k, int32_t *d_out, void *hip_stream);
+/* The shards of ONE process (several handles on one device: service.ShardedCorpus, the one-GPU form of
+ * configs[4]): tvz_match_topk on every handle in turn, the blocks written where the merge reads them
+ *   d_blocks : int32[n_shards][Q][k+1][3]  (as an all-gather would deliver them)
+ * and the merge -> d_topk int32[Q][k][3], d_totals int32[Q] - ONE call for the whole tick (a Python
+ * host otherwise re-takes its interpreter lock after every launch; with 16 upload threads busy in the
+ * ORM that was ~4 ms per tick against ~0.2 ms of GPU work).  One workspace sized for ONE handle
+ * (tvz_match_workspace_bytes(Q, max_query_len, cap, k, 1)) serves all of them: same stream, in order. */
+int tvz_match_topk_shards(tvz_corpus *const *shards, int32_t n_shards, const double *d_queries,
+                          const int64_t *d_q_offsets, int32_t Q, int32_t max_query_len, int32_t min_match,
+                          const int32_t *d_exclude_ids, int32_t cap, int32_t k, int32_t *d_blocks,
+                          int32_t *d_topk, int32_t *d_totals, void *d_workspace, size_t workspace_bytes,
+                          int32_t algo, void *hip_stream);
 int tvz_topk_merge(const int32_t *d_gathered, int32_t n_ranks, int32_t Q, int32_t k,
                    int32_t *d_topk, int32_t *d_totals, void *hip_stream);
 

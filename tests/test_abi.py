@@ -30,7 +30,7 @@ def test_library_builds_loads_and_exports_every_symbol():
     for name in _declared():
         assert hasattr(lib, name), f"{name} declared in tvz.h but not exported"
         assert name in _lib.SIGNATURES, f"{name} has no ctypes signature"
-    assert lib.tvz_version() == _lib.VERSION == 300
+    assert lib.tvz_version() == _lib.VERSION == 400
     assert lib.tvz_scene_workspace_bytes(10000, 1080, 1920) > 0
     assert lib.tvz_scene_workspace_bytes(-1, 1080, 1920) == 0
     assert lib.tvz_scene_state_bytes(1080, 1920, 1) >= 2 * 1080 * 1920

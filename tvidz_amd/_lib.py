@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.environ.get("TVZ_LIB") or os.path.join(_HERE, "libtvz.so")
 
 KTH_NEVER = 0x7FFFFFFF
-VERSION = 300
+VERSION = 400
 
 # name -> (restype, argtypes); mirrors include/tvz.h one to one
 _P = C.c_void_p
@@ -56,6 +56,8 @@ SIGNATURES = {
     "tvz_topk": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P]),
     "tvz_topk_shard": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P]),
     "tvz_topk_merge": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P]),
+    "tvz_match_topk_shards": (C.c_int, [_P, C.c_int32, _P, _P, C.c_int32, C.c_int32, C.c_int32, _P, C.c_int32,
+                                        C.c_int32, _P, _P, _P, _P, C.c_size_t, C.c_int32, _P]),
     "tvz_comm_unique_id": (C.c_int, [_P]),
     "tvz_comm_init": (C.c_int, [C.POINTER(C.c_void_p), _P, C.c_int32, C.c_int32, C.c_int32]),
     "tvz_comm_info": (C.c_int, [_P, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),

@@ -295,6 +295,27 @@ def topk_shard(hits: torch.Tensor, hits_n: torch.Tensor, k: int,
     return out
 
 
+def match_topk_shards(shards: Sequence["DeviceCorpus"], d_queries: torch.Tensor, d_q_offsets: torch.Tensor,
+                      max_query_len: int, min_match: int, cap: int, k: int, workspace: torch.Tensor,
+                      d_exclude_ids: Optional[torch.Tensor] = None, stream: Optional[torch.cuda.Stream] = None,
+                      algo: int = _lib.ALGO_AUTO):
+    """tvz_match_topk on every handle of ONE device + the merge behind one library call:
+    -> (blocks int32 [R,Q,k+1,3], merged int32 [Q,k,3], totals int32 [Q])."""
+    dev = d_queries.device
+    R, Q = len(shards), d_q_offsets.numel() - 1
+    blocks = torch.empty((R, Q, k + 1, 3), dtype=torch.int32, device=dev)
+    merged = torch.empty((Q, k, 3), dtype=torch.int32, device=dev)
+    totals = torch.empty(Q, dtype=torch.int32, device=dev)
+    handles = (C.c_void_p * R)(*[s._h for s in shards])
+    s = stream if stream is not None else torch.cuda.current_stream(dev)
+    with torch.cuda.device(dev):
+        _lib.check(_lib.load().tvz_match_topk_shards(
+            handles, R, d_queries.data_ptr(), d_q_offsets.data_ptr(), Q, int(max_query_len), int(min_match),
+            d_exclude_ids.data_ptr() if d_exclude_ids is not None else None, int(cap), int(k), blocks.data_ptr(),
+            merged.data_ptr(), totals.data_ptr(), workspace.data_ptr(), workspace.numel(), int(algo), s.cuda_stream))
+    return blocks, merged, totals
+
+
 def topk_merge(gathered: torch.Tensor, k: int, stream: Optional[torch.cuda.Stream] = None):
     """All-gathered int32 [R,Q,k+1,3] -> (merged int32 [Q,k,3], totals int32 [Q])."""
     R, Q, k1, _ = gathered.shape

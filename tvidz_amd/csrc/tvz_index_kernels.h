@@ -745,7 +745,7 @@ __device__ __forceinline__ void ix_lookup_body(
     }
     const int n = (int)n64;
 #ifdef TVZ_IX_STAMP
-    unsigned long long st_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long st_acc[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long st_last = __builtin_amdgcn_s_memtime();
 #endif
     const int lane = threadIdx.x & 63;
@@ -1256,10 +1256,11 @@ __device__ __forceinline__ void ix_lookup_body(
             o[i * 3 + 1] = i == (uint32_t)tk_k ? ((int64_t)emitted > (int64_t)cap ? -(int32_t)emitted : (int32_t)emitted) : 0;
             o[i * 3 + 2] = TVZ_KTH_NEVER;
         }
+        TVZ_STAMP(10);
     } else if (!HOSTOUT && alone && threadIdx.x == 0) hits_n[(size_t)q * ns] = (int32_t)emitted;
 #ifdef TVZ_IX_STAMP
     if (threadIdx.x == 0) {
-        for (int i = 0; i < 10; ++i) atomicAdd(&g_ix_stamps[i], st_acc[i]);
+        for (int i = 0; i < 11; ++i) atomicAdd(&g_ix_stamps[i], st_acc[i]);
         atomicAdd(&g_ix_stamps[15], 1ull);
     }
 #endif

@@ -2022,6 +2022,29 @@ static int tvz_topk_shard_impl(const int32_t *d_hits, const int32_t *d_hits_n, i
 }
 
 static int tvz_topk_merge_impl(const int32_t *d_gathered, int32_t n_ranks, int32_t Q, int32_t k,
+                               int32_t *d_topk, int32_t *d_totals, void *hip_stream);
+
+static int tvz_match_topk_shards_impl(tvz_corpus *const *shards, int32_t n_shards, const double *d_queries,
+                                      const int64_t *d_q_offsets, int32_t Q, int32_t max_query_len,
+                                      int32_t min_match, const int32_t *d_exclude_ids, int32_t cap, int32_t k,
+                                      int32_t *d_blocks, int32_t *d_topk, int32_t *d_totals, void *d_workspace,
+                                      size_t workspace_bytes, int32_t algo, void *hip_stream) {
+    TVZ_REQUIRE(shards != nullptr && n_shards >= 1, "no shards");
+    TVZ_REQUIRE(Q == 0 || (d_blocks && d_topk && d_totals), "NULL output");
+    if (Q == 0) return TVZ_OK;
+    for (int32_t r = 0; r < n_shards; ++r) {
+        TVZ_REQUIRE(shards[r] != nullptr && shards[r]->device == shards[0]->device,
+                    "shard %d is NULL or on another device than shard 0", r);
+        if (int rc = tvz_match_topk_local(shards[r], d_queries, d_q_offsets, Q, max_query_len, min_match, d_exclude_ids,
+                                          cap, k, d_blocks + (size_t)r * (size_t)Q * (size_t)(k + 1) * 3, d_workspace,
+                                          workspace_bytes, 1, algo, hip_stream, nullptr))
+            return rc;
+    }
+    DeviceGuard dg(shards[0]->device);
+    return tvz_topk_merge_impl(d_blocks, n_shards, Q, k, d_topk, d_totals, hip_stream);
+}
+
+static int tvz_topk_merge_impl(const int32_t *d_gathered, int32_t n_ranks, int32_t Q, int32_t k,
                               int32_t *d_topk, int32_t *d_totals, void *hip_stream) {
     TVZ_REQUIRE(n_ranks >= 1 && Q >= 0, "bad list shape");
     TVZ_REQUIRE(k >= 1 && k <= kSortCap / 2, "k=%d out of range [1, %d]", k, kSortCap / 2);
@@ -2142,6 +2165,16 @@ TVZ_EXPORT int tvz_topk(const int32_t *d_lists, const int32_t *d_lists_n, int32_
 TVZ_EXPORT int tvz_topk_shard(const int32_t *d_hits, const int32_t *d_hits_n, int32_t Q,
                               int32_t cap, int32_t k, int32_t *d_out, void *hip_stream) {
     TVZ_GUARDED(tvz_topk_shard_impl(d_hits, d_hits_n, Q, cap, k, d_out, hip_stream));
+}
+
+TVZ_EXPORT int tvz_match_topk_shards(tvz_corpus *const *shards, int32_t n_shards, const double *d_queries,
+                                     const int64_t *d_q_offsets, int32_t Q, int32_t max_query_len, int32_t min_match,
+                                     const int32_t *d_exclude_ids, int32_t cap, int32_t k, int32_t *d_blocks,
+                                     int32_t *d_topk, int32_t *d_totals, void *d_workspace, size_t workspace_bytes,
+                                     int32_t algo, void *hip_stream) {
+    TVZ_GUARDED(tvz_match_topk_shards_impl(shards, n_shards, d_queries, d_q_offsets, Q, max_query_len, min_match,
+                                           d_exclude_ids, cap, k, d_blocks, d_topk, d_totals, d_workspace,
+                                           workspace_bytes, algo, hip_stream));
 }
 
 TVZ_EXPORT int tvz_topk_merge(const int32_t *d_gathered, int32_t n_ranks, int32_t Q, int32_t k,

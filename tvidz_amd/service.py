@@ -240,11 +240,10 @@ class ShardedCorpus:
             need = tc.workspace_bytes(Q, max_len, self.cap, self.k)
             if self._ws[0] is None or self._ws[0].numel() < need:
                 self._ws[0] = torch.empty(need, dtype=torch.uint8, device=self.dev)       # one workspace: the shards run in turn
-            blocks = torch.empty((self.R, Q, self.k + 1, 3), dtype=torch.int32, device=self.dev)
-            for r, shard in enumerate(self.shards):
-                shard.match_topk(d_q, d_off, max_len, mm, self.cap, self.k, d_exclude_ids=d_ex, out=blocks[r],
-                                 workspace=self._ws[0])
-            merged, totals = tc.topk_merge(blocks, self.k)
+            # ONE library call for the R lookups + the merge (tvz_match_topk_shards): every return to the
+            # interpreter is a chance to wait for its lock behind 16 upload threads busy in the ORM
+            _, merged, totals = tc.match_topk_shards(self.shards, d_q, d_off, max_len, mm, self.cap, self.k,
+                                                     self._ws[0], d_exclude_ids=d_ex)
             both = torch.cat([merged.reshape(Q, self.k * 3), totals.reshape(Q, 1)], dim=1).cpu().numpy()
         self.tick_host_s += time.perf_counter() - t0
         k3 = self.k * 3
