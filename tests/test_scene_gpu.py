@@ -355,3 +355,29 @@ def test_detect_scene_cuts_from_a_file_path(tmp_path):
     _, o_sel, _, _ = _oracle_all(frames.cpu().numpy())
     assert got == [(int(i), oracle.pts_time_value(int(i), 1, 25, 0)) for i in np.flatnonzero(o_sel)]
     assert len(got) >= 2
+
+
+@pytest.mark.parametrize("splits", [(300,), (100, 200), (1, 149, 150), (75, 75, 75, 75), (0, 120, 0, 180), (299, 1)])
+def test_one_long_video_in_time_chunks_with_a_one_frame_halo(splits):
+    """SURVEY 8e, scene scoring: a single long video over several GPUs = time chunks, each scored on its
+    device against a one-frame halo, the SADs concatenated before the diff step.  One GPU here (every
+    chunk on cuda:0: the data path - halo copy, per-chunk SAD, concatenation, ONE epilogue - is the same);
+    the selected frames equal the oracle's over the whole video, cuts AT chunk boundaries included."""
+    T, H, W = 300, 96, 160
+    frames, _ = synth.synth_luma(T, H, W, device=DEV, seed=11, min_scene=9, max_scene=40)
+    f_np = frames.cpu().numpy()
+    # force cuts exactly at the boundaries the splits create (a level jump the filter must see across chunks)
+    for b in np.cumsum(splits)[:-1]:
+        if 0 < b < T:
+            f_np[b:] = (f_np[b:].astype(np.int16) + 97).astype(np.uint8)
+    frames = torch.from_numpy(f_np).to(DEV)
+    _, sel, _, _ = _oracle_all(f_np)
+    chunks, at = [], 0
+    for n in splits:
+        chunks.append(frames[at:at + n])
+        at += n
+    assert at == T
+    got = scene.scene_cuts_chunked(chunks).tolist()
+    assert got == np.flatnonzero(sel).tolist() and len(got) >= 5
+    whole = [i for i, _ in scene.detect_scene_cuts(frames, batch=64)]
+    assert got == whole

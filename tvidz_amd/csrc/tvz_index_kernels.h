@@ -764,6 +764,7 @@ __device__ __forceinline__ void ix_lookup_body(
         for (int i = threadIdx.x; i < kIxTkBins + 2; i += kIxBlock) kh[i] = 0;      // histogram, fill, pad
     }
     unsigned long long tk_cut = ~0ull;                     // TOPK: hits >= this cannot make the top-k (block-uniform)
+    uint32_t tk_bmax = 0xffffffffu;                        // TOPK: hits with kth beyond this neither (block-uniform)
 
     // ---- directory: ONE probe per query position; the counts of this block's sub-indexes to LDS ----
     const uint32_t smask = (1u << (dir_bits >> 8)) - 1u;   // probes wrap inside the directory slice
@@ -1079,11 +1080,19 @@ __device__ __forceinline__ void ix_lookup_body(
                 if (vid[u] >= 0 && (int32_t)tcnt[k] < min_match) vid[u] = -1;
                 mine += vid[u] >= 0 ? 1u : 0u;
                 if constexpr (TOPK) {
+                    // Only hits that can still make the top-k are looked at any further: kth <= tk_bmax, the
+                    // threshold bin of the parts so far (block-uniform; no bound before k hits below position 63
+                    // exist).  After the first sub-index that is a few per cent of the hits.  The bin "63 or
+                    // later" is never counted: no threshold is ever read from it, and with ~70 % of a part's
+                    // hits in it the one LDS address was a serialised atomic per hit.
                     ek[u] = ~0ull;
                     if (vid[u] >= 0) {
-                        const int32_t kth = kth_of(k);
-                        ek[u] = ix_tk_pack(kth, vid[u], tcnt[k]);
-                        atomicAdd(&kh[kth < kIxTkBins - 1 ? kth : kIxTkBins - 1], 1u);
+                        const uint32_t kth = (uint32_t)kth_of(k);
+                        if (kth <= tk_bmax) {
+                            ek[u] = ix_tk_pack((int32_t)kth, vid[u], tcnt[k]);
+                            if (kth < (uint32_t)kIxTkBins - 1u) atomicAdd(&kh[kth], 1u);
+                            mine += 1u << 16;              // (high half: candidates for the list; <= 1024 per part)
+                        }
                     }
                 }
             }
@@ -1107,20 +1116,22 @@ __device__ __forceinline__ void ix_lookup_body(
                 all += a;
             }
             if constexpr (TOPK) {
-                emitted += all;
-                if (all) {                                 // block-uniform
-                    // b* = the first kth bin whose prefix reaches k; every wave scans the 64 bins itself (the
+                emitted += all & 0xffffu;
+                const uint32_t n_cand_tk = all >> 16;      // this part's hits at or below the threshold bin
+                if (n_cand_tk) {                           // block-uniform (nothing to keep otherwise: most later parts)
+                    // b* = the first kth bin whose prefix reaches k; every wave scans the bins itself (the
                     // histogram does not change before the next part's emit: same result in all of them)
-                    const uint32_t hincl = wave_scan_incl(kh[lane]);
+                    const uint32_t hincl = wave_scan_incl(lane < kIxTkBins - 1 ? kh[lane] : 0u);
                     const unsigned long long reach = __ballot(hincl >= (uint32_t)tk_k);
                     const int bfirst = __builtin_amdgcn_readfirstlane(reach ? __ffsll((long long)reach) - 1 : kIxTkBins);
-                    uint32_t bound = all;                  // this part's keepers, at most
+                    uint32_t bound = n_cand_tk;            // this part's keepers, at most
                     unsigned long long cut = tk_cut;
-                    if (bfirst < kIxTkBins - 1) {          // (the last bin is "63 or later": no bound from it)
+                    if (bfirst < kIxTkBins - 1) {
                         const uint32_t cum = (uint32_t)__builtin_amdgcn_readlane((int)hincl, bfirst);
-                        bound = cum < all ? cum : all;
+                        bound = cum < n_cand_tk ? cum : n_cand_tk;
                         const unsigned long long bc = (unsigned long long)(bfirst + 1) << 44;
                         cut = bc < cut ? bc : cut;
+                        tk_bmax = (uint32_t)bfirst < tk_bmax ? (uint32_t)bfirst : tk_bmax;
                     }
                     if (tk_before + bound <= (uint32_t)kIxTkCap) {
 #pragma unroll
@@ -1146,7 +1157,12 @@ __device__ __forceinline__ void ix_lookup_body(
                             const uint32_t left = N < (uint32_t)tk_k ? N : (uint32_t)tk_k;
                             if (threadIdx.x == 0) *tk_n = left;
                             __syncthreads();
-                            if (N >= (uint32_t)tk_k) { const unsigned long long t = s_tkT; tk_cut = t < tk_cut ? t : tk_cut; }
+                            if (N >= (uint32_t)tk_k) {
+                                const unsigned long long t = s_tkT;
+                                tk_cut = t < tk_cut ? t : tk_cut;
+                                const uint32_t tb = (uint32_t)(tk_cut >> 44);          // nothing beyond the k-th best's kth matters
+                                tk_bmax = tb < tk_bmax ? tb : tk_bmax;
+                            }
                             return left;
                         };
                         uint32_t nb = reduce(tk_before);

@@ -253,6 +253,53 @@ def detect_scene_cuts(frames: Union[torch.Tensor, Iterable], time_base: Tuple[in
         base += chunk.shape[0]
 
 
+def scene_cuts_chunked(chunks: Sequence[torch.Tensor], threshold: float = DEFAULT_THRESHOLD,
+                       gather_device: Optional[Union[str, torch.device]] = None) -> torch.Tensor:
+    """ONE long video over several GPUs (scene scoring): `chunks` are consecutive time
+    ranges of the video's 8-bit luma, uint8 [T_c,H,W] each on ITS device.  Every device computes the SADs
+    of its chunk against a one-frame halo - the last frame of the chunk before it, copied over (2 MB at
+    1080p: the only data that crosses devices) - so each luma byte is still read once; the per-frame SADs
+    (8 B per frame) are concatenated on `gather_device` BEFORE the diff step, where the epilogue of
+    get_scene_score (mafd, |mafd - prev_mafd|, clip, threshold: inspector/app.py:206's `select` filter) runs
+    once over the whole video.  No collective: a host that owns all chunks drives it (one process per GPU
+    would ship its int64[T_c] SAD vector).  -> int64 indices of the selected frames, on the host.
+    Identical to scoring the whole video on one device (tests/test_scene_gpu.py)."""
+    if not chunks:
+        return torch.empty(0, dtype=torch.int64)
+    H, W = int(chunks[0].shape[1]), int(chunks[0].shape[2])
+    out_dev = torch.device(gather_device) if gather_device is not None else chunks[0].device
+    sads, prev_last = [], None
+    for c, chunk in enumerate(chunks):
+        if chunk.dtype != torch.uint8 or chunk.dim() != 3 or tuple(chunk.shape[1:]) != (H, W):
+            raise RuntimeError("chunks must be uint8 [T,H,W] of one frame size")
+        dev = chunk.device
+        if dev.type != "cuda":
+            raise RuntimeError("chunks live on their GPUs (no CPU path)")
+        T = int(chunk.shape[0])
+        if T == 0:
+            continue
+        with torch.cuda.device(dev):
+            if prev_last is None:
+                frames = chunk
+            else:                                  # halo + chunk, contiguous for the flat kernel
+                frames = torch.empty((T + 1, H, W), dtype=torch.uint8, device=dev)
+                frames[0].copy_(prev_last, non_blocking=True)
+                frames[1:].copy_(chunk, non_blocking=True)
+            sc = SceneScorer(H, W, int(frames.shape[0]), dev, threshold)
+            sad = sc.luma_sad(frames)              # sad[0] = 0: the halo (or the video's first frame)
+            sads.append((sad if prev_last is None else sad[1:]).to(out_dev, non_blocking=True))
+            prev_last = chunk[T - 1]
+    for chunk in chunks:                           # the copies above are ordered on each source device's stream
+        if chunk.device.type == "cuda":
+            torch.cuda.current_stream(chunk.device).synchronize()
+    if not sads:
+        return torch.empty(0, dtype=torch.int64)
+    with torch.cuda.device(out_dev):
+        whole = torch.cat(sads).contiguous()
+        sel, _, _ = scene_select(whole, H, W, threshold)
+        return torch.nonzero(sel, as_tuple=False).flatten().cpu()
+
+
 class ReaderPts:
     """pts[n] of a reader: its own per-frame pts if it has them, else the frame index."""
 
