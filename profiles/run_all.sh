@@ -6,14 +6,18 @@
 # build container) copies the summaries that are cited into profiles/.  Every step writes its own file
 # and a progress line, so a long run never looks hung.
 TAG=${1:-r4}
+PART=${2:-all}        # a = bench + traces + counters, b = everything else (a gpurun call is capped at 20 minutes)
 REPO=$(pwd)
 OUT=$REPO/gpurun_out/final_$TAG
 mkdir -p $OUT
+if [ "$PART" != "b" ]; then
 echo "== bench (un-profiled)";            python bench.py --steps 20 --warmup 5 > $OUT/bench.json 2> $OUT/bench.err; echo rc=$?
 echo "== scene kernel trace + FETCH/WRITE"; bash profiles/run_profile.sh $TAG > $OUT/run_profile.log 2>&1; echo rc=$?
 echo "== matcher trace + counters"
 for w in topk shard8 index index1 join q1_100k q1_5k tile; do bash profiles/pmc_match.sh $TAG $w >> $OUT/pmc_match.log 2>&1; echo "  $w done"; done
 echo "== index rebuild, 100k rows (kernel trace)"; bash profiles/trace_one.sh rebuild 10 > $OUT/rebuild_trace.txt 2>&1
+fi
+if [ "$PART" != "a" ]; then
 echo "== predicted scaling (100k x 4096 / 1024, 800k x 4096)"
 python profiles/predict_scaling.py 4096 2>/dev/null | tail -1 > $OUT/predicted_scaling.json; python profiles/predict_scaling.py 1024 2>/dev/null | tail -1 >> $OUT/predicted_scaling.json
 python profiles/predict_scaling.py 4096 800000 2>/dev/null | tail -1 >> $OUT/predicted_scaling.json
@@ -35,4 +39,5 @@ done > $OUT/e2e_service.txt
 echo "== index at 1 M rows";              python profiles/scale_probe.py 2>/dev/null | tail -1 > $OUT/scale_probe.txt
 echo "== differential soak, 120 s";       python profiles/fuzz_parity.py 120 4242 > $OUT/fuzz_parity.txt 2>&1; tail -1 $OUT/fuzz_parity.txt
 echo "== tile vs join vs q1 grid";        python profiles/ab_match_join.py 2>/dev/null > $OUT/match_ab.txt
+fi
 ls -la $OUT

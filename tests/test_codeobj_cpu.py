@@ -83,3 +83,14 @@ def test_eight_waves_per_simd_kernels_fit_64_vgprs(kernels):
             assert k[".vgpr_count"] <= 64, (name, k[".vgpr_count"])
             assert k.get(".vgpr_spill_count", 0) == 0, (name, k)
     assert n >= 10          # index x {host, device} x {M2, Top5, Count}, top-k x 2, fused x 2, join
+
+
+def test_static_lds_of_the_single_query_sweep_is_what_its_launch_guard_assumes(kernels):
+    """launch_q1 (tvz_match.hip) refuses a launch whose dynamic + static LDS exceeds the 160 KiB of a
+    gfx950 workgroup, with kQ1StaticLds = kQ1Stage * 12 + 64 = 3,136 B for the static part."""
+    seen = 0
+    for name, k in kernels.items():
+        if "ts_match_q1_kernel" in name:
+            seen += 1
+            assert k[".group_segment_fixed_size"] <= 256 * 12 + 64, (name, k[".group_segment_fixed_size"])
+    assert seen == 6

@@ -81,6 +81,8 @@ struct RingSlot {
 // Inverted index over rows [0, n_main) as they were when it was built (tvz_index_kernels.h) plus
 // the DELTA table: the current entry of every row that was added or replaced since.  A match with
 // the index = index lookup (rows that are unchanged since the build) + a sweep of the delta table.
+constexpr int kLdsPerWorkgroup = 160 * 1024;        // gfx950
+constexpr int kQ1StaticLds = kQ1Stage * 12 + 64;    // ts_match_q1_kernel: per-block hit staging + a few words (3,088 B in the code object)
 constexpr int kIxMaxLds = 159 * 1024;               // gfx950: 160 KiB of LDS per workgroup, less the static part
 constexpr int64_t kIxSliceBytes = 32 * 1024;        // a directory slice, built by one block in LDS
 constexpr int64_t kIxSliceBytesMax = 128 * 1024;
@@ -862,6 +864,16 @@ int launch_q1(tvz_corpus *c, RowSpan span, const double *d_queries, const int64_
     const int64_t n_rows = span.n;
     const int s_log2 = q1_slots_log2(max_query_len);
     const size_t lds = q1_lds_bytes(s_log2);
+    // The launch limit, named: a workgroup gets at most 160 KiB of LDS on gfx950, and this
+    // kernel's request is dynamic (query table + Bloom words, up to 112 KiB at 4095 timestamps) PLUS static
+    // (the per-block hit staging, 3 KiB) - a launch beyond it fails in the runtime with an error string that
+    // names neither.  (One launch of this kernel did fail on 2026-10-04 in a working tree between two commits,
+    // "out of memory" in test_golden_kat, gpurun_out/r3_t12.log: that tree is not in the history; the two
+    // resources a launch can run out of are this one and scratch, and tests/test_codeobj_cpu.py now pins the
+    // kernel's scratch at 0 bytes.)
+    TVZ_REQUIRE(lds + kQ1StaticLds <= (size_t)kLdsPerWorkgroup,
+                "single-query sweep: %zu B of dynamic + %d B of static LDS exceed the %d B a gfx950 workgroup can have",
+                lds, kQ1StaticLds, kLdsPerWorkgroup);
     const dim3 grid((unsigned)blocks_x, (unsigned)Q);
 #define TVZ_Q1(MODE)                                                                              \
     hipLaunchKernelGGL((ts_match_q1_kernel<MODE, HOSTOUT>), grid, dim3(kQ1Block), lds, st, span.p, \
