@@ -81,6 +81,9 @@ def test_index_equals_oracle_and_sweeps(dc, C, mean_len, Q):
         _check(dc, rows, queries, mm)
         _check(dc, rows, queries, mm, excl=excl, algo=_lib.ALGO_AUTO)
         _check(dc, rows, queries, mm, cap=3)
+        for q in queries[:4]:                                         # tvz_find_duplicates takes the same path (a batch of one)
+            _check_single(dc, rows, q, mm)
+            _check_single(dc, rows, q, mm, excl=excl[0])
 
 
 def test_more_candidates_than_the_lds_table_holds(dc):

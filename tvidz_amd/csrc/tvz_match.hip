@@ -1961,17 +1961,20 @@ static int tvz_find_duplicates_impl(tvz_corpus *c, const double *h_query, int64_
                                        s->d_smult, (int32_t)uq.size(), min_match, -1, (int32_t)want, s->d_hits,
                                        s->d_hits_n);
                     TVZ_HIP(hipGetLastError());
+                    if (min_match > 0) {
+                        hipLaunchKernelGGL(ts_kth_fixup_kernel, dim3(1), dim3(kBlock), 0, s->stream, c->rows.p,
+                                           c->keys.p, reinterpret_cast<const double *>(d_q + 2), d_q, min_match,
+                                           (int32_t)want, s->d_hits, s->d_hits_n, 1);
+                        TVZ_HIP(hipGetLastError());
+                    }
                 } else {
-                    if (int rc = launch_q1<false>(c, RowSpan{c->rows.p, n_rows}, reinterpret_cast<const double *>(d_q + 2), d_q, 1, (int32_t)n,
-                                                  min_match, nullptr, -1, (int32_t)want, s->d_hits, s->d_hits_n, 1,
-                                                  q1_blocks(n_rows, 1), HostOut{nullptr, nullptr, 0}, s->stream))
+                    // min_match > 5 (or <= 0): what a batch of one takes - on an indexed handle the lookup with a
+                    // count-only pass B + the kth fix-up walk and a sweep of the delta table, else the single-query
+                    // sweep; the fix-ups are part of those paths
+                    if (int rc = launch_match_short(c, reinterpret_cast<const double *>(d_q + 2), d_q, 1, (int32_t)n, min_match,
+                                                    nullptr, (int32_t)want, s->d_hits, s->d_hits_n, 1, nullptr, 0,
+                                                    TVZ_ALGO_AUTO, s->stream))
                         return rc;
-                }
-                if (min_match > 0) {
-                    hipLaunchKernelGGL(ts_kth_fixup_kernel, dim3(1), dim3(kBlock), 0, s->stream, c->rows.p,
-                                       c->keys.p, reinterpret_cast<const double *>(d_q + 2), d_q, min_match,
-                                       (int32_t)want, s->d_hits, s->d_hits_n, 1);
-                    TVZ_HIP(hipGetLastError());
                 }
             }
             if (int rc = record(c, s->stream)) return rc;
