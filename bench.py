@@ -529,9 +529,9 @@ def bench_e2e(dev, rank: int = 0, world: int = 1, n_uploads: int = 8, n_frames: 
         if world > 1:
             from tvidz_amd import service
             shard = tc.DeviceCorpus(dev.index)
-            group = dist.new_group(backend="nccl")                       # the tick thread's own
+            group = dist.new_group(backend="gloo")                       # the tick thread's own; the asks are host data
             matcher = sharded.RcclShardedMatcher(shard, sharded.make_comm(dev.index), k=64, cap=4096)
-            rc = service.RankCorpus(shard, matcher, group=group, xdev=str(dev))
+            rc = service.RankCorpus(shard, matcher, group=group, xdev="cpu")
             store = tdb.Store(f"sqlite:///{tmp}/tvidz.db", corpus=rc, census=False)   # this rank's partition of the table
 
             def load():

@@ -5,7 +5,10 @@ driver): N distinct synthetic 1080p clips as mono Y4M files in RAM -> Inspector.
 No decoder in the loop (the host-side ffmpeg decode is outside the hot path); PCIe-inclusive.
    python profiles/e2e_service.py [n_uploads] [frames_per_clip] [workers] [batch] [slot_MiB] [switch] [H] [W] [shards]
 H W default to 1080p; 2160 3840 = configs[4]'s 4K uploads.  shards > 0: the table in that many shards
-(service.ShardedCorpus), every ask through the tick-batched sharded match."""
+(service.ShardedCorpus), every ask through the tick-batched sharded match.  shards = -1: what ONE rank of
+`python -m tvidz_amd.service --ranks N` runs - service.RankCorpus over RcclShardedMatcher (tvz_match_sharded
+with a one-rank communicator: the collective tick exchange degenerates to this process, everything else is
+the N-rank path)."""
 import json
 import os
 import shutil
@@ -41,10 +44,15 @@ try:
         feeder.write_y4m(files[name], frames.cpu().numpy(), fps=(30, 1), chroma="mono")
         del frames
     corpus = None
-    if SHARDS:
+    if SHARDS > 0:
         from tvidz_amd import service
         corpus = service.ShardedCorpus(0, n_shards=SHARDS, k=16)
-    store = tdb.Store(f"sqlite:///{tmp}/tvidz.db", device=0, corpus=corpus)
+    elif SHARDS < 0:
+        from tvidz_amd import corpus as tc, service, sharded
+        shard = tc.DeviceCorpus(0)
+        comm = sharded.make_comm(0)
+        corpus = service.RankCorpus(shard, sharded.RcclShardedMatcher(shard, comm, k=16, cap=4096, priority=-1), xdev="cpu")   # asks are exchanged on the host
+    store = tdb.Store(f"sqlite:///{tmp}/tvidz.db", device=0, corpus=corpus, census=SHARDS >= 0)
     ids, offs, keys = synth.synth_timestamp_corpus(5000, seed=1)
     lib_rows = [(int(ids[c]) + 100000, keys[offs[c]:offs[c + 1]].tolist()) for c in range(len(ids))]
     store.corpus.upload(lib_rows)                         # a 5k-video corpus to match against
@@ -73,7 +81,10 @@ try:
                                                for k, v in sorted(ins.phase_seconds.items()) if not k.startswith("n_")},
                       "tick": ({"ticks": corpus.batcher.ticks, "asks": corpus.batcher.asks, "exact_asks": corpus.exact_asks,
                                 "tick_wall_s": round(corpus.tick_host_s, 4),
-                                "us_per_tick": round(corpus.tick_host_s * 1e6 / max(corpus.batcher.ticks, 1), 1)} if SHARDS else None),
+                                "us_per_tick": round(corpus.tick_host_s * 1e6 / max(corpus.batcher.ticks, 1), 1)} if SHARDS > 0 else
+                               {"ticks": corpus.ticks, "busy_ticks": corpus.busy_ticks, "exact_asks": corpus.exact_asks,
+                                "tick_wall_s": round(corpus.tick_host_s, 4),
+                                "us_per_busy_tick": round(corpus.tick_host_s * 1e6 / max(corpus.busy_ticks, 1), 1)} if SHARDS < 0 else None),
                       "tmp": "shm" if root else "disk"}))
     store.close()
 finally:

@@ -99,7 +99,7 @@ def test_rank_corpus_on_one_gpu_through_the_rccl_path():
 
 def test_rank_service_launcher_on_one_gpu(tmp_path):
     """`python -m tvidz_amd.service --ranks 1` as the launcher runs it on an MI355X: a parent that never
-    touches the GPU, ONE fresh rank process (NCCL process group, DeviceCorpus, RcclShardedMatcher behind
+    touches the GPU, ONE fresh rank process (host-side exchange on gloo, DeviceCorpus, RcclShardedMatcher behind
     the C ABI, the real driver with the HIP scene kernels), the front's HTTP surface.  Unique clips, a copy
     of an earlier upload (flagged at its 2nd cut, app.py:238-255) and a burst of twins through /notify,
     /status and the SSE stream; expected cut times from the oracle's pts_time text (app.py:230).
@@ -112,7 +112,7 @@ def test_rank_service_launcher_on_one_gpu(tmp_path):
 
     port = 6100 + os.getpid() % 200
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    svc = service.RankService(1, f"sqlite:///{tmp_path}/t.db", base_port=port, backend="nccl",
+    svc = service.RankService(1, f"sqlite:///{tmp_path}/t.db", base_port=port,
                               parts="tests.fakes:gpu_rank_parts", k=16, cap=1024, workers=8, ready_timeout=240,
                               env={"PYTHONPATH": root})
     srv = make_server("127.0.0.1", port, service.create_front(svc.urls), threaded=True)

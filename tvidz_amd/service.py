@@ -58,6 +58,46 @@ def _hits_from_topk(rows: np.ndarray, total: int):
     return hits, True
 
 
+class _Stage:
+    """A tick's inputs in ONE pinned block and ONE host-to-device copy: [keys f64 | offsets i64 | exclude
+    ids i32] (three small copies and a fresh pinned allocation each were most of a tick's host time at 64
+    asks, and every one of them is a point where the tick thread gives up the interpreter lock).  The
+    block is reused: a tick ends with a device-to-host copy of its results, so the next one starts
+    behind it on the same stream."""
+
+    def __init__(self, dev):
+        self.dev = torch.device(dev)
+        self._pin = None
+        self._dev = None
+
+    def put(self, queries, excl):
+        """queries: a list of float64 arrays."""
+        lens = np.fromiter((len(q) for q in queries), dtype=np.int64, count=len(queries))
+        return self.put_flat(np.concatenate(queries) if int(lens.sum()) else np.zeros(0), lens, excl)
+
+    def put_flat(self, flat, lens, excl):
+        """flat: all keys back to back (float64[sum(lens)]); -> (d_keys, d_offsets, d_exclude, max_len)."""
+        Q = len(lens)
+        total = int(lens.sum())
+        nk = max(total, 1)
+        need = 8 * nk + 8 * (Q + 1) + 4 * Q
+        if self._pin is None or self._pin.numel() < need:
+            self._pin = torch.empty(max(need, 1 << 16), dtype=torch.uint8).pin_memory()
+            self._dev = torch.empty(self._pin.numel(), dtype=torch.uint8, device=self.dev)
+        h = self._pin.numpy()
+        keys = h[:8 * nk].view(np.float64)
+        offs = h[8 * nk:8 * nk + 8 * (Q + 1)].view(np.int64)
+        ex = h[8 * nk + 8 * (Q + 1):need].view(np.int32)
+        offs[0] = 0
+        np.cumsum(lens, out=offs[1:])
+        keys[:total] = flat
+        ex[:] = excl
+        d = self._dev
+        d[:need].copy_(self._pin[:need], non_blocking=True)
+        return (d[:8 * nk].view(torch.float64), d[8 * nk:8 * nk + 8 * (Q + 1)].view(torch.int64),
+                d[8 * nk + 8 * (Q + 1):need].view(torch.int32), int(lens.max()) if Q else 0)
+
+
 class TickBatcher:
     """Collects find_duplicates asks of concurrent uploads and answers them in batches: one
     `run_batch(items)` per tick, items = [(timestamps float64[], min_match, exclude_id)] sharing one
@@ -130,12 +170,13 @@ class ShardedCorpus:
         self.R = int(n_shards)
         self.k, self.cap = int(k), max(int(cap), int(k))
         self.shards = [tc.DeviceCorpus(self.device) for _ in range(self.R)]
-        self.stream = torch.cuda.Stream(self.dev)          # the tick thread's own (not the legacy default stream)
+        # the tick thread's own stream, at high priority: a tick is a few tiny kernels and two tiny copies
+        # that otherwise queue behind the upload workers' scene kernels
+        self.stream = torch.cuda.Stream(self.dev, priority=-1)
         self._owner = {}
         self._lock = threading.Lock()
         self._ws = [None] * self.R
-        self._pin = None
-        self._dstage = None
+        self._stager = _Stage(self.dev)
         self.exact_asks = 0
         self.tick_host_s = 0.0              # wall time inside _run_batch (host work + the wait for the GPU)
         self.batcher = TickBatcher(self._run_batch, linger_s=linger_s)
@@ -201,29 +242,7 @@ class ShardedCorpus:
         return self._exact(q, min_match, exclude_id, True)
 
     def _stage(self, queries, excl):
-        """The tick's inputs in ONE pinned block and ONE host-to-device copy: [keys f64 | offsets i64 |
-        exclude ids i32] (three small copies and a fresh pinned allocation each were most of a tick's
-        host time at 64 asks)."""
-        Q = len(queries)
-        lens = np.fromiter((len(q) for q in queries), dtype=np.int64, count=Q)
-        nk = max(int(lens.sum()), 1)
-        need = 8 * nk + 8 * (Q + 1) + 4 * Q
-        if self._pin is None or self._pin.numel() < need:
-            self._pin = torch.empty(max(need, 1 << 16), dtype=torch.uint8).pin_memory()
-            self._dstage = torch.empty(self._pin.numel(), dtype=torch.uint8, device=self.dev)
-        h = self._pin.numpy()
-        keys = h[:8 * nk].view(np.float64)
-        offs = h[8 * nk:8 * nk + 8 * (Q + 1)].view(np.int64)
-        ex = h[8 * nk + 8 * (Q + 1):need].view(np.int32)
-        offs[0] = 0
-        np.cumsum(lens, out=offs[1:])
-        if int(lens.sum()):
-            np.concatenate(queries, out=keys[:int(lens.sum())])
-        ex[:] = excl
-        d = self._dstage
-        d[:need].copy_(self._pin[:need], non_blocking=True)
-        return (d[:8 * nk].view(torch.float64), d[8 * nk:8 * nk + 8 * (Q + 1)].view(torch.int64),
-                d[8 * nk + 8 * (Q + 1):need].view(torch.int32), int(lens.max()) if Q else 0)
+        return self._stager.put(queries, excl)
 
     def _run_batch(self, items):
         """One tick: every shard's lookup (top-k kept in the lookup's epilogue) over the whole batch, the
@@ -300,7 +319,8 @@ class RankCorpus:
         self.ticks = 0
         self.busy_ticks = 0
         self.exact_asks = 0
-        self.tick_host_s = 0.0              # host time of the busy ticks (profiles/tick_cost.py)
+        self._stager = None                 # pinned staging of the device matcher's inputs (created on first use)
+        self.tick_host_s = 0.0              # wall time of the busy ticks (profiles/e2e_service.py ... -1)
         self._thread = threading.Thread(target=self._loop, name="tvz-rank-tick", daemon=True)
         self._thread.start()
 
@@ -419,15 +439,27 @@ class RankCorpus:
             np.cumsum(lens, out=offs[1:])
             keys2d = g_keys[rr[sel], ii[sel]]                                      # [n, Lcap]
             flat = keys2d[np.arange(Lcap)[None, :] < lens[:, None]]                # row-major: ask after ask
-            if flat.size == 0:
-                flat = np.zeros(1)
-            d_q = torch.from_numpy(np.ascontiguousarray(flat, dtype=np.float64)).to(mdev)
-            d_off = torch.from_numpy(offs).to(mdev)
-            d_ex = torch.from_numpy(excl_all[sel].astype(np.int32)).to(mdev)
-            merged, totals = self.matcher.match_topk(d_q, d_off, int(lens.max()) if len(lens) else 0, mm, d_ex)
-            Qn, k = merged.shape[0], merged.shape[1]
-            # ONE device-to-host copy per batch: rows and totals together
-            both = torch.cat([merged.reshape(Qn, k * 3), totals.reshape(Qn, 1).to(merged.dtype)], dim=1).cpu().numpy()
+            if mdev.type == "cuda":
+                # one pinned block, one host-to-device copy for keys + offsets + exclusions; the tick's own
+                # high-priority stream (its tiny kernels and copies otherwise queue behind the scene kernels)
+                if self._stager is None:
+                    self._stager = _Stage(mdev)
+                    self._stream = torch.cuda.Stream(mdev, priority=-1)
+                with torch.cuda.device(mdev), torch.cuda.stream(self._stream):
+                    d_q, d_off, d_ex, _ = self._stager.put_flat(flat, lens, excl_all[sel].astype(np.int32))
+                    merged, totals = self.matcher.match_topk(d_q, d_off, int(lens.max()) if len(lens) else 0, mm, d_ex)
+                    Qn, k = merged.shape[0], merged.shape[1]
+                    # ONE device-to-host copy per batch: rows and totals together
+                    both = torch.cat([merged.reshape(Qn, k * 3), totals.reshape(Qn, 1)], dim=1).cpu().numpy()
+            else:
+                if flat.size == 0:
+                    flat = np.zeros(1)
+                d_q = torch.from_numpy(np.ascontiguousarray(flat, dtype=np.float64))
+                d_off = torch.from_numpy(offs)
+                d_ex = torch.from_numpy(excl_all[sel].astype(np.int32))
+                merged, totals = self.matcher.match_topk(d_q, d_off, int(lens.max()) if len(lens) else 0, mm, d_ex)
+                Qn, k = merged.shape[0], merged.shape[1]
+                both = torch.cat([merged.reshape(Qn, k * 3), totals.reshape(Qn, 1).to(merged.dtype)], dim=1).numpy()
             for j in np.flatnonzero(mine[sel]):
                 a = int(sel[j])
                 take[int(ii[a])][4].set_result((both[j, :k * 3].reshape(k, 3).copy(), int(both[j, k * 3])))
@@ -526,8 +558,12 @@ def _hip_parts(rank: int, world: int, group, a):
     from .inspector import Inspector
     shard = tc.DeviceCorpus(a.device)
     comm = sharded.make_comm(a.device)                          # rank 0's 128-byte id over the default group
-    matcher = sharded.RcclShardedMatcher(shard, comm, k=a.k, cap=a.cap)
-    return dict(shard=shard, matcher=matcher, xdev=f"cuda:{a.device}",
+    matcher = sharded.RcclShardedMatcher(shard, comm, k=a.k, cap=a.cap, priority=-1)
+    # the asks are host data: they are exchanged on the host (`group`: gloo by default) - no H2D / D2H and no
+    # stream synchronisation per tick just to learn who asks what; the device collective (one ncclAllGather
+    # of the top-k blocks per batch) lives behind the C ABI in `comm`
+    xdev = f"cuda:{a.device}" if a.backend == "nccl" else "cpu"
+    return dict(shard=shard, matcher=matcher, xdev=xdev,
                 inspector=lambda store: Inspector(store, device=f"cuda:{a.device}", max_workers=a.workers))
 
 
@@ -537,6 +573,11 @@ def _child_main(a) -> int:
     from .inspector import create_app
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ["MASTER_PORT"] = str(a.master_port)
+    if a.switch_interval > 0:
+        # 16 upload threads hold the interpreter lock in turn (the ORM is pure Python); a thread that comes
+        # back from a library call waits for it up to one switch interval - 5 ms by default, a tick's
+        # worth of GPU work twenty times over (profiles/r4_e2e_service.txt)
+        sys.setswitchinterval(a.switch_interval)
     if a.backend == "nccl":
         torch.cuda.set_device(a.device)
     dist.init_process_group(a.backend, rank=a.rank, world_size=a.ranks,
@@ -654,7 +695,7 @@ class RankService:
     """The parent's side: spawn the rank processes, wait until they answer, watch them, stop them.
     Used by main() and by the tests (which talk to the front through Flask's test client or HTTP)."""
 
-    def __init__(self, ranks: int, db_url: str, base_port: int = 5000, backend: str = "nccl", parts: str = "",
+    def __init__(self, ranks: int, db_url: str, base_port: int = 5000, backend: str = "gloo", parts: str = "",
                  devices: Optional[List[int]] = None, k: int = 64, cap: int = 4096, workers: int = 16,
                  tick_s: float = 0.0005, env: Optional[dict] = None, ready_timeout: float = 300.0):
         import socket
@@ -720,7 +761,10 @@ def main(argv=None) -> int:  # pragma: no cover - exercised through subprocesses
     ap.add_argument("--ranks", type=int, default=1)
     ap.add_argument("--port", type=int, default=5000, help="the front; rank r listens on port + 1 + r (loopback)")
     ap.add_argument("--db", default=os.environ.get("POSTGRES_URL", "postgresql://tvidz:tvidz@postgres:5432/tvidz"))
-    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"])
+    ap.add_argument("--backend", default="gloo", choices=["gloo", "nccl"],
+                    help="torch.distributed backend of the HOST-side exchange (who asks what); the device collective "
+                         "is RCCL behind the C ABI either way")
+    ap.add_argument("--switch-interval", type=float, default=0.0005, help="sys.setswitchinterval of a rank process (0: leave)")
     ap.add_argument("--parts", default="", help="module:function building a rank's shard/matcher/driver (tests)")
     ap.add_argument("--k", type=int, default=64)
     ap.add_argument("--cap", type=int, default=4096)

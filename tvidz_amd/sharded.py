@@ -131,14 +131,16 @@ class RcclShardedMatcher:
     merge of batch i overlap the sweep of batch i+1; finish() makes the current stream wait for
     the ticket.  Same results as ShardedMatcher (which keeps the merge logic testable on gloo)."""
 
-    def __init__(self, corpus, comm, k: int = 64, cap: int = 1024, n_streams: int = 2):
+    def __init__(self, corpus, comm, k: int = 64, cap: int = 1024, n_streams: int = 2, priority: int = 0):
+        """`priority=-1`: the service's ticks - a few tiny launches that should not queue behind the upload
+        workers' scene kernels."""
         self.corpus, self.comm = corpus, comm
         self.k = int(k)
         self.cap = max(int(cap), self.k)
         self.world, self.rank = comm.n_ranks, comm.rank
         self.collective = True
         self.dev = torch.device("cuda", corpus.device)
-        self.streams = [torch.cuda.Stream(self.dev) for _ in range(n_streams)]
+        self.streams = [torch.cuda.Stream(self.dev, priority=priority) for _ in range(n_streams)]
         self.ws = [None] * n_streams
         self.out = [None] * n_streams
         self.events = [torch.cuda.Event() for _ in range(n_streams)]
