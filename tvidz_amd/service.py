@@ -574,9 +574,9 @@ def _child_main(a) -> int:
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ["MASTER_PORT"] = str(a.master_port)
     if a.switch_interval > 0:
-        # 16 upload threads hold the interpreter lock in turn (the ORM is pure Python); a thread that comes
-        # back from a library call waits for it up to one switch interval - 5 ms by default, a tick's
-        # worth of GPU work twenty times over (profiles/r4_e2e_service.txt)
+        # (an option, off by default: with 16 upload threads taking the interpreter lock in turn a shorter
+        # switch interval was expected to shorten a tick's waits for it; measured, 0.5 ms against the default
+        # 5 ms made no difference to a tick's ~2.8 ms of wall time or to the fps - gpurun_out/r4_e2e_e.txt)
         sys.setswitchinterval(a.switch_interval)
     if a.backend == "nccl":
         torch.cuda.set_device(a.device)
@@ -764,7 +764,7 @@ def main(argv=None) -> int:  # pragma: no cover - exercised through subprocesses
     ap.add_argument("--backend", default="gloo", choices=["gloo", "nccl"],
                     help="torch.distributed backend of the HOST-side exchange (who asks what); the device collective "
                          "is RCCL behind the C ABI either way")
-    ap.add_argument("--switch-interval", type=float, default=0.0005, help="sys.setswitchinterval of a rank process (0: leave)")
+    ap.add_argument("--switch-interval", type=float, default=0.0, help="sys.setswitchinterval of a rank process (0: leave)")
     ap.add_argument("--parts", default="", help="module:function building a rank's shard/matcher/driver (tests)")
     ap.add_argument("--k", type=int, default=64)
     ap.add_argument("--cap", type=int, default=4096)
