@@ -58,6 +58,9 @@ def parse():
     ap.add_argument("--no-match", action="store_true")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", help="skip the bounded driver run (16 x 256 1080p uploads)")
+    ap.add_argument("--e2e-ranked", action="store_true",
+                    help="run the e2e leg over service.RankCorpus (what --gpus N > 1 does on every rank) at any N: "
+                         "the one way to exercise that code path on a one-GPU box")
     ap.add_argument("--cpu-frames", type=int, default=1536)
     ap.add_argument("--cpu-threads", type=int, default=0)
     return ap.parse_args()
@@ -500,7 +503,7 @@ def bench_config0(dev, n_threads: int = 0):
     return res
 
 
-def bench_e2e(dev, rank: int = 0, world: int = 1, n_uploads: int = 8, n_frames: int = 256):
+def bench_e2e(dev, rank: int = 0, world: int = 1, n_uploads: int = 8, n_frames: int = 256, ranked: bool = False):
     """A bounded run of the whole driver (BASELINE.json configs[4]'s shape at 1080p): N concurrent
     uploads as mono Y4M files in RAM -> reader threads -> pinned slot pool -> H2D -> scene kernels ->
     one match per micro-batch -> write-behind SQL.  PCIe-inclusive; never part of `value`.  The 16 /
@@ -526,10 +529,11 @@ def bench_e2e(dev, rank: int = 0, world: int = 1, n_uploads: int = 8, n_frames: 
         ids, offs, keys = synth.synth_timestamp_corpus(5000, seed=1)
         lib_rows = [(int(ids[c]) + 100000, keys[offs[c]:offs[c + 1]].tolist()) for c in range(len(ids))]
         rc = None
-        if world > 1:
+        if world > 1 or ranked:
             from tvidz_amd import service
             shard = tc.DeviceCorpus(dev.index)
-            group = dist.new_group(backend="gloo")                       # the tick thread's own; the asks are host data
+            # the tick thread's own group; the asks are host data (a single process: no group at all)
+            group = dist.new_group(backend="gloo") if dist.is_initialized() else None
             matcher = sharded.RcclShardedMatcher(shard, sharded.make_comm(dev.index), k=64, cap=4096)
             rc = service.RankCorpus(shard, matcher, group=group, xdev="cpu")
             store = tdb.Store(f"sqlite:///{tmp}/tvidz.db", corpus=rc, census=False)   # this rank's partition of the table
@@ -703,7 +707,7 @@ def main():
         out["config0"] = bench_config0(dev, args.cpu_threads)
     if not args.no_e2e:                   # every rank: the N-rank leg is collective (the tick exchange)
         try:
-            e2e = bench_e2e(dev, rank, world)
+            e2e = bench_e2e(dev, rank, world, ranked=args.e2e_ranked)
         except Exception as e:            # the driver needs SQLAlchemy + a writable temp directory: report, don't die
             e2e = {"error": repr(e)}
             if world > 1:

@@ -87,6 +87,12 @@ constexpr int kIxMaxLds = 159 * 1024;               // gfx950: 160 KiB of LDS pe
 constexpr int64_t kIxSliceBytes = 32 * 1024;        // a directory slice, built by one block in LDS
 constexpr int64_t kIxSliceBytesMax = 128 * 1024;
 constexpr int kIxSliceLdsFloor = 40 * 1024;         // LDS asked for per slice block: at most 3 per CU, 40 KB stay free
+// Directory load.  Every probe step of a lookup is a dependent random line fetch, and a wave waits for its
+// LONGEST chain - the 13 % of a shard batch's keys that are in no row of the shard walk to the next free slot.
+// Measured on rank 0's 1/8 shard of config 4 (Q = 4096, lookup kernel, rocprofv3): load <= 0.9 / 0.8: 86 us,
+// <= 0.5: 60.4, <= 0.25: 57.7, <= 0.12: 57.8 (full corpus 347 -> 341 us).  Memory is not the constraint
+// (64 MB of directory at config 4 on a 288 GB device).
+constexpr int kIxDirLoadPct = 25;
 constexpr int64_t kIndexMinRows = 4096;           // a corpus grown by upserts gets its first index here
 constexpr int64_t kIndexMinDelta = 512;           // rebuilt when the delta exceeds max(this, n_main / 256)
 
@@ -375,14 +381,28 @@ int build_kernels(tvz_corpus *c, IndexBuf &b, const Row *d_rows, int64_t n_rows,
     if (int rc = ensure(b.post, post_cap, 0)) return rc;
     if (int rc = ensure(b.ivid, std::max<int64_t>(rows_cap, n_rows), 0)) return rc;
     if (int rc = ensure(b.drows, delta_capacity(std::max<int64_t>(rows_cap, n_rows)), 0)) return rc;
-    // ONE directory over the distinct keys of all rows, load <= 0.5.  Sized from a guess - a
-    // fingerprint corpus repeats its keys many times over (cuts sit on frame grids) - and doubled
+    // ONE directory over the distinct keys of all rows, load <= 0.25 (kIxDirLoadPct).  Sized from a guess -
+    // a fingerprint corpus repeats its keys many times over (cuts sit on frame grids) - and doubled
     // while too crowded
+    // the size for `distinct` keys: load <= kIxDirLoadPct - unless that directory is too large for the
+    // partitioned build while one of half the size (load <= 0.5) is not (1 M rows x 62 sub-indexes: 144-byte
+    // entries, 4,096 slices of 128 KB at load 0.5)
+    auto partitionable = [&](int lg) {
+        int sl = 6;
+        while (((int64_t)2 << sl) * es <= kIxSliceBytes && sl < lg) ++sl;
+        while ((((int64_t)1 << lg) >> sl) > kIxMaxParts && ((int64_t)2 << sl) * es <= kIxSliceBytesMax) ++sl;
+        return (((int64_t)1 << lg) >> sl) <= kIxMaxParts && ((int64_t)es << sl) <= kIxSliceBytesMax;
+    };
+    auto size_for = [&](double distinct) {
+        int lg = 10;
+        while ((double)((int64_t)1 << lg) * kIxDirLoadPct < 100.0 * distinct && lg < 30) ++lg;
+        if (!partitionable(lg) && partitionable(lg - 1) && (double)((int64_t)1 << (lg - 1)) >= 2.0 * distinct) --lg;
+        return lg;
+    };
     int log2 = 10;
     if (ix.hint_post > 0) {
         // the last build knows how often this corpus repeats its keys: one pass, no retry
-        const double guess = (double)ix.hint_distinct * (double)live_keys / (double)ix.hint_post * 1.25;
-        while ((double)((int64_t)1 << log2) < 2.0 * guess && log2 < 30) ++log2;
+        log2 = size_for((double)ix.hint_distinct * (double)live_keys / (double)ix.hint_post * 1.25);
     } else {
         while (((int64_t)1 << log2) < live_keys / 8) ++log2;
     }
@@ -450,15 +470,14 @@ int build_kernels(tvz_corpus *c, IndexBuf &b, const Row *d_rows, int64_t n_rows,
         TVZ_HIP(hipMemcpyAsync(ix.h_info, ix.info, sizeof(info), hipMemcpyDeviceToHost, st));
         if (int rc = wait_stream_polling(st, ix.build_ev)) return rc;
         info = *ix.h_info;
-        if (!info.failed && (int64_t)info.n_distinct * 2 <= dn) {
+        if (!info.failed && (int64_t)info.n_distinct * 2 <= dn) {            // accepted up to load 0.5; sized for kIxDirLoadPct
             // A directory guessed from the key count of a corpus that repeats its keys (the first
             // build of a handle) comes out many times too large - 4 M entries for 442 k distinct keys
             // at 100k rows, 128 MB instead of 32 - and at 1 M rows too large for the partitioned
             // build.  The count is cheap enough to run once more at the size it has just revealed
-            // (load <= 0.5), if that is at least four times smaller.
-            int fit = 10;
-            while (((int64_t)1 << fit) < (int64_t)info.n_distinct * 2) ++fit;
-            if (!shrunk && fit + 1 < log2) { log2 = fit; shrunk = true; continue; }
+            // (load <= kIxDirLoadPct), if that is at least four times smaller.
+            const int fit = size_for((double)info.n_distinct);
+            if (!shrunk && (fit + 1 < log2 || fit > log2)) { log2 = fit; shrunk = true; continue; }   // (or too small for the target load)
             if (partitioned) break;
             hipLaunchKernelGGL(ix_offsets_kernel, dim3((unsigned)tvz::ceil_div(dn, kBlock)), dim3(kBlock), 0, st, b.dir.p,
                                (size_t)dn, es, ks, ix.info);
