@@ -404,7 +404,9 @@ class RankCorpus:
                 if int(allmeta[:, 0].sum()) == 0:
                     if int(allmeta[:, 2].min()) == 1:        # every rank is closing and nothing is pending anywhere
                         return
-                    time.sleep(self.tick_s)
+                    with self._cv:                           # idle: until the next cadence point, or an ask of this rank
+                        if not self._pending and not self._stop:
+                            self._cv.wait(timeout=self.tick_s)
                     continue
                 self.busy_ticks += 1
                 t0 = time.perf_counter()
