@@ -46,10 +46,32 @@ for N in (1, 2, 4, 8):
     rows.append({"n_gpus": N, "shard_rows": int(len(s_ids)), "ms_per_batch": round(ms, 4)})
     dc.close()
 comm.close()
+# What the one-rank communicator cannot show: at N ranks the merge reads N gathered blocks per query (here: the
+# last shard's block N times over, event-timed on an idle GPU) and the all-gather moves N x Q x 17 x 12 bytes per
+# rank over xGMI.  Both run on the second stream behind the next batch's lookup; the merge takes CUs from it.
+dc = tc.DeviceCorpus(0)
+dc.upload_csr(*sharded.shard_csr(ids, offs, keys, 0, 8))
+ws = torch.empty(tc.workspace_bytes(Q, max_len, 16384, 16), dtype=torch.uint8, device=dev)
+blk = dc.match_topk(d_q, d_off, max_len, 2, 16384, 16, workspace=ws).clone()
+for r in rows:
+    N = r["n_gpus"]
+    g = blk.unsqueeze(0).repeat(N, 1, 1, 1).contiguous()
+    ts = []
+    for _ in range(30):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(); tc.topk_merge(g, 16); b.record()
+        torch.cuda.synchronize()
+        ts.append(a.elapsed_time(b))
+    r["merge_of_N_blocks_ms"] = round(float(np.median(ts[5:])), 4)
+    r["allgather_bytes_received_per_rank"] = N * Q * 17 * 12
+dc.close()
 t1 = rows[0]["ms_per_batch"]
 for r in rows:
     r["predicted_speedup"] = round(t1 / r["ms_per_batch"], 2)
     r["allgather_bytes_per_rank"] = Q * 17 * 12
 print(json.dumps({"Q": Q, "C": C, "k": 16, "cap": 16384, "rows": rows,
                   "note": "rank-0 shard on one MI355X; the collective (204 B per query and rank) is overlapped with the "
-                          "next batch's sweep on a second stream, so the prediction is T_shard(1) / T_shard(N)"}))
+                          "next batch's sweep on a second stream, so the prediction is T_shard(1) / T_shard(N); "
+                          "merge_of_N_blocks_ms = the merge of N gathered blocks alone on an idle GPU (the timed loop merges "
+                          "ONE block): at N ranks it runs on the second stream and takes that much GPU time from the next "
+                          "batch's lookup"}))
