@@ -26,6 +26,7 @@ import argparse
 import json
 import os
 import sys
+import threading
 import time
 from concurrent.futures import ThreadPoolExecutor
 
@@ -58,6 +59,7 @@ def parse():
     ap.add_argument("--no-match", action="store_true")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", help="skip the bounded driver run (16 x 256 1080p uploads)")
+    ap.add_argument("--e2e-timeout", type=float, default=240.0, help="abandon the e2e leg after this many seconds")
     ap.add_argument("--e2e-ranked", action="store_true",
                     help="run the e2e leg over service.RankCorpus (what --gpus N > 1 does on every rank) at any N: "
                          "the one way to exercise that code path on a one-GPU box")
@@ -715,7 +717,28 @@ def main():
     torch.cuda.empty_cache()
     if rank == 0 and world == 1 and not args.no_cpu:
         out["config0"] = bench_config0(dev, args.cpu_threads)
+    if match_leg is not None:
+        out["match"] = match_leg
+    printed = threading.Event()
+
+    def emit():
+        if rank == 0 and not printed.is_set():
+            printed.set()
+            sys.stdout.flush()
+            os.write(real_stdout, (json.dumps(out) + "\n").encode())
+
     if not args.no_e2e:                   # every rank: the N-rank leg is collective (the tick exchange)
+        # The leg that has never run on more than one GPU comes LAST and under a watchdog: if it hangs (a
+        # collective that some rank never joins), the line - headline, roofline, match - is printed without
+        # it and every rank leaves, instead of the whole scaling run being lost.
+        def watchdog():
+            if not done.wait(args.e2e_timeout):
+                out["e2e"] = {"error": f"e2e leg did not finish within {args.e2e_timeout:.0f} s on rank {rank} (abandoned)"}
+                print(f"[bench] rank {rank}: e2e leg timed out; leaving", file=sys.stderr)
+                emit()
+                os._exit(0)
+        done = threading.Event()
+        threading.Thread(target=watchdog, daemon=True).start()
         try:
             e2e = bench_e2e(dev, rank, world, ranked=args.e2e_ranked)
         except Exception as e:            # the driver needs SQLAlchemy + a writable temp directory: report, don't die
@@ -725,14 +748,13 @@ def main():
         if rank == 0:
             out["e2e"] = e2e
         torch.cuda.empty_cache()
-    if match_leg is not None:
-        out["match"] = match_leg
+        if dist.is_initialized():
+            dist.barrier()                # (still under the watchdog)
+        done.set()
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
-    if rank == 0:
-        sys.stdout.flush()
-        os.write(real_stdout, (json.dumps(out) + "\n").encode())
+    emit()
 
 
 if __name__ == "__main__":
