@@ -59,7 +59,7 @@ def _sse_last(base, filename, out):
 def svc(tmp_path_factory):
     db_url = f"sqlite:///{tmp_path_factory.mktemp('svc')}/t.db"
     s = service.RankService(2, db_url, base_port=PORT, backend="gloo", parts="tests.fakes:cpu_rank_parts", k=4, cap=64,
-                            workers=8, tick_s=0.002, ready_timeout=120,
+                            workers=8, tick_s=0.002, ready_timeout=300,
                             env={"PYTHONPATH": os.path.dirname(os.path.dirname(os.path.abspath(__file__)))})
     front = service.create_front(s.urls)
     from werkzeug.serving import make_server
