@@ -283,7 +283,9 @@ int tvz_topk(const int32_t *d_lists, const int32_t *d_lists_n, int32_t n_lists, 
  *   d_gathered : int32[n_ranks][Q][k+1][3]  ->  d_topk int32[Q][k][3], d_totals int32[Q]
  * (d_totals = hits over all shards; > k means the merged list is truncated to the k best;
  * NEGATIVE means some shard's hit list overflowed `cap`, so its top-k may be inexact: re-run with
- * a larger cap). */
+ * a larger cap).  The gathered blocks are what tvz_match_topk / tvz_topk_shard wrote: k rows in
+ * ascending (kth, video_id, count) order, padding last - up to 16 ranks and k <= 64 are merged as
+ * SORTED lists (a k-way merge, not a selection). */
 int tvz_topk_shard(const int32_t *d_hits, const int32_t *d_hits_n, int32_t Q, int32_t cap,
                    int32_t k, int32_t *d_out, void *hip_stream);
 /* The shards of ONE process (several handles on one device: service.ShardedCorpus, the one-GPU form of

@@ -17,6 +17,7 @@ TAGS = {"join": "C100000_Q4096", "q1_100k": "C100000_Q1", "q1_5k": "C5000_Q1", "
         "topk": "C100000_Q4096", "shard8": "C12500_Q4096", "index": "C100000_Q4096_index",
         "index1": "C100000_Q1_index", "index1_5k": "C5000_Q1_index"}
 OURS = ("ts_match_q1", "ts_match_tile", "ts_match_join", "ts_join_build", "ts_topk_select", "ts_topk_kernel", "ts_topk_wave",
+        "ts_topk_merge_sorted",
         "ts_prep", "ts_kth_fixup", "ts_counts_gather", "ts_match_index_topk", "ts_match_index", "ix_count", "ix_fill",
         "ix_offsets")
 

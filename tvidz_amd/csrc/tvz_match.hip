@@ -1221,6 +1221,25 @@ int launch_topk_lists(const int32_t *d_lists, const int32_t *d_lists_n, int32_t 
     const int32_t *flags = nullptr;
     unsigned grid = (unsigned)Q;
     (void)d_flags;
+    if (mode == 2 && n_lists <= 16 && k <= 64) {
+        // the gathered blocks are sorted (tvz_match_topk / tvz_topk_shard wrote them): a k-way merge, 64 / G queries
+        // per wave, instead of a selection over an unordered set
+        int G = 1;
+        while (G < n_lists) G <<= 1;
+        const unsigned blocks = (unsigned)tvz::ceil_div((int64_t)Q * G, 64);
+        const size_t lds = (size_t)64 * (3 * (size_t)k + 1) * 4;
+#define TVZ_MS(GG) hipLaunchKernelGGL(ts_topk_merge_sorted_kernel<GG>, dim3(blocks), dim3(64), lds, st, d_lists, n_lists, Q, k, d_topk, d_totals)
+        switch (G) {
+            case 1: TVZ_MS(1); break;
+            case 2: TVZ_MS(2); break;
+            case 4: TVZ_MS(4); break;
+            case 8: TVZ_MS(8); break;
+            default: TVZ_MS(16); break;
+        }
+#undef TVZ_MS
+        TVZ_HIP(hipGetLastError());
+        return TVZ_OK;
+    }
     if (mode == 2 && k <= kWsK && (int64_t)n_lists * k <= kWsMax) {
         // n_lists x k entries fit one wave's registers: no block kernel, no flags
         hipLaunchKernelGGL(ts_topk_wave_kernel, dim3((unsigned)tvz::ceil_div(Q, kBlock / 64)), dim3(kBlock), 0, st,

@@ -1603,6 +1603,82 @@ __global__ __launch_bounds__(kBlock) void ts_topk_wave_kernel(
         wave_topk_body<kWsE>(h, lane, q, n, total_row, lists, n_lists, Q, cap, k, topk, mode, totals, flags, ns);
 }
 
+// ---- merge of the gathered per-rank blocks when they are SORTED (they are: tvz_match_topk / tvz_topk_shard write
+// their k rows in ascending (kth, video_id, count) order) and there are at most 16 of them ----------------------------
+// The one-wave kernel above treats the R x k gathered entries as an unordered set (histogram, compaction, 64-lane
+// bitonic network: ~720 VALU instructions per query) - 15 % of a sharded batch's instructions on a 1/8 shard, on the
+// stream that shares the GPU with the next batch's lookup.  Sorted inputs need a k-way merge only: a group of G =
+// 2^ceil(log2 R) lanes takes one query, lane r walks list r (staged in LDS, one private run per lane: no
+// synchronisation), and each of the k steps min-reduces the G heads by a DPP butterfly inside the group; the winner
+// writes output row t and moves to its next entry.  64 / G queries per wave: ~50 instructions per query at R = 8,
+// a plain copy at R = 1.  Totals: |n| summed over the ranks, negated if any rank's list overflowed (as above).
+template <int G>
+__global__ __launch_bounds__(64) void ts_topk_merge_sorted_kernel(const int32_t *__restrict__ lists, int32_t n_lists,
+                                                                  int32_t Q, int32_t k, int32_t *__restrict__ topk,
+                                                                  int32_t *__restrict__ totals) {
+    extern __shared__ int32_t s_lists[];                   // [64][3 k + 1] (the odd stride spreads the lanes over the banks)
+    const int lane = threadIdx.x;
+    const int q = (int)blockIdx.x * (64 / G) + lane / G;
+    const int r = lane % G;
+    const bool live = q < Q && r < n_lists;
+    int32_t *mine = s_lists + (size_t)lane * (3 * k + 1);
+    int32_t t_r = 0;
+    if (live) {
+        const int32_t *src = lists + (((int64_t)r * Q + q) * (k + 1)) * 3;
+        for (int i = 0; i < 3 * k; ++i) mine[i] = src[i];
+        t_r = src[3 * k + 1];
+    }
+    // hit totals over the ranks (each butterfly step adds two disjoint sets of lanes)
+    unsigned long long sum = t_r < 0 ? (unsigned long long)(-(long long)t_r) : (unsigned long long)t_r;
+    uint32_t over = t_r < 0 ? 1u : 0u;
+#define TVZ_MS_SUM(C) { sum += dpp16_64<C>(sum); over |= dpp16<C>(over); }
+    if (G >= 2) TVZ_MS_SUM(0xB1)
+    if (G >= 4) TVZ_MS_SUM(0x4E)
+    if (G >= 8) TVZ_MS_SUM(0x141)
+    if (G >= 16) TVZ_MS_SUM(0x140)
+#undef TVZ_MS_SUM
+    if (q < Q && r == 0 && totals) {
+        int32_t t = sum > 0x7fffffffULL ? 0x7fffffff : (int32_t)sum;
+        if (over) t = (t == 0) ? INT32_MIN : -t;
+        totals[q] = t;
+    }
+    // the k-way merge: heads compared as (kth + 1, video_id, count, rank) - the order of the top-k kernels, made
+    // unique inside a group by the rank
+    int p = 0;
+    uint32_t hi, lo, wc;
+    auto head = [&]() {
+        if (live && p < k && mine[3 * p] >= 0) {
+            hi = (uint32_t)mine[3 * p + 2] + 1u;
+            lo = (uint32_t)mine[3 * p];
+            wc = (uint32_t)mine[3 * p + 1];
+        } else {
+            hi = lo = wc = 0xffffffffu;                    // exhausted (or padding: the rest of a sorted list is padding too)
+        }
+    };
+    head();
+    for (int t = 0; t < k; ++t) {
+        uint32_t mh = hi, ml = lo, mc = wc, mr = (uint32_t)r;
+#define TVZ_MS_MIN(C) { const uint32_t oh = dpp16<C>(mh), ol = dpp16<C>(ml), oc = dpp16<C>(mc), orr = dpp16<C>(mr); \
+                        if (oh < mh || (oh == mh && (ol < ml || (ol == ml && (oc < mc || (oc == mc && orr < mr)))))) \
+                            { mh = oh; ml = ol; mc = oc; mr = orr; } }
+        if (G >= 2) TVZ_MS_MIN(0xB1)
+        if (G >= 4) TVZ_MS_MIN(0x4E)
+        if (G >= 8) TVZ_MS_MIN(0x141)
+        if (G >= 16) TVZ_MS_MIN(0x140)
+#undef TVZ_MS_MIN
+        if (q < Q) {
+            int32_t *o = topk + ((int64_t)q * k + t) * 3;
+            if (mh == 0xffffffffu) {                       // every list is exhausted: padding from here on
+                if (r == 0) { o[0] = -1; o[1] = 0; o[2] = TVZ_KTH_NEVER; }
+            } else if (mr == (uint32_t)r) {                // this lane's head is the smallest
+                o[0] = (int32_t)ml; o[1] = (int32_t)mc; o[2] = (int32_t)(mh - 1u);
+                ++p;
+                head();
+            }
+        }
+    }
+}
+
 // ---- small helpers launched around the sweeps ------------------------------------------------
 // hit counters = 0, hash-join key tables = 0xff.. (kJEmpty), presence bitmaps = 0: one launch
 __global__ __launch_bounds__(kBlock) void ts_prep_kernel(int32_t *__restrict__ hits_n, int32_t ns, int32_t Q,
