@@ -59,6 +59,8 @@ def parse():
     ap.add_argument("--no-match", action="store_true")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", help="skip the bounded driver run (16 x 256 1080p uploads)")
+    ap.add_argument("--match-depth", type=int, default=0,
+                    help="query batches in flight in the corpus-match leg, one stream each (0: calibrate 2 against 3)")
     ap.add_argument("--e2e-timeout", type=float, default=240.0, help="abandon the e2e leg after this many seconds")
     ap.add_argument("--e2e-ranked", action="store_true",
                     help="run the e2e leg over service.RankCorpus (what --gpus N > 1 does on every rank) at any N: "
@@ -207,39 +209,70 @@ def bench_match(args, rank, world, dev):
     # merge) at every N, a single process included (one-rank communicator); torch.distributed only
     # ships the 128-byte RCCL id
     comm = sharded.make_comm(dev.index)
-    sm = sharded.RcclShardedMatcher(dc, comm, k=K_TOP, cap=CAP)
-    # the very first FULL batch this handle ever answers: nothing of the index is in any cache.  (A one-query
-    # batch goes first: the communicator's first collective, the workspaces and the streams are one-time
-    # set-up - tens of milliseconds on some boxes - not the cost of a cold index.)
-    one = tc.pack_queries(q_sets[0][:1], dev)
-    sm.match_topk(one[0], one[1], max_len, 2)
-    torch.cuda.synchronize()
-    tc0 = time.perf_counter()
-    merged, totals = sm.match_topk(batches[NB - 1][0], batches[NB - 1][1], max_len, 2)
-    torch.cuda.synchronize()
-    first_batch_ms = (time.perf_counter() - tc0) * 1e3
+    # Batches in flight, each on its own stream.  A third one can fill the gaps the tails of two lookups leave
+    # (55 -> 46 us per batch on a 1/8 shard in a fresh process) - or lose 20 %: how the runtime maps the streams
+    # onto hardware queues decides, and that is not in the program's hands (profiles/r3_shard_pipeline.txt).  So
+    # the depth is CALIBRATED: both pipelines answer 40 batches, the faster one runs the timed loop
+    # (--match-depth 2|3 pins it).
+    from collections import deque
+
+    def run_stream(m, depth, steps, pick):
+        inflight, last = deque(), None
+        for i in range(steps):
+            b = pick(i)
+            inflight.append(m.submit(b[0], b[1], max_len, 2, inputs_ready=True))
+            if len(inflight) >= depth:
+                last = m.finish(inflight.popleft(), host=True)
+        while inflight:
+            last = m.finish(inflight.popleft(), host=True)
+        return last
+    calib = {}
+    first_batch_ms = None
+    cands = {}
+    for d in ((args.match_depth,) if args.match_depth else (2, 3)):
+        m = sharded.RcclShardedMatcher(dc, comm, k=K_TOP, cap=CAP, n_streams=d)
+        if first_batch_ms is None:
+            # the very first FULL batch this handle ever answers: nothing of the index is in any cache.  (A
+            # one-query batch goes first: the communicator's first collective, the workspaces and the streams
+            # are one-time set-up - tens of milliseconds on some boxes - not the cost of a cold index.)
+            one = tc.pack_queries(q_sets[0][:1], dev)
+            m.match_topk(one[0], one[1], max_len, 2)
+            torch.cuda.synchronize()
+            tc0 = time.perf_counter()
+            m.match_topk(batches[NB - 1][0], batches[NB - 1][1], max_len, 2)
+            torch.cuda.synchronize()
+            first_batch_ms = (time.perf_counter() - tc0) * 1e3
+        for i in range(2 * d + 4):
+            m.match_topk(batches[i % NB][0], batches[i % NB][1], max_len, 2)
+        torch.cuda.synchronize()
+        tcal = time.perf_counter()
+        run_stream(m, d, 40, lambda i: batches[i % NB])
+        torch.cuda.synchronize()
+        calib[d] = (time.perf_counter() - tcal) * 1e3 / 40
+        cands[d] = m
+    DEPTH = min(calib, key=calib.get)
+    if world > 1:                        # every rank must run the same pipeline: rank 0's choice
+        t = torch.tensor([DEPTH], dtype=torch.int64, device=dev)
+        dist.broadcast(t, src=0)
+        DEPTH = int(t.item())
+    sm = cands[DEPTH]
     for i in range(20):
         merged, totals = sm.match_topk(batches[i % NB][0], batches[i % NB][1], max_len, 2)
     barrier_sync(world)
+
+    def stream_of_batches(pick):
+        """A stream of query batches over DEPTH HIP streams: the all-gather + merge of a batch overlap the
+        lookups of the next ones; every batch is fully merged inside the timed region."""
+        return run_stream(sm, DEPTH, args.match_steps, pick)
     t0 = time.perf_counter()
-    # a stream of query batches over two HIP streams: the all-gather + merge of batch i overlap the
-    # sweep of batch i+1; every batch is fully merged inside the timed region
-    ticket = sm.submit(batches[0][0], batches[0][1], max_len, 2, inputs_ready=True)
-    for i in range(1, args.match_steps):
-        nxt = sm.submit(batches[i % NB][0], batches[i % NB][1], max_len, 2, inputs_ready=True)
-        merged, totals = sm.finish(ticket, host=True)
-        ticket = nxt
-    merged, totals = sm.finish(ticket, host=True)
+    merged, totals = stream_of_batches(lambda i: batches[i % NB])
     barrier_sync(world)
     wall = max_over_ranks(time.perf_counter() - t0, world, dev)
+    merged, totals = merged.clone(), totals.clone()      # (the matcher's output slots are reused by the next loop)
     # the same loop replaying ONE batch (what rounds 1-3 timed), for the record
     t0 = time.perf_counter()
-    ticket = sm.submit(d_q, d_off, max_len, 2, inputs_ready=True)
-    for i in range(1, args.match_steps):
-        nxt = sm.submit(d_q, d_off, max_len, 2, inputs_ready=True)
-        sm.finish(ticket, host=True)
-        ticket = nxt
-    sm.finish(ticket, host=True)
+    stream_of_batches(lambda i: batches[0])
+    torch.cuda.synchronize()
     replay_ms = (time.perf_counter() - t0) * 1e3 / args.match_steps
     pairs = Q * C * args.match_steps
     mean_len = float(offs[-1]) / C
@@ -297,6 +330,8 @@ def bench_match(args, rank, world, dev):
            "mean_cuts_per_video": round(mean_len, 1), "min_match": 2, "steps": args.match_steps,
            "ms_per_batch": wall * 1e3 / args.match_steps,
            "ms_per_batch_one_batch_replayed": replay_ms, "first_batch_ms_cold": first_batch_ms,
+           "batches_in_flight": DEPTH,
+           "batches_in_flight_calibration_ms": {str(d): round(v, 4) for d, v in calib.items()},
            "distinct_query_batches_rotating": NB,
            "algo": "AUTO = inverted-index lookup, ONE block per query walking the query's sub-indexes of 16384 rows "
                    "and keeping the per-shard top-k in its epilogue (no hit lists, no top-k launch) + sweep of the "

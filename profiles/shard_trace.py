@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """The sharded match pipeline of ONE rank's 1/N shard under a kernel trace: which kernels a batch is
-made of and how the two alternating streams overlap.   python profiles/shard_trace.py [N] [Q] [steps]
-(run under rocprofv3 --kernel-trace; profiles/shard_timeline.py reads the trace)"""
+made of and how the two alternating streams overlap.   python profiles/shard_trace.py [N] [Q] [steps] [streams] [nowait|-] [depth]
+(run under rocprofv3 --kernel-trace; profiles/shard_timeline.py reads the trace).  depth = batches in flight
+(default 2: submit the next, then finish the previous)."""
 import os
 import sys
 
@@ -15,6 +16,7 @@ Q = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
 STEPS = int(sys.argv[3]) if len(sys.argv) > 3 else 40
 N_STREAMS = int(sys.argv[4]) if len(sys.argv) > 4 else 2
 NO_WAIT = len(sys.argv) > 5 and sys.argv[5] == "nowait"      # probe only: drop the wait on the caller's stream
+DEPTH = int(sys.argv[6]) if len(sys.argv) > 6 else 2
 if NO_WAIT:
     torch.cuda.Stream.wait_stream = lambda self, other: None
 dev = torch.device("cuda:0")
@@ -31,13 +33,15 @@ for _ in range(3):
 torch.cuda.synchronize()
 import time
 t0 = time.perf_counter()
-ticket = sm.submit(d_q, d_off, max_len, 2, inputs_ready=True)
-for _ in range(STEPS - 1):
-    nxt = sm.submit(d_q, d_off, max_len, 2, inputs_ready=True)
-    sm.finish(ticket, host=True)
-    ticket = nxt
-sm.finish(ticket, host=True)
+from collections import deque
+inflight = deque()
+for _ in range(STEPS):
+    inflight.append(sm.submit(d_q, d_off, max_len, 2, inputs_ready=True))
+    if len(inflight) >= DEPTH:
+        sm.finish(inflight.popleft(), host=True)
+while inflight:
+    sm.finish(inflight.popleft(), host=True)
 torch.cuda.synchronize()
-print(f"N={N} Q={Q} streams={N_STREAMS} nowait={NO_WAIT}: {(time.perf_counter() - t0) * 1e6 / STEPS:.1f} us per batch")
+print(f"N={N} Q={Q} streams={N_STREAMS} depth={DEPTH} nowait={NO_WAIT}: {(time.perf_counter() - t0) * 1e6 / STEPS:.1f} us per batch")
 dc.close()
 comm.close()
