@@ -35,13 +35,19 @@ import time
 t0 = time.perf_counter()
 from collections import deque
 inflight = deque()
+t_submit = t_finish = 0.0
 for _ in range(STEPS):
+    a = time.perf_counter()
     inflight.append(sm.submit(d_q, d_off, max_len, 2, inputs_ready=True))
+    b = time.perf_counter()
+    t_submit += b - a
     if len(inflight) >= DEPTH:
         sm.finish(inflight.popleft(), host=True)
+        t_finish += time.perf_counter() - b
 while inflight:
     sm.finish(inflight.popleft(), host=True)
 torch.cuda.synchronize()
-print(f"N={N} Q={Q} streams={N_STREAMS} depth={DEPTH} nowait={NO_WAIT}: {(time.perf_counter() - t0) * 1e6 / STEPS:.1f} us per batch")
+print(f"N={N} Q={Q} streams={N_STREAMS} depth={DEPTH} nowait={NO_WAIT}: {(time.perf_counter() - t0) * 1e6 / STEPS:.1f} us per batch "
+      f"(host: {t_submit * 1e6 / STEPS:.1f} us in submit, {t_finish * 1e6 / STEPS:.1f} us waiting in finish)")
 dc.close()
 comm.close()
