@@ -304,7 +304,7 @@ class RankCorpus:
     still exchanging stop together; the service process then exits non-zero (service main)."""
 
     def __init__(self, shard, matcher, group=None, xdev="cpu", tick_s: float = 0.0005, max_batch: int = 1024,
-                 owner_fn: Optional[Callable[[int], int]] = None):
+                 owner_fn: Optional[Callable[[int], int]] = None, idle_tick_s: float = 0.005, idle_after: int = 400):
         self.shard, self.matcher, self.group = shard, matcher, group
         self.xdev = torch.device(xdev)
         inited = dist.is_available() and dist.is_initialized()
@@ -312,6 +312,11 @@ class RankCorpus:
         self.rank = dist.get_rank(group) if inited else 0
         self.owner_fn = owner_fn
         self.tick_s, self.max_batch = float(tick_s), int(max_batch)
+        # a service nobody uploads to still exchanges "nothing to do" at every cadence point: after `idle_after`
+        # empty ticks in a row (the same count on every rank: it is read off the exchanged meta) the cadence
+        # drops to `idle_tick_s`; an ask of this rank still wakes its loop at once, the siblings follow within
+        # one idle tick
+        self.idle_tick_s, self.idle_after = max(float(idle_tick_s), float(tick_s)), int(idle_after)
         self._cv = threading.Condition()
         self._pending: List[tuple] = []
         self._stop = False
@@ -387,6 +392,7 @@ class RankCorpus:
 
     def _loop(self):
         take = []
+        idle = 0
         try:
             while True:
                 with self._cv:
@@ -404,10 +410,12 @@ class RankCorpus:
                 if int(allmeta[:, 0].sum()) == 0:
                     if int(allmeta[:, 2].min()) == 1:        # every rank is closing and nothing is pending anywhere
                         return
+                    idle += 1
                     with self._cv:                           # idle: until the next cadence point, or an ask of this rank
                         if not self._pending and not self._stop:
-                            self._cv.wait(timeout=self.tick_s)
+                            self._cv.wait(timeout=self.tick_s if idle < self.idle_after else self.idle_tick_s)
                     continue
+                idle = 0
                 self.busy_ticks += 1
                 t0 = time.perf_counter()
                 self._exchange_and_answer(take, allmeta)
@@ -543,6 +551,7 @@ class FilenameOwner:
         if int(video_id) not in self.names:
             from . import db
             self.names = db.video_filenames(self.url)           # (one SELECT per reload, not per row)
+            self.names.setdefault(int(video_id), None)          # timestamps of a video `videos` does not hold: asked once
         name = self.names.get(int(video_id))
         return owner_rank(name, self.world) if name is not None else int(video_id) % self.world
 
