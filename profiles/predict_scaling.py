@@ -16,7 +16,7 @@ import numpy as np
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from tvidz_amd import corpus as tc, sharded, synth  # noqa: E402
+from tvidz_amd import _lib, corpus as tc, sharded, synth  # noqa: E402
 
 Q = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 C = int(sys.argv[2]) if len(sys.argv) > 2 else 100000
@@ -29,6 +29,50 @@ queries = synth.synth_queries(ids, offs, keys, Q, seed=synth.CORPUS_SEED + 1)
 d_q, d_off, max_len = tc.pack_queries(queries, dev)
 rows = []
 comm = sharded.make_comm(0)
+K, CAP = 16, 16384
+
+
+def emulated_tail(dc, depth, B, steps=100):
+    lib = _lib.load()
+    sts = [torch.cuda.Stream(dev) for _ in range(depth)]
+    evs = [torch.cuda.Event() for _ in range(depth)]
+    ws = [torch.empty(tc.workspace_bytes(Q, max_len, CAP, K), dtype=torch.uint8, device=dev) for _ in range(depth)]
+    src = dc.match_topk(d_q, d_off, max_len, 2, CAP, K, workspace=ws[0]).unsqueeze(0).repeat(B, 1, 1, 1).contiguous()
+    g = [torch.empty((B, Q, K + 1, 3), dtype=torch.int32, device=dev) for _ in range(depth)]
+    loc = [torch.empty((Q, K + 1, 3), dtype=torch.int32, device=dev) for _ in range(depth)]
+    out = [(torch.empty((Q, K, 3), dtype=torch.int32, device=dev), torch.empty(Q, dtype=torch.int32, device=dev))
+           for _ in range(depth)]
+    torch.cuda.synchronize()
+
+    def submit(i):
+        st = sts[i]
+        _lib.check(lib.tvz_match_topk(dc._h, d_q.data_ptr(), d_off.data_ptr(), Q, max_len, 2, None, CAP, K,
+                                      loc[i].data_ptr(), ws[i].data_ptr(), ws[i].numel(), _lib.ALGO_AUTO, st.cuda_stream))
+        with torch.cuda.stream(st):
+            g[i].copy_(src, non_blocking=True)              # B blocks land in the gathered buffer ...
+            if B > 1:
+                g[i][0].copy_(loc[i], non_blocking=True)    # ... this rank's own among them
+        _lib.check(lib.tvz_topk_merge(g[i].data_ptr(), B, Q, K, out[i][0].data_ptr(), out[i][1].data_ptr(), st.cuda_stream))
+        evs[i].record(st)
+    best = None
+    for _ in range(2):
+        for i in range(depth):
+            submit(i)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        inflight = deque()
+        for n in range(steps):
+            i = n % depth
+            if len(inflight) >= depth:
+                evs[inflight.popleft()].synchronize()
+            submit(i)
+            inflight.append(i)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) * 1e3 / steps
+        best = dt if best is None else min(best, dt)
+    return best
+
+
 for N in (1, 2, 4, 8):
     s_ids, s_offs, s_keys = sharded.shard_csr(ids, offs, keys, 0, N)
     dc = tc.DeviceCorpus(0)
@@ -51,8 +95,21 @@ for N in (1, 2, 4, 8):
         torch.cuda.synchronize()
         by_depth[depth] = (time.perf_counter() - t0) * 1e3 / steps
     ms = min(by_depth.values())
+    best = min(by_depth, key=by_depth.get)
     rows.append({"n_gpus": N, "shard_rows": int(len(s_ids)), "ms_per_batch": round(ms, 4),
                  "ms_per_batch_by_batches_in_flight": {str(d): round(v, 4) for d, v in by_depth.items()}})
+    # What the one-rank communicator leaves out of that loop: at N ranks every batch WRITES N blocks into this
+    # rank's gathered buffer and the merge READS N lists per query.  The same pipeline from three library calls
+    # (tvz_match_topk -> a device copy of B blocks -> tvz_topk_merge of B blocks), once with B = 1 (the shape of
+    # the loop above) and once with B = N (the other ranks' blocks are stand-ins: earlier results of this shard):
+    # the difference is the GPU time the N-block tail takes from the pipeline.  (Not the link time: xGMI moves
+    # the blocks while the next batch's lookup runs; see the note.)
+    emu = {}
+    for B in sorted({1, N}):
+        emu[B] = emulated_tail(dc, best, B)
+    rows[-1]["three_call_loop_ms_1_block"] = round(emu[1], 4)
+    rows[-1]["three_call_loop_ms_N_blocks"] = round(emu[N], 4)
+    rows[-1]["ms_per_batch_with_N_block_tail"] = round(ms + max(emu[N] - emu[1], 0.0), 4)
     dc.close()
 comm.close()
 # What the one-rank communicator cannot show: at N ranks the merge reads N gathered blocks per query (here: the
@@ -77,6 +134,7 @@ dc.close()
 t1 = rows[0]["ms_per_batch"]
 for r in rows:
     r["predicted_speedup"] = round(t1 / r["ms_per_batch"], 2)
+    r["predicted_speedup_with_N_block_tail"] = round(rows[0]["ms_per_batch_with_N_block_tail"] / r["ms_per_batch_with_N_block_tail"], 2)
     r["allgather_bytes_per_rank"] = Q * 17 * 12
 print(json.dumps({"Q": Q, "C": C, "k": 16, "cap": 16384, "batches_in_flight": DEPTH or "calibrated per N: the faster of 2 and 3", "rows": rows,
                   "note": "rank-0 shard on one MI355X; the collective (204 B per query and rank) is overlapped with the "

@@ -12,7 +12,8 @@ import pytest
 from tvidz_amd import build as tbuild
 
 HOT = ("ts_match_index_kernel", "ts_match_index_topk_kernel", "ts_find_fused_kernel", "ts_match_join_kernel",
-       "ts_match_q1_kernel", "ts_match_tile_kernel", "luma_sad_flat_kernel", "ts_topk_wave_kernel")
+       "ts_match_q1_kernel", "ts_match_tile_kernel", "luma_sad_flat_kernel", "ts_topk_wave_kernel",
+       "ts_topk_merge_sorted_kernel")
 AT_MOST_64_VGPRS = ("ts_match_index_kernel", "ts_match_index_topk_kernel", "ts_find_fused_kernel", "ts_match_join_kernel")
 
 

@@ -1625,8 +1625,17 @@ __global__ __launch_bounds__(64) void ts_topk_merge_sorted_kernel(const int32_t 
     int32_t t_r = 0;
     if (live) {
         const int32_t *src = lists + (((int64_t)r * Q + q) * (k + 1)) * 3;
-        for (int i = 0; i < 3 * k; ++i) mine[i] = src[i];
         t_r = src[3 * k + 1];
+        // twelve loads in flight at a time (k is a run-time value: the plain loop was 3 k dependent round trips)
+        int i = 0;
+        for (; i + 12 <= 3 * k; i += 12) {
+            int32_t v[12];
+#pragma unroll
+            for (int j = 0; j < 12; ++j) v[j] = src[i + j];
+#pragma unroll
+            for (int j = 0; j < 12; ++j) mine[i + j] = v[j];
+        }
+        for (; i < 3 * k; ++i) mine[i] = src[i];
     }
     // hit totals over the ranks (each butterfly step adds two disjoint sets of lanes)
     unsigned long long sum = t_r < 0 ? (unsigned long long)(-(long long)t_r) : (unsigned long long)t_r;
@@ -1643,24 +1652,24 @@ __global__ __launch_bounds__(64) void ts_topk_merge_sorted_kernel(const int32_t 
         totals[q] = t;
     }
     // the k-way merge: heads compared as (kth + 1, video_id, count, rank) - the order of the top-k kernels, made
-    // unique inside a group by the rank
+    // unique inside a group by the rank.  Two 64-bit words per head and bitwise logic on the comparisons: the
+    // short-circuit form compiled to a ladder of branches per butterfly step (and a lambda that captured the head
+    // by reference put it in scratch memory: two scratch loads per output row).
     int p = 0;
-    uint32_t hi, lo, wc;
-    auto head = [&]() {
-        if (live && p < k && mine[3 * p] >= 0) {
-            hi = (uint32_t)mine[3 * p + 2] + 1u;
-            lo = (uint32_t)mine[3 * p];
-            wc = (uint32_t)mine[3 * p + 1];
-        } else {
-            hi = lo = wc = 0xffffffffu;                    // exhausted (or padding: the rest of a sorted list is padding too)
-        }
-    };
-    head();
+    unsigned long long ha, hb;                                 // (kth + 1) << 32 | video_id ; count << 32 | rank
+#define TVZ_MS_HEAD() do { \
+        const int pp = p < k ? p : k - 1; \
+        const int32_t v0 = mine[3 * pp], v1 = mine[3 * pp + 1], v2 = mine[3 * pp + 2]; \
+        const bool ok = live & (p < k) & (v0 >= 0);            /* exhausted, or padding: the rest of a sorted list is padding too */ \
+        ha = ok ? ((unsigned long long)((uint32_t)v2 + 1u) << 32) | (uint32_t)v0 : ~0ULL; \
+        hb = ok ? ((unsigned long long)(uint32_t)v1 << 32) | (uint32_t)r : ~0ULL; \
+    } while (0)
+    TVZ_MS_HEAD();
     for (int t = 0; t < k; ++t) {
-        uint32_t mh = hi, ml = lo, mc = wc, mr = (uint32_t)r;
-#define TVZ_MS_MIN(C) { const uint32_t oh = dpp16<C>(mh), ol = dpp16<C>(ml), oc = dpp16<C>(mc), orr = dpp16<C>(mr); \
-                        if (oh < mh || (oh == mh && (ol < ml || (ol == ml && (oc < mc || (oc == mc && orr < mr)))))) \
-                            { mh = oh; ml = ol; mc = oc; mr = orr; } }
+        unsigned long long ma = ha, mb = hb;
+#define TVZ_MS_MIN(C) { const unsigned long long oa = dpp16_64<C>(ma), ob = dpp16_64<C>(mb); \
+                        const bool lt = (oa < ma) | ((oa == ma) & (ob < mb)); \
+                        ma = lt ? oa : ma; mb = lt ? ob : mb; }
         if (G >= 2) TVZ_MS_MIN(0xB1)
         if (G >= 4) TVZ_MS_MIN(0x4E)
         if (G >= 8) TVZ_MS_MIN(0x141)
@@ -1668,15 +1677,16 @@ __global__ __launch_bounds__(64) void ts_topk_merge_sorted_kernel(const int32_t 
 #undef TVZ_MS_MIN
         if (q < Q) {
             int32_t *o = topk + ((int64_t)q * k + t) * 3;
-            if (mh == 0xffffffffu) {                       // every list is exhausted: padding from here on
+            if (ma == ~0ULL) {                                 // every list is exhausted: padding from here on
                 if (r == 0) { o[0] = -1; o[1] = 0; o[2] = TVZ_KTH_NEVER; }
-            } else if (mr == (uint32_t)r) {                // this lane's head is the smallest
-                o[0] = (int32_t)ml; o[1] = (int32_t)mc; o[2] = (int32_t)(mh - 1u);
+            } else if ((uint32_t)mb == (uint32_t)r) {          // this lane's head is the smallest
+                o[0] = (int32_t)(uint32_t)ma; o[1] = (int32_t)(mb >> 32); o[2] = (int32_t)((uint32_t)(ma >> 32) - 1u);
                 ++p;
-                head();
+                TVZ_MS_HEAD();
             }
         }
     }
+#undef TVZ_MS_HEAD
 }
 
 // ---- small helpers launched around the sweeps ------------------------------------------------
