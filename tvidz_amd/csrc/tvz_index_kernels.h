@@ -879,7 +879,11 @@ __device__ __forceinline__ void ix_lookup_body(
                 }
                 uint32_t r[N];
 #pragma unroll
+#ifdef TVZ_IX_FAKEPOST      // diagnostic build only (WRONG results): no posting line is fetched, the row is made up from the address
+                for (int u = 0; u < N; ++u) r[u] = ((e[u].x + (uint32_t)(u * 64 + lane)) * 2654435761u) >> (32 - kSubLog2);
+#else
                 for (int u = 0; u < N; ++u) r[u] = post[e[u].x + (uint32_t)(u * 64 + lane)];
+#endif
 #pragma unroll
                 for (int u = 0; u < N; ++u) lbits[2 * u + (lane & 1)] = 0;      // done with: ready for the next sub-index
 #pragma unroll
