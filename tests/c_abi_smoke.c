@@ -138,6 +138,64 @@ int main(void) {
         hipFree(d_q); hipFree(d_off); hipFree(d_out); hipFree(d_mws);
         CHECK(tvz_corpus_destroy(c2));
     }
+    /* the sharded forms: two shard handles of one process (tvz_match_topk_shards), and the one-process-per-GPU
+     * path with a ONE-rank communicator (tvz_comm_* + tvz_match_sharded: lookup -> ncclAllGather -> merge) -
+     * RCCL driven from plain C, no Python or torch in the process */
+    {
+        int32_t ids_a[2] = {1, 2}, ids_b[2] = {3, 4}, ids_all[4] = {1, 2, 3, 4};
+        int64_t offs2[3] = {0, 5, 10}, offs4[5] = {0, 5, 10, 15, 20};
+        double keys_all[20] = {1.0, 2.0, 3.0, 4.0, 5.0,   10.0, 20.0, 30.0, 40.0, 50.0,
+                               10.0, 20.0, 31.0, 41.0, 51.0,   50.0, 60.0, 70.0, 80.0, 10.0};
+        tvz_corpus *sh[2] = {NULL, NULL}, *all = NULL;
+        CHECK(tvz_corpus_create(&sh[0], 0)); CHECK(tvz_corpus_create(&sh[1], 0)); CHECK(tvz_corpus_create(&all, 0));
+        CHECK(tvz_corpus_upload(sh[0], ids_a, offs2, keys_all, 2, 10));
+        CHECK(tvz_corpus_upload(sh[1], ids_b, offs2, keys_all + 10, 2, 10));
+        CHECK(tvz_corpus_upload(all, ids_all, offs4, keys_all, 4, 20));
+        enum { K = 2, CAP = 8 };
+        double *d_q; int64_t *d_off; int32_t *d_blocks, *d_topk, *d_tot; void *d_mws;
+        int64_t qoff[2] = {0, 5};
+        size_t mws = tvz_match_workspace_bytes(1, 5, CAP, K, 1);
+        HIPCHECK(hipMalloc((void **)&d_q, 5 * 8)); HIPCHECK(hipMalloc((void **)&d_off, 16));
+        HIPCHECK(hipMalloc((void **)&d_blocks, 2 * (K + 1) * 3 * 4)); HIPCHECK(hipMalloc((void **)&d_topk, K * 3 * 4));
+        HIPCHECK(hipMalloc((void **)&d_tot, 4)); HIPCHECK(hipMalloc(&d_mws, mws));
+        HIPCHECK(hipMemcpy(d_q, q1, 5 * 8, hipMemcpyHostToDevice));
+        HIPCHECK(hipMemcpy(d_off, qoff, 16, hipMemcpyHostToDevice));
+        /* q1 = {10,20,30,40,50}, min_match 2: video 2 (5 cuts, 2nd at position 1), video 3 (10 and 20: position 1),
+         * video 4 (10 and 50: position 4); the two best by (kth, video_id) are 2 and 3, three hits in all */
+        CHECK(tvz_match_topk_shards(sh, 2, d_q, d_off, 1, 5, 2, NULL, CAP, K, d_blocks, d_topk, d_tot, d_mws, mws,
+                                    TVZ_ALGO_AUTO, NULL));
+        HIPCHECK(hipDeviceSynchronize());
+        int32_t blocks[2 * (K + 1) * 3], top[K * 3], tot;
+        HIPCHECK(hipMemcpy(blocks, d_blocks, sizeof blocks, hipMemcpyDeviceToHost));
+        HIPCHECK(hipMemcpy(top, d_topk, sizeof top, hipMemcpyDeviceToHost));
+        HIPCHECK(hipMemcpy(&tot, d_tot, 4, hipMemcpyDeviceToHost));
+        EXPECT(blocks[0] == 2 && blocks[1] == 5 && blocks[2] == 1 && blocks[3] == -1 && blocks[7] == 1);      /* shard A */
+        EXPECT(blocks[9] == 3 && blocks[10] == 2 && blocks[11] == 1 && blocks[12] == 4 && blocks[13] == 2 && blocks[14] == 4
+               && blocks[16] == 2);                                                                             /* shard B */
+        EXPECT(top[0] == 2 && top[1] == 5 && top[2] == 1 && top[3] == 3 && top[4] == 2 && top[5] == 1 && tot == 3);
+        unsigned char uid[TVZ_UNIQUE_ID_BYTES];
+        tvz_comm *comm = NULL;
+        int rc = tvz_comm_unique_id(uid);
+        if (rc == 0) rc = tvz_comm_init(&comm, uid, 1, 0, 0);
+        if (rc == TVZ_ERR_COMM) {
+            printf("note: no usable librccl.so for a plain C process here (%s): tvz_match_sharded not exercised\n", tvz_last_error());
+        } else {
+            CHECK(rc);
+            int32_t nr_ = 0, rk_ = -1;
+            CHECK(tvz_comm_info(comm, &nr_, &rk_));
+            EXPECT(nr_ == 1 && rk_ == 0);
+            HIPCHECK(hipMemset(d_topk, 0xff, K * 3 * 4)); HIPCHECK(hipMemset(d_tot, 0xff, 4));
+            CHECK(tvz_match_sharded(all, comm, d_q, d_off, 1, 5, 2, NULL, CAP, K, d_topk, d_tot, d_mws, mws, TVZ_ALGO_AUTO, NULL));
+            HIPCHECK(hipDeviceSynchronize());
+            HIPCHECK(hipMemcpy(top, d_topk, sizeof top, hipMemcpyDeviceToHost));
+            HIPCHECK(hipMemcpy(&tot, d_tot, 4, hipMemcpyDeviceToHost));
+            EXPECT(top[0] == 2 && top[1] == 5 && top[2] == 1 && top[3] == 3 && top[4] == 2 && top[5] == 1 && tot == 3);
+            CHECK(tvz_comm_destroy(comm));
+            printf("tvz_match_sharded through a one-rank RCCL communicator OK\n");
+        }
+        hipFree(d_q); hipFree(d_off); hipFree(d_blocks); hipFree(d_topk); hipFree(d_tot); hipFree(d_mws);
+        CHECK(tvz_corpus_destroy(sh[0])); CHECK(tvz_corpus_destroy(sh[1])); CHECK(tvz_corpus_destroy(all));
+    }
     hipFree(d_cuts); hipFree(d_state);
     hipFree(d_luma); hipFree(d_sad); hipFree(d_mafd); hipFree(d_score); hipFree(d_sel); hipFree(d_ws);
     printf("c_abi_smoke OK\n");
