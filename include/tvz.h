@@ -217,6 +217,13 @@ int tvz_corpus_index_stats(tvz_corpus *c, int64_t *n_indexed_rows, int64_t *n_de
 #define TVZ_ALGO_TILE 2
 #define TVZ_ALGO_JOIN 3
 #define TVZ_ALGO_INDEX 4
+/* Shape of the lookup that keeps the top-k (tvz_match_topk, tvz_match_topk_shards, tvz_match_sharded), OR-ed into
+ * `algo`.  By default a block takes TWO queries - their directory probes share one probe phase - when the batch
+ * still fills the chip with half as many blocks (Q >= 2048) and the LDS of both fits four blocks per CU (queries of
+ * up to ~380 timestamps on a handle of one or two sub-indexes, ~150 at seven); _PAIR asks for it at any batch size
+ * (where the LDS allows), _NO_PAIR never.  Same results either way. */
+#define TVZ_ALGO_PAIR 0x100
+#define TVZ_ALGO_NO_PAIR 0x200
 
 /* Scratch for the batched calls below.  k = 0 for tvz_match (tables of the hash join only);
  * k > 0 adds the hit lists + per-shard top-k block of tvz_match_topk / tvz_match_sharded

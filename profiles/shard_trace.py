@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """The sharded match pipeline of ONE rank's 1/N shard under a kernel trace: which kernels a batch is
-made of and how the two alternating streams overlap.   python profiles/shard_trace.py [N] [Q] [steps] [streams] [nowait|-] [depth]
+made of and how the two alternating streams overlap.   python profiles/shard_trace.py [N] [Q] [steps] [streams] [nowait|-] [depth] [algo flags]
 (run under rocprofv3 --kernel-trace; profiles/shard_timeline.py reads the trace).  depth = batches in flight
 (default 2: submit the next, then finish the previous)."""
 import os
@@ -27,7 +27,8 @@ comm = sharded.make_comm(0)
 s_ids, s_offs, s_keys = sharded.shard_csr(ids, offs, keys, 0, N)
 dc = tc.DeviceCorpus(0)
 dc.upload_csr(s_ids, s_offs, s_keys)
-sm = sharded.RcclShardedMatcher(dc, comm, k=16, cap=16384, n_streams=N_STREAMS)
+ALGO = int(sys.argv[7], 0) if len(sys.argv) > 7 else 0     # 0x100: two queries per block at any batch size, 0x200: never
+sm = sharded.RcclShardedMatcher(dc, comm, k=16, cap=16384, n_streams=N_STREAMS, algo=ALGO)
 for _ in range(3):
     sm.match_topk(d_q, d_off, max_len, 2)
 torch.cuda.synchronize()

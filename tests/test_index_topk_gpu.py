@@ -37,9 +37,12 @@ def _check_topk(dc, exp_rows, queries, mm, k, cap, excl=None, algo=_lib.ALGO_AUT
     Q = len(queries)
     d_ex = torch.tensor(excl, dtype=torch.int32, device=DEV) if excl is not None else None
     ws = torch.empty(tc.workspace_bytes(Q, max_len, cap, k), dtype=torch.uint8, device=DEV)
-    out = dc.match_topk(d_q, d_off, max_len, mm, cap, k, d_exclude_ids=d_ex, workspace=ws, algo=algo)
+    # both shapes of the fused lookup - two queries per block (their probes share one phase) and one - must agree
+    out = dc.match_topk(d_q, d_off, max_len, mm, cap, k, d_exclude_ids=d_ex, workspace=ws, algo=algo | _lib.ALGO_PAIR)
     torch.cuda.synchronize()
     out = out.cpu().numpy()
+    one = dc.match_topk(d_q, d_off, max_len, mm, cap, k, d_exclude_ids=d_ex, workspace=ws, algo=algo | _lib.ALGO_NO_PAIR)
+    assert (one.cpu().numpy() == out).all()
     for qi in range(Q):
         rows = exp_rows[qi]
         assert tuple(out[qi, k][[0, 2]]) == (-1, NEVER)
@@ -184,3 +187,49 @@ def test_sharded_call_uses_the_fused_lookup_and_matches_the_oracle(dc):
         want += [(-1, 0, NEVER)] * (k - len(want))
         assert [tuple(int(x) for x in r) for r in merged[qi]] == want
         assert int(totals[qi]) == len(exp[qi])
+
+
+def test_two_queries_per_block_refusals_odd_batches_and_neighbours(dc):
+    """The lookup takes two queries per block when the LDS of both fits (their directory probes share the
+    block's one probe phase).  What must not leak between the two: a query LONGER than the stated
+    max_query_len is refused on its own (padding rows + total INT32_MIN: the contract of every batched
+    kernel) whichever side of a pair it sits on, its neighbour is answered; an odd batch's last block
+    holds one query; Q = 1 takes the one-query form; queries of very different lengths, empty ones and
+    heavy ties sit next to each other; the second query's top-k list and histogram start clean."""
+    C = 2500
+    ids, offs, keys = synth.synth_timestamp_corpus(C, seed=77, mean_len=60, dup_frac=0.06, frag_frac=0.05)
+    rows = [(int(ids[r]), keys[offs[r]:offs[r + 1]].tolist()) for r in range(C)]
+    # forty true copies of one row: ~40 hits tied at one kth for the queries that hold its keys
+    copy_of = rows[5][1]
+    rows += [(90000 + i, list(copy_of)) for i in range(40)]
+    dc.upload(rows)
+    base = synth.synth_queries(ids, offs, keys, 9, seed=5, mean_len=60)
+    long_q = np.concatenate([np.asarray(copy_of, dtype=np.float64), 1e7 + np.arange(400, dtype=np.float64)])
+    queries = [base[0], long_q, long_q, base[1], np.zeros(0), np.asarray(copy_of, dtype=np.float64),
+               np.asarray(copy_of[:3], dtype=np.float64), base[2], base[3]]           # 9 queries: odd
+    honest = max(len(q) for q in queries)
+    lying = 200                                                  # queries 1 and 2 (len > 400) exceed it
+    for mm in (1, 2, 4):
+        exp = _expected_rows(rows, queries, mm)
+        for k in (4, 16):
+            d_q, d_off, _ = tc.pack_queries(queries, DEV)
+            for bound in (honest, lying):
+                ws = torch.empty(tc.workspace_bytes(len(queries), bound, 4096, k), dtype=torch.uint8, device=DEV)
+                out = dc.match_topk(d_q, d_off, bound, mm, 4096, k, workspace=ws, algo=_lib.ALGO_PAIR).cpu().numpy()
+                for qi, q in enumerate(queries):
+                    want = sorted(exp[qi], key=lambda h: (h[2], h[0], h[1]))[:k]
+                    want += [(-1, 0, NEVER)] * (k - len(want))
+                    got = [tuple(int(x) for x in r) for r in out[qi, :k]]
+                    if len(q) > bound:
+                        assert int(out[qi, k, 1]) == np.iinfo(np.int32).min and all(r == (-1, 0, NEVER) for r in got), (mm, k, qi)
+                    else:
+                        assert int(out[qi, k, 1]) == len(exp[qi]) and got == want, (mm, k, bound, qi)
+            # the short queries alone (their bound leaves room for two per block), against the oracle
+            short = [q for q in queries if len(q) <= lying]
+            _check_topk(dc, [e for e, q in zip(exp, queries) if len(q) <= lying], short, mm, k, 4096)
+            # every prefix of the batch: Q = 1 (one query per block), even and odd batches
+            for Qn in (1, 2, 3, 6):
+                d_q1, d_off1, ml1 = tc.pack_queries(queries[:Qn], DEV)
+                out1 = dc.match_topk(d_q1, d_off1, ml1, mm, 4096, k, algo=_lib.ALGO_PAIR).cpu().numpy()
+                full = dc.match_topk(d_q, d_off, honest, mm, 4096, k, algo=_lib.ALGO_NO_PAIR).cpu().numpy()
+                assert (out1 == full[:Qn]).all(), (mm, k, Qn)

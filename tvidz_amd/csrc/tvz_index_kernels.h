@@ -691,15 +691,20 @@ __device__ __forceinline__ unsigned long long ix_tk_pack(int32_t kth, int32_t vi
     return ((unsigned long long)(uint32_t)kth << 44) | ((unsigned long long)(uint32_t)vid << 12) | cnt;
 }
 
-template <bool HOSTOUT, int MODE, bool TOPK>
+// NQ (TOPK only): queries per block.  With NQ = 2 block b takes queries 2 b and 2 b + 1: BOTH are probed in the one
+// probe phase at the start (a query of ~200 timestamps occupies 200 of the block's 512 threads there, and the phase is
+// two dependent round trips - keys, directory entries - during which the block does nothing else: a third of a
+// block's time on a 1/8 shard), then walked one after the other.  `q` = the block's first query, `Q` = queries in the batch.
+template <bool HOSTOUT, int MODE, bool TOPK, int NQ = 1>
 __device__ __forceinline__ void ix_lookup_body(
     const unsigned char *__restrict__ dir, int dir_bits, int ks, const uint16_t *__restrict__ post,
     const int32_t *__restrict__ ivid, int64_t n_indexed, int32_t n_sub, int32_t spb,
     const double *__restrict__ queries, const int64_t *__restrict__ q_offsets, int32_t max_len,
     int32_t min_match, const int32_t *__restrict__ exclude_ids, int32_t exclude_one, int32_t cap,
-    int32_t *__restrict__ hits, int32_t *__restrict__ hits_n, int32_t ns, const QByVal *qv, const int q,
-    const int group, const int n_groups, const int32_t tk_k = 0) {
+    int32_t *__restrict__ hits, int32_t *__restrict__ hits_n, int32_t ns, const QByVal *qv, const int q_first,
+    const int group, const int n_groups, const int32_t tk_k = 0, const int32_t Q = 0) {
     static_assert(!(TOPK && (HOSTOUT || MODE == kIxCount)), "the fused top-k needs kth in the block and a device list");
+    static_assert(NQ == 1 || (NQ == 2 && TOPK), "two queries per block: the top-k form only");
     constexpr bool TOP5 = MODE == kIxTop5;
     const int dir_log2 = dir_bits & 0xff;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -709,16 +714,16 @@ __device__ __forceinline__ void ix_lookup_body(
     unsigned long long *ttop = reinterpret_cast<unsigned long long *>(tcnt + kIxSlots);
     uint32_t *m1 = reinterpret_cast<uint32_t *>(ttop), *m2 = m1 + kIxSlots;   // kIxM2: the same 8 B per slot
     uint32_t *pcache_all = reinterpret_cast<uint32_t *>(ttop + kIxSlots);  // cached postings: row | position << kSubLog2
-    const int L = max_len > 0 ? max_len : 1;
+    const int L = NQ * (max_len > 0 ? max_len : 1);        // positions of all of the block's queries
     uint2 *lst_all = reinterpret_cast<uint2 *>(pcache_all + kIxCache);  // per wave: non-empty list j = {first posting - local start, position}
     uint32_t *lbits_all = reinterpret_cast<uint32_t *>(lst_all + kIxWaves * 64);   // per wave: bit t = a list starts at local posting t
     unsigned long long *tkb = reinterpret_cast<unsigned long long *>(lbits_all + kIxWaves * kIxLW);   // TOPK: kept hits
     uint32_t *kh = reinterpret_cast<uint32_t *>(tkb + kIxTkCap);        // TOPK: hits per kth bin, all sub-indexes so far
     uint32_t *tk_n = kh + kIxTkBins;                                    // TOPK: entries in tkb (+ one pad word)
-    uint32_t *e_cur = TOPK ? tk_n + 2 : reinterpret_cast<uint32_t *>(tkb);   // [L] first posting of position i in the CURRENT sub-index
-    uint16_t *elist = reinterpret_cast<uint16_t *>(e_cur + L + 1);      // row (in the sub-index) of slot k
+    uint32_t *e_cur_all = TOPK ? tk_n + 2 : reinterpret_cast<uint32_t *>(tkb);   // [L] first posting of position i in the CURRENT sub-index
+    uint16_t *elist = reinterpret_cast<uint16_t *>(e_cur_all + L + 1);  // row (in the sub-index) of slot k
     uint16_t *rank = elist + kIxSlots;                                  // candidates before bitmap word j
-    uint16_t *e_len = rank + kIxWords;                                  // [L][nsb] postings of position i per sub-index
+    uint16_t *e_len_all = rank + kIxWords;                              // [L][nsb] postings of position i per sub-index
     __shared__ uint32_t s_wb[kIxWaves], s_wc[kIxWaves];
     __shared__ uint32_t s_bcast;
     __shared__ uint32_t s_tk[TOPK ? kIxWaves : 1];
@@ -729,21 +734,35 @@ __device__ __forceinline__ void ix_lookup_body(
     const int nsb = (spb + 1) & ~1;
     const bool alone = n_groups == 1;                  // this block owns the query's hit list
     const bool byval = !TOPK && q_offsets == nullptr;      // (the query travels in the kernel arguments)
-    const int64_t qo = byval ? 0 : q_offsets[q];
-    const int64_t n64 = byval ? qv->n : q_offsets[q + 1] - qo;
-    if (n64 > max_len) {       // max_query_len was not an upper bound (the LDS arrays are sized from it)
-        if (TOPK) {            // what the top-k kernels make of a refused query: padding + the poisoned total
-            int32_t *o = hits + (int64_t)q * (tk_k + 1) * 3;
-            for (int i = threadIdx.x; i <= tk_k; i += kIxBlock) {
-                o[i * 3 + 0] = -1;
-                o[i * 3 + 1] = i == tk_k ? INT32_MIN : 0;
-                o[i * 3 + 2] = TVZ_KTH_NEVER;
-            }
-        } else if (HOSTOUT) { for (int s = sub_lo + threadIdx.x; s < sub_hi; s += kIxBlock) hits_n[s] = INT32_MIN; }
-        else if (threadIdx.x == 0) hits_n[(size_t)q * ns] = INT32_MIN;
-        return;
+    int64_t qo_[NQ];
+    int n_[NQ];
+    bool skip_[NQ];                                        // refused (too long), or past the end of the batch
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) {
+        const int q = q_first + j;
+        skip_[j] = NQ > 1 && q >= Q;
+        qo_[j] = 0;
+        n_[j] = 0;
+        if (skip_[j]) continue;
+        qo_[j] = byval ? 0 : q_offsets[q];
+        const int64_t n64 = byval ? qv->n : q_offsets[q + 1] - qo_[j];
+        if (n64 > max_len) {   // max_query_len was not an upper bound (the LDS arrays are sized from it)
+            if (TOPK) {        // what the top-k kernels make of a refused query: padding + the poisoned total
+                int32_t *o = hits + (int64_t)q * (tk_k + 1) * 3;
+                for (int i = threadIdx.x; i <= tk_k; i += kIxBlock) {
+                    o[i * 3 + 0] = -1;
+                    o[i * 3 + 1] = i == tk_k ? INT32_MIN : 0;
+                    o[i * 3 + 2] = TVZ_KTH_NEVER;
+                }
+            } else if (HOSTOUT) { for (int s = sub_lo + threadIdx.x; s < sub_hi; s += kIxBlock) hits_n[s] = INT32_MIN; }
+            else if (threadIdx.x == 0) hits_n[(size_t)q * ns] = INT32_MIN;
+            skip_[j] = true;
+            if (NQ == 1) return;
+            continue;
+        }
+        n_[j] = (int)n64;
     }
-    const int n = (int)n64;
+    const int n_all = NQ == 1 ? n_[0] : n_[0] + n_[NQ - 1];
 #ifdef TVZ_IX_STAMP
     unsigned long long st_acc[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long st_last = __builtin_amdgcn_s_memtime();
@@ -769,11 +788,13 @@ __device__ __forceinline__ void ix_lookup_body(
     // ---- directory: ONE probe per query position; the counts of this block's sub-indexes to LDS ----
     const uint32_t smask = (1u << (dir_bits >> 8)) - 1u;   // probes wrap inside the directory slice
     const int es = 16 + 2 * ks;
-    for (int i = threadIdx.x; i < n; i += kIxBlock) {
+    for (int i = threadIdx.x; i < n_all; i += kIxBlock) {
         uint32_t base = 0, total = 0;
         const unsigned char *ent = nullptr;
         int64_t k;
-        if (canon_key(byval ? qv->k[i] : queries[qo + i], k)) {           // NaN never matches
+        // (position i of the block = position i of its first query, or i - n_[0] of its second)
+        const int64_t kq = NQ == 1 || i < n_[0] ? qo_[0] + i : qo_[NQ - 1] + (i - n_[0]);
+        if (canon_key(byval ? qv->k[i] : queries[kq], k)) {               // NaN never matches
             uint32_t s = ix_slot(k, dir_log2);
             for (int probes = 0; probes < kIxMaxProbe; ++probes) {
                 const unsigned char *e = dir + (size_t)s * es;
@@ -784,7 +805,7 @@ __device__ __forceinline__ void ix_lookup_body(
                 s = (s & ~smask) | ((s + 1) & smask);
             }
         }
-        uint16_t *el = e_len + (size_t)i * nsb;
+        uint16_t *el = e_len_all + (size_t)i * nsb;
         if (ks == 0) {                                                   // one sub-index: the total is its count
             el[0] = (uint16_t)total;
             el[1] = 0;
@@ -805,7 +826,7 @@ __device__ __forceinline__ void ix_lookup_body(
                 }
             }
         }
-        e_cur[i] = base;
+        e_cur_all[i] = base;
     }
     __syncthreads();
     TVZ_STAMP(0);
@@ -813,6 +834,21 @@ __device__ __forceinline__ void ix_lookup_body(
     return;
 #endif
 
+#pragma unroll 1
+    for (int qj = 0; qj < NQ; ++qj) {                      // the block's queries, one after the other
+    if (skip_[qj]) continue;                               // (block-uniform)
+    const int q = q_first + qj;
+    const int n = n_[qj];
+    uint32_t *e_cur = e_cur_all + (qj ? n_[0] : 0);
+    uint16_t *e_len = e_len_all + (size_t)(qj ? n_[0] : 0) * nsb;
+    if (NQ > 1 && qj) {
+        // the first query's epilogue has read the kept hits: start the second one's list and histogram
+        __syncthreads();
+        for (int i = threadIdx.x; i < kIxTkBins + 2; i += kIxBlock) kh[i] = 0;
+        tk_cut = ~0ull;
+        tk_bmax = 0xffffffffu;
+        __syncthreads();
+    }
     const int32_t excl = exclude_ids ? exclude_ids[q] : exclude_one;
     const int n_chunks = (n + kIxBlock - 1) / kIxBlock;    // query positions come in chunks of one per thread
     uint32_t emitted = 0;                                  // hits so far (identical in every thread)
@@ -1278,6 +1314,7 @@ __device__ __forceinline__ void ix_lookup_body(
         }
         TVZ_STAMP(10);
     } else if (!HOSTOUT && alone && threadIdx.x == 0) hits_n[(size_t)q * ns] = (int32_t)emitted;
+    }                                                      // (the block's next query)
 #ifdef TVZ_IX_STAMP
     if (threadIdx.x == 0) {
         for (int i = 0; i < 11; ++i) atomicAdd(&g_ix_stamps[i], st_acc[i]);
@@ -1300,16 +1337,17 @@ __global__ __launch_bounds__(kIxBlock) __attribute__((amdgpu_waves_per_eu(8, 8))
 
 // the lookup with the per-shard top-k in its epilogue: grid = (Q), one block per query over ALL
 // sub-indexes; topk = [Q][k + 1][3] (k best + totals row), no hit list, no counters
-template <int MODE>
+// NQ = 2: grid = (ceil(Q / 2)), a block takes two queries (probed together, walked in turn)
+template <int MODE, int NQ>
 __global__ __launch_bounds__(kIxBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) void ts_match_index_topk_kernel(
     const unsigned char *__restrict__ dir, int dir_bits, int ks, const uint16_t *__restrict__ post,
     const int32_t *__restrict__ ivid, int64_t n_indexed, int32_t n_sub,
-    const double *__restrict__ queries, const int64_t *__restrict__ q_offsets, int32_t max_len,
+    const double *__restrict__ queries, const int64_t *__restrict__ q_offsets, int32_t Q, int32_t max_len,
     int32_t min_match, const int32_t *__restrict__ exclude_ids, int32_t cap, int32_t k,
     int32_t *__restrict__ topk) {
-    ix_lookup_body<false, MODE, true>(dir, dir_bits, ks, post, ivid, n_indexed, n_sub, n_sub, queries, q_offsets,
-                                      max_len, min_match, exclude_ids, -1, cap, topk, nullptr, 1, nullptr,
-                                      (int)blockIdx.x, 0, 1, k);
+    ix_lookup_body<false, MODE, true, NQ>(dir, dir_bits, ks, post, ivid, n_indexed, n_sub, n_sub, queries, q_offsets,
+                                          max_len, min_match, exclude_ids, -1, cap, topk, nullptr, 1, nullptr,
+                                          (int)blockIdx.x * NQ, 0, 1, k, Q);
 }
 
 // tvz_find_duplicates on an indexed corpus with rows in the delta table - the streaming driver's call:

@@ -82,6 +82,7 @@ struct RingSlot {
 // the DELTA table: the current entry of every row that was added or replaced since.  A match with
 // the index = index lookup (rows that are unchanged since the build) + a sweep of the delta table.
 constexpr int kLdsPerWorkgroup = 160 * 1024;        // gfx950
+constexpr int kIxResidentBlocks = 256 * 4;          // lookup blocks (512 threads, <= 40 KiB of LDS) resident on an MI355X
 constexpr int kQ1StaticLds = kQ1Stage * 12 + 64;    // ts_match_q1_kernel: per-block hit staging + a few words (3,088 B in the code object)
 constexpr int kIxMaxLds = 159 * 1024;               // gfx950: 160 KiB of LDS per workgroup, less the static part
 constexpr int64_t kIxSliceBytes = 32 * 1024;        // a directory slice, built by one block in LDS
@@ -1034,14 +1035,25 @@ bool index_topk_usable(const tvz_corpus *c, int32_t Q, int32_t max_query_len, in
 // faster on a 1/8 shard, the probe pass cost 27 us: profiles/r4_probe_prepass.txt.)
 int launch_index_topk(tvz_corpus *c, const double *d_queries, const int64_t *d_q_offsets, int32_t Q,
                       int32_t max_query_len, int32_t min_match, const int32_t *d_exclude_ids, int32_t cap,
-                      int32_t k, int32_t *d_block, hipStream_t st) {
+                      int32_t k, int32_t *d_block, int32_t flags, hipStream_t st) {
     const IndexBuf &ix = c->ix.now();
-    const size_t lds = ix_lds_bytes(max_query_len, ix.n_sub, true);
-#define TVZ_IXK(MODE)                                                                                       \
-    hipLaunchKernelGGL((ts_match_index_topk_kernel<MODE>), dim3((unsigned)Q), dim3(kIxBlock), lds, st,        \
+    // Two queries per block - their directory probes share the block's one probe phase (profiles/r4_pair.txt) -
+    // when the LDS of both still leaves four blocks on a CU, and when half as many blocks still fill the chip
+    // (256 CUs x 4 blocks: below that a batch is one round of blocks, and blocks twice as long would only make it
+    // twice as long).
+    const int one = max_query_len > 0 ? max_query_len : 1;
+    const size_t lds2 = ix_lds_bytes(2 * one, ix.n_sub, true);
+    const bool no_pair = (flags & TVZ_ALGO_NO_PAIR) != 0, force_pair = (flags & TVZ_ALGO_PAIR) != 0;   // per call, like the algorithm
+    const bool pair = Q >= 2 && (Q >= 2 * kIxResidentBlocks || force_pair) &&
+                      lds2 + 256 <= (size_t)kLdsPerWorkgroup / 4 && !no_pair;   // (+ the body's static LDS)
+    const size_t lds = pair ? lds2 : ix_lds_bytes(max_query_len, ix.n_sub, true);
+    const unsigned grid = pair ? (unsigned)((Q + 1) / 2) : (unsigned)Q;
+#define TVZ_IXK(MODE, NQ)                                                                                   \
+    hipLaunchKernelGGL((ts_match_index_topk_kernel<MODE, NQ>), dim3(grid), dim3(kIxBlock), lds, st,           \
                        ix.dir.p, ix.dir_bits(), ix.ks, ix.post.p, ix.ivid.p, ix.n_main, ix.n_sub, d_queries,   \
-                       d_q_offsets, max_query_len, min_match, d_exclude_ids, cap, k, d_block)
-    if (min_match <= 2) TVZ_IXK(kIxM2); else TVZ_IXK(kIxTop5);
+                       d_q_offsets, Q, max_query_len, min_match, d_exclude_ids, cap, k, d_block)
+    if (pair) { if (min_match <= 2) TVZ_IXK(kIxM2, 2); else TVZ_IXK(kIxTop5, 2); }
+    else { if (min_match <= 2) TVZ_IXK(kIxM2, 1); else TVZ_IXK(kIxTop5, 1); }
 #undef TVZ_IXK
     TVZ_HIP(hipGetLastError());
     return TVZ_OK;
@@ -1273,6 +1285,8 @@ int tvz_match_topk_local(tvz_corpus *c, const double *d_queries, const int64_t *
                          void *hip_stream, int32_t **gathered_out) {
     if (int rc = check_batch_args(c, d_queries, d_q_offsets, Q, max_query_len, cap)) return rc;
     TVZ_REQUIRE(k >= 1 && k <= kSortCap / 2, "k=%d out of range [1, %d]", k, kSortCap / 2);
+    const int32_t flags = algo & (TVZ_ALGO_PAIR | TVZ_ALGO_NO_PAIR);      // shape of the fused lookup (tvz.h)
+    algo &= ~(TVZ_ALGO_PAIR | TVZ_ALGO_NO_PAIR);
     if (Q == 0) return TVZ_OK;
     TVZ_REQUIRE(d_workspace != nullptr, "d_workspace is NULL");
     const WsLayout w = ws_layout(d_workspace, Q, max_query_len, cap, k, n_ranks);
@@ -1290,7 +1304,7 @@ int tvz_match_topk_local(tvz_corpus *c, const double *d_queries, const int64_t *
         const int64_t n_delta = c->ix.n_delta;
         int32_t *blk = n_delta ? w.pair : d_out;
         if (int rc = launch_index_topk(c, d_queries, d_q_offsets, Q, max_query_len, min_match, d_exclude_ids, cap, k,
-                                       blk, st))
+                                       blk, flags, st))
             return rc;
         if (n_delta) {
             const RowSpan span{c->ix.now().drows.p, n_delta};
@@ -1368,10 +1382,11 @@ static int tvz_corpus_create_impl(tvz_corpus **out, int device) {
     TVZ_IX_ATTR(false, kIxM2); TVZ_IX_ATTR(false, kIxTop5); TVZ_IX_ATTR(false, kIxCount);
     TVZ_IX_ATTR(true, kIxM2); TVZ_IX_ATTR(true, kIxTop5);
 #undef TVZ_IX_ATTR
-    TVZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(ts_match_index_topk_kernel<kIxM2>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, kIxMaxLds));
-    TVZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(ts_match_index_topk_kernel<kIxTop5>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, kIxMaxLds));
+#define TVZ_IXK_ATTR(M, NQ)                                                                       \
+    TVZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(ts_match_index_topk_kernel<M, NQ>),    \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, kIxMaxLds))
+    TVZ_IXK_ATTR(kIxM2, 1); TVZ_IXK_ATTR(kIxTop5, 1); TVZ_IXK_ATTR(kIxM2, 2); TVZ_IXK_ATTR(kIxTop5, 2);
+#undef TVZ_IXK_ATTR
     TVZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(ix_slice_count_kernel),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)kIxSliceBytesMax));
     TVZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(ix_slice_fill_kernel),

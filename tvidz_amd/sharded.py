@@ -131,10 +131,12 @@ class RcclShardedMatcher:
     merge of batch i overlap the sweep of batch i+1; finish() makes the current stream wait for
     the ticket.  Same results as ShardedMatcher (which keeps the merge logic testable on gloo)."""
 
-    def __init__(self, corpus, comm, k: int = 64, cap: int = 1024, n_streams: int = 2, priority: int = 0):
+    def __init__(self, corpus, comm, k: int = 64, cap: int = 1024, n_streams: int = 2, priority: int = 0,
+                 algo: int = 0):
         """`priority=-1`: the service's ticks - a few tiny launches that should not queue behind the upload
         workers' scene kernels."""
         self.corpus, self.comm = corpus, comm
+        self.algo = int(algo)               # _lib.ALGO_* (+ ALGO_PAIR / ALGO_NO_PAIR) of every batch
         self.k = int(k)
         self.cap = max(int(cap), self.k)
         self.world, self.rank = comm.n_ranks, comm.rank
@@ -174,7 +176,7 @@ class RcclShardedMatcher:
             st.wait_stream(torch.cuda.current_stream(self.dev))   # the queries are complete before the match reads them
         merged, totals = self.comm.match_sharded(self.corpus, d_queries, d_q_offsets, max_query_len,
                                                  min_match, self.cap, self.k, d_exclude_ids,
-                                                 workspace=self.ws[i], stream=st, out=self.out[i])
+                                                 workspace=self.ws[i], stream=st, out=self.out[i], algo=self.algo)
         ev = self.events[i]
         ev.record(st)
         return (merged, totals, ev)
