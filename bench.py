@@ -333,7 +333,8 @@ def bench_match(args, rank, world, dev):
            "batches_in_flight": DEPTH,
            "batches_in_flight_calibration_ms": {str(d): round(v, 4) for d, v in calib.items()},
            "distinct_query_batches_rotating": NB,
-           "algo": "AUTO = inverted-index lookup, ONE block per query walking the query's sub-indexes of 16384 rows "
+           "algo": "AUTO = inverted-index lookup, one block per query (two queries per block, probed together, on shards of one or "
+                   "two sub-indexes) walking the query's sub-indexes of 16384 rows "
                    "and keeping the per-shard top-k in its epilogue (no hit lists, no top-k launch) + sweep of the "
                    "delta table (empty here); identical rows to the full sweep + top-k (tests/test_index_topk_gpu.py)",
            "index": ix,
