@@ -136,7 +136,12 @@ class RcclShardedMatcher:
         """`priority=-1`: the service's ticks - a few tiny launches that should not queue behind the upload
         workers' scene kernels."""
         self.corpus, self.comm = corpus, comm
+        from . import _lib
         self.algo = int(algo)               # _lib.ALGO_* (+ ALGO_PAIR / ALGO_NO_PAIR) of every batch
+        if not self.algo & (_lib.ALGO_PAIR | _lib.ALGO_NO_PAIR) and n_streams < 3:
+            # two queries per lookup block pay off when a THIRD batch's blocks fill the longer tail of a launch
+            # (42 against 46 us per batch on a 1/8 shard); with two batches in flight they cost (57 against 52)
+            self.algo |= _lib.ALGO_NO_PAIR
         self.k = int(k)
         self.cap = max(int(cap), self.k)
         self.world, self.rank = comm.n_ranks, comm.rank
