@@ -2,8 +2,11 @@
 """bench.py — headline benchmark of the tvidz inspector hot path on MI355X.
 
   python bench.py --gpus N --steps K --warmup W
-  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N
-          --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...)
+  N > 1 without a launcher around it: this process touches no GPU and starts N fresh rank
+  processes of itself (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 / MASTER_PORT in
+  their environment, exactly what `python -m torch.distributed.run --nnodes=1 --nproc-per-node N
+  --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...` gives them), relays rank 0's one
+  JSON line and exits with the worst return code of the ranks.  With WORLD_SIZE set it is a rank.
 
 Primary metric (BASELINE.json configs[1]): 1080p frames/s of scene-cut scoring.  A "step" is one
 pass of the scene path (luma SAD kernel + finalize/select kernel, through the C ABI) over a
@@ -25,6 +28,8 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import threading
 import time
@@ -45,7 +50,7 @@ H, W = 1080, 1920
 FRAME_BYTES = H * W
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
@@ -67,7 +72,17 @@ def parse():
                          "the one way to exercise that code path on a one-GPU box")
     ap.add_argument("--cpu-frames", type=int, default=1536)
     ap.add_argument("--cpu-threads", type=int, default=0)
-    return ap.parse_args()
+    ap.add_argument("--e2e-shapes", default="8x256,64x256",
+                    help="uploads x frames of the bounded driver runs; the first is the `e2e` object, the others go "
+                         "to e2e.other_shapes (configs[4] is 64 concurrent uploads)")
+    ap.add_argument("--force-launch", action="store_true",
+                    help="start the rank process(es) through the launcher at --gpus 1 too (the path --gpus N > 1 takes)")
+    ap.add_argument("--dry-launch", action="store_true", help="print the launcher's child command as JSON and exit")
+    ap.add_argument("--launch-stub", action="store_true",
+                    help="CPU self-test of the launcher: every rank joins a gloo group and all-reduces one number, rank 0 "
+                         "prints a stub line; a rank named by TVZ_BENCH_STUB_FAIL_RANK exits 7 (tests/test_bench_contract_cpu.py)")
+    ap.add_argument("--stub-hang-e2e", action="store_true", help=argparse.SUPPRESS)
+    return ap.parse_args(argv)
 
 
 def barrier_sync(world):
@@ -83,6 +98,14 @@ def max_over_ranks(x: float, world: int, dev) -> float:
     t = torch.tensor([x], dtype=torch.float64, device=dev)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+def sum_over_ranks(x: int, world: int, dev) -> int:
+    if not dist.is_initialized():
+        return int(x)
+    t = torch.tensor([int(x)], dtype=torch.int64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return int(t.item())
 
 
 def bench_scene(args, rank, world, dev):
@@ -209,6 +232,7 @@ def bench_match(args, rank, world, dev):
     # merge) at every N, a single process included (one-rank communicator); torch.distributed only
     # ships the 128-byte RCCL id
     comm = sharded.make_comm(dev.index)
+    rccl_ranks, rccl_rank = comm.info()                # what the communicator inside the library says (tvz_comm_info)
     # Batches in flight, each on its own stream.  A third one can fill the gaps the tails of two lookups leave
     # (55 -> 46 us per batch on a 1/8 shard in a fresh process) - or lose 20 %: how the runtime maps the streams
     # onto hardware queues decides, and that is not in the program's hands (profiles/r3_shard_pipeline.txt).  So
@@ -326,7 +350,8 @@ def bench_match(args, rank, world, dev):
     q_per_tile = max(1, min(1024, int(0.55 * (1 << 19)) // max(max_len, 1), Q))
     n_tiles = -(-Q // q_per_tile)
     comm.close()
-    out = {"value": pairs / wall, "unit": "pairs/s", "corpus_videos": C, "queries_per_batch": Q,
+    out = {"value": pairs / wall, "unit": "pairs/s", "rccl_ranks": rccl_ranks, "n_gpus": world,
+           "corpus_videos": C, "queries_per_batch": Q,
            "mean_cuts_per_video": round(mean_len, 1), "min_match": 2, "steps": args.match_steps,
            "ms_per_batch": wall * 1e3 / args.match_steps,
            "ms_per_batch_one_batch_replayed": replay_ms, "first_batch_ms_cold": first_batch_ms,
@@ -363,6 +388,8 @@ def bench_match(args, rank, world, dev):
         "frac": alg_ix / (index_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
         "traffic": t_ix, "traffic_source": t_src,
         "algorithmic_bytes_per_launch": alg_ix, "avg_launch_ms": index_ms,
+        "workload": f"rank {rank}'s shard of {C} videos ({shard_rows} rows, {n_sub} sub-index(es)) x {Q} queries",
+        "pairs_per_s": Q * shard_rows / (index_ms * 1e-3),
         "algorithmic_bytes": f"{postings:.0f} postings x 2 B + one {entry_bytes} B directory entry and one 8 B query key per "
                              f"query element ({n_elems:.0f}) + {Q} x {K_TOP + 1} output rows x 12 B (means over the rotating "
                              f"batches; the {n_hits} hits of a batch are no longer written)",
@@ -385,6 +412,8 @@ def bench_match(args, rank, world, dev):
             "achieved": alg8 / (ms8 * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": alg8 / (ms8 * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": t8, "traffic_source": t8_src,
             "algorithmic_bytes_per_launch": alg8, "avg_launch_ms": ms8,
+            "workload": f"rank 0's 1/8 shard of {C} videos ({rows8} rows) x {Q} queries",
+            "pairs_per_s": Q * rows8 / (ms8 * 1e-3),
             "limiter": "instruction issue, as on the full corpus, plus the per-query part that does not shrink with the "
                        "shard (offsets -> keys -> directory probe: 10.7 us net of the 60 us launch, profiles/r4_probe_prepass.txt)"}
         dc8.close()
@@ -604,17 +633,23 @@ def bench_e2e(dev, rank: int = 0, world: int = 1, n_uploads: int = 8, n_frames: 
                 store.corpus.upload_csr(ids + 100000, offs, keys)
         load()
         ins = insp.Inspector(store, device=str(dev), frame_source=lambda b, k, f, u: (feeder.Y4MReader(files[k]), None),
-                             batch=256, max_workers=n_uploads)
+                             batch=256, max_workers=min(n_uploads, 16))
         [f.result() for f in [ins.submit("videos", k) for k in files]]          # warm-up: slots, scorers, SQL
-        ok, dts = True, []
+        ok, dts, scored, dups = True, [], [], 0
         for _ in range(3):               # three timed passes, the median reported: a 0.15 s run is at the host's mercy
             load()
             barrier_sync(world)
+            before = ins.frames_scored
             t0 = time.perf_counter()
             res = [f.result() for f in [ins.submit("videos", k) for k in files]]
             dts.append(max_over_ranks(time.perf_counter() - t0, world, dev))
+            # frames the scene kernels actually scored: an upload that reaches a duplicate verdict stops there
+            # (inspector/app.py:249-255), so it is NOT uploads x frames
+            scored.append(sum_over_ranks(ins.frames_scored - before, world, dev))
             ok = ok and all(r["status"] == "done" for r in res)
-        dt = float(np.median(dts))
+            dups = sum(1 for r in res if r["duplicates"])
+        mid = int(np.argsort(dts)[len(dts) // 2])
+        dt = dts[mid]
         ins.close()
         tick = None
         if rc is not None:
@@ -622,14 +657,19 @@ def bench_e2e(dev, rank: int = 0, world: int = 1, n_uploads: int = 8, n_frames: 
                     "host_us_per_busy_tick": round(rc.tick_host_s * 1e6 / max(rc.busy_ticks, 1), 1)}
             barrier_sync(world)
         store.close()                    # (RankCorpus.close is collective: every rank gets here)
-        total = world * n_uploads * n_frames
-        return {"value": total / dt, "unit": "frames/s", "uploads": world * n_uploads, "frames_per_upload": n_frames,
+        submitted = world * n_uploads * n_frames
+        return {"value": scored[mid] / dt, "unit": "frames/s", "uploads": world * n_uploads, "frames_per_upload": n_frames,
+                "frames_scored": scored[mid], "frames_submitted": submitted,
+                "submitted_frames_per_s": submitted / dt,
+                "uploads_stopped_by_a_duplicate_verdict_rank0": dups,
                 "ranks": world, "rank_tick": tick, "unmeasured_on_hardware_for_ranks_above_1": world > 1,
-                "height": H, "width": W, "all_done": ok, "GBps_luma": total * FRAME_BYTES / dt / 1e9,
-                "passes_s": [round(x, 4) for x in dts], "passes_fps": [round(total / x) for x in dts],
-                "note": "whole Python driver, PCIe-inclusive, files in RAM, no decoder; short clips: per-upload set-up "
-                        "(SQL insert, reader thread, first slot) is inside the wall time.  profiles/r4_e2e_service.txt: "
-                        "16 / 64 uploads x 512 frames 24 / 31 k fps (H2D bound 27.6 k at one copy in flight), 64 x 4K 5.6-5.8 k fps"}
+                "height": H, "width": W, "all_done": ok, "GBps_luma": scored[mid] * FRAME_BYTES / dt / 1e9,
+                "passes_s": [round(x, 4) for x in dts], "passes_fps": [round(n / x) for n, x in zip(scored, dts)],
+                "note": "whole Python driver, PCIe-inclusive, files in RAM, NO DECODER (the reference's ffmpeg decode, "
+                        "inspector/app.py:202-216, is not in this figure: no ffmpeg binary exists here); value = frames the "
+                        "scene kernels scored / wall (an upload stops at its duplicate verdict, app.py:249-255), "
+                        "submitted_frames_per_s = uploads x frames / wall is NOT a throughput; short clips: per-upload "
+                        "set-up (SQL insert, reader thread, first slot) is inside the wall time; one H2D copy in flight"}
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
 
@@ -674,8 +714,132 @@ def pmc_traffic(kernel: str, T: int = 0, tag: str = ""):
     return best, src
 
 
-def main():
-    args = parse()
+def free_port() -> int:
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def launcher_cmd(argv):
+    """The command of ONE rank process of the self-launcher (rank, world and rendezvous travel in the environment,
+    as under torch.distributed.run: RANK, LOCAL_RANK, WORLD_SIZE, MASTER_ADDR, MASTER_PORT)."""
+    keep = [a for a in argv if a not in ("--force-launch", "--dry-launch")]
+    return [sys.executable, os.path.abspath(__file__)] + keep
+
+
+def rank_env(rank: int, world: int, port: int) -> dict:
+    env = dict(os.environ)
+    env.update({"RANK": str(rank), "LOCAL_RANK": str(rank), "WORLD_SIZE": str(world), "LOCAL_WORLD_SIZE": str(world),
+                "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)})
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")        # dmabuf IPC: RCCL across processes needs it on this pool
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return env
+
+
+def launch_ranks(args, argv) -> int:
+    """--gpus N without a launcher around it (WORLD_SIZE unset): THIS process has not touched a GPU and never
+    will - it starts N FRESH rank processes (one per GPU; nothing is exec'ed over a process that has initialised
+    the GPU), relays rank 0's one JSON line and returns the WORST return code of the ranks.  When a rank fails the
+    others get 10 s to leave by themselves (a watchdog's return code 3 is worth more than a SIGTERM's), then are ended."""
+    cmd, port, n = launcher_cmd(argv), free_port(), args.gpus
+    if args.dry_launch:
+        print(json.dumps({"launch": cmd, "ranks": n,
+                          "env": {k: rank_env(0, n, port)[k] for k in ("WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}}))
+        return 0
+    procs = [subprocess.Popen(cmd, env=rank_env(r, n, port), stdout=subprocess.PIPE if r == 0 else sys.stderr)
+             for r in range(n)]
+    line = [None]
+
+    def relay():                                              # ranks write everything but rank 0's line to stderr
+        for raw in procs[0].stdout:
+            txt = raw.decode(errors="replace")
+            try:
+                d = json.loads(txt)
+                ok = isinstance(d, dict) and ("metric" in d or d.get("stub"))
+            except ValueError:
+                ok = False
+            if ok and line[0] is None:
+                line[0] = txt
+            else:
+                sys.stderr.write(txt)
+    th = threading.Thread(target=relay, daemon=True)
+    th.start()
+    first_fail = None
+    while any(p.poll() is None for p in procs):
+        time.sleep(0.05)
+        bad = [p for p in procs if p.poll() not in (None, 0)]
+        if bad and first_fail is None:
+            first_fail = time.monotonic()
+        if first_fail is not None and time.monotonic() - first_fail > 10.0:
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()                             # the exact processes this launcher started
+            first_fail = time.monotonic() + 1e9
+    th.join(5.0)
+    rcs = [p.returncode if p.returncode >= 0 else 128 - p.returncode for p in procs]
+    rc = max(rcs)
+    if rc:
+        print(f"[bench] return codes of the {n} rank processes: {rcs}", file=sys.stderr)
+    if line[0] is not None:
+        sys.stdout.write(line[0] if line[0].endswith("\n") else line[0] + "\n")
+        sys.stdout.flush()
+    if rc == 0 and line[0] is None:
+        print("[bench] the rank processes printed no result line", file=sys.stderr)
+        rc = 4
+    return rc
+
+
+def run_under_watchdog(leg, timeout: float, rank: int, world: int, out: dict, key: str, emit, store=None):
+    """Run leg() - a collective leg that has never run on more than one GPU - under a watchdog.  If it does not
+    finish in `timeout` seconds (a collective some rank never joins), rank 0 prints the line it has, with
+    out[key] = {"error": ..., "ranks_that_never_finished": [...]} (from markers the ranks leave in the
+    rendezvous store, a host TCP channel that does not depend on the hung collective), and EVERY rank leaves with
+    return code 3: a process that abandons a hung collective on the GPU must not look like a successful run."""
+    done = threading.Event()
+
+    def mark(name):
+        if store is not None:
+            try:
+                store.set(f"tvz_bench_{key}_{name}_{rank}", "1")
+            except Exception:
+                pass
+
+    def watchdog():
+        if done.wait(timeout):
+            return
+        missing = None
+        if store is not None:
+            try:
+                missing = [r for r in range(world) if not store.check([f"tvz_bench_{key}_finished_{r}"])]
+            except Exception:
+                missing = None
+        out[key] = {"error": f"{key} leg did not finish within {timeout:.0f} s on rank {rank} (abandoned; exit code 3)",
+                    "ranks_that_never_finished": missing}
+        print(f"[bench] rank {rank}: {key} leg timed out (ranks that never finished: {missing}); leaving with rc 3",
+              file=sys.stderr)
+        if rank != 0:
+            time.sleep(2.0)               # rank 0 prints first: the launcher ends the others at the first failure
+        emit()
+        os._exit(3)
+    threading.Thread(target=watchdog, daemon=True).start()
+    try:
+        res = leg()
+    except Exception as e:                # the driver needs SQLAlchemy + a writable temp directory: report, don't die
+        res = {"error": repr(e)}
+        print(f"[bench] {key} leg failed on rank {rank}: {e!r}", file=sys.stderr)
+    mark("finished")
+    if dist.is_initialized():
+        dist.barrier()                    # (still under the watchdog)
+    done.set()
+    return res
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    args = parse(argv)
+    # Launcher: before anything touches a GPU (importing torch does not; torch.cuda.* is not called above)
+    if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or args.force_launch or args.dry_launch):
+        raise SystemExit(launch_ranks(args, argv))
     # ONE JSON line on stdout, nothing else: native libraries print there too (RCCL's version banner at
     # communicator creation), so everything written to descriptor 1 during the run goes to stderr and the
     # result line is written to the real stdout at the end
@@ -686,13 +850,41 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus} "
+                         "(or run `python bench.py --gpus N` alone: it launches the ranks itself)")
+    out = {}
+    printed = threading.Event()
+
+    def emit():
+        if rank == 0 and not printed.is_set():
+            printed.set()
+            sys.stdout.flush()
+            os.write(real_stdout, (json.dumps(out) + "\n").encode())
+
+    launched = "RANK" in os.environ and "MASTER_ADDR" in os.environ   # under torch.distributed.run
+    if args.launch_stub:
+        # CPU self-test of the launcher and of the watchdog's return code: no GPU, no kernels, gloo
+        if launched:
+            dist.init_process_group("gloo")
+        t = torch.tensor([rank + 1.0])
+        if dist.is_initialized():
+            dist.all_reduce(t)
+        if os.environ.get("TVZ_BENCH_STUB_FAIL_RANK", "") == str(rank):
+            os._exit(7)
+        out.update({"stub": True, "n_gpus": world, "sum_of_rank_numbers": float(t.item())})
+        if args.stub_hang_e2e:
+            store = dist.distributed_c10d._get_default_store() if dist.is_initialized() else None
+            hang = (lambda: time.sleep(3600)) if rank == world - 1 else (lambda: {"ok": True})
+            out["e2e"] = run_under_watchdog(hang, args.e2e_timeout, rank, world, out, "e2e", emit, store)
+        if dist.is_initialized():
+            dist.barrier()
+            dist.destroy_process_group()
+        emit()
+        return
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    launched = "RANK" in os.environ and "MASTER_ADDR" in os.environ   # under torch.distributed.run
     if world > 1 or launched:
         dist.init_process_group("nccl", device_id=dev)
     _lib.load()
@@ -715,13 +907,19 @@ def main():
     T, K = args.frames, args.steps
     wall = res["wall"]
     fps = world * T * K / wall
-    kern_ms = float(np.mean(res["step_ms"]))
-    achieved = (T - 1) * FRAME_BYTES / (kern_ms * 1e-3) / 1e9
+    # ONE time base for value, ms_per_step and the roofline: the timed region (barrier + synchronize on both
+    # sides) divided by its K launches; the per-launch HIP-event durations (which leave out the gaps between
+    # launches) are reported beside it
+    step_ms = wall * 1e3 / K
+    ev_ms = float(np.mean(res["step_ms"]))
+    alg_scene = (T - 1) * FRAME_BYTES
+    achieved = alg_scene / (step_ms * 1e-3) / 1e9
+    scene_traffic, scene_src = pmc_traffic("luma_sad", T)
 
-    out = {
+    out.update({
         "metric": "1080p frames/sec scene-cut scoring (luma SAD + select), frames resident in HBM",
         "value": fps, "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
-        "ms_per_step": wall * 1e3 / K, "higher_is_better": True, "scaling": "weak",
+        "ms_per_step": step_ms, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "u8", "data": "synthetic",
         "config": {"workload": f"configs[1]: {T} synthetic 1080p luma frames per GPU per step, "
                                "HIP luma-SAD scene-cut kernel + select epilogue",
@@ -729,14 +927,33 @@ def main():
                    "parallelism": f"{world} independent video batches (no collective)"},
         "cuts_detected_per_step": res["n_cuts"],
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic("luma_sad", T)[0],
-                     "traffic_source": pmc_traffic("luma_sad", T)[1],
-                     "kernel": "luma_sad_flat_kernel<8,nt> (event pair also covers scene_finalize_kernel, <1% of the step)",
-                     "algorithmic_bytes_per_launch": (T - 1) * FRAME_BYTES,
-                     "avg_launch_ms": kern_ms, "median_launch_ms": float(np.median(res["step_ms"])),
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": scene_traffic,
+                     "traffic_source": scene_src,
+                     "kernel": "luma_sad_flat_kernel<8,nt> (a step also holds scene_finalize_kernel, <1% of it)",
+                     "algorithmic_bytes_per_launch": alg_scene,
+                     "avg_launch_ms": step_ms,
+                     "time_base": "the timed region / its K launches = ms_per_step (the launches run back to back on one stream)",
+                     "per_launch_event_ms_mean": ev_ms, "median_launch_ms": float(np.median(res["step_ms"])),
                      "p10_p90_ms": [float(np.percentile(res["step_ms"], 10)),
                                     float(np.percentile(res["step_ms"], 90))]},
-    }
+    })
+    # both halves of BASELINE.json's metric in the objects the driver keeps whole: the dominant
+    # kernel of each leg with everything a reader needs to recompute its fraction
+    kernels = [{"name": "luma_sad_flat_kernel", "workload": out["config"]["workload"], "avg_launch_ms": step_ms,
+                "algorithmic_bytes": alg_scene, "traffic": scene_traffic, "frac": achieved / HBM_PEAK_GBS,
+                "frames_per_s": fps / world}]
+    if isinstance(match_leg, dict) and "roofline" in match_leg:
+        for r in (match_leg["roofline"], match_leg.get("shard8_roofline")):
+            if r:
+                kernels.append({"name": r["kernel"].split(" ")[0], "workload": r.get("workload"),
+                                "avg_launch_ms": r["avg_launch_ms"], "algorithmic_bytes": r["algorithmic_bytes_per_launch"],
+                                "traffic": r["traffic"], "frac": r["frac"], "pairs_per_s": r.get("pairs_per_s"),
+                                "frac_bound": r.get("frac_bound")})
+        kernels.append({"name": "tvz_match_sharded (whole batch: lookup with top-k -> ncclAllGather -> merge, pipelined)",
+                        "workload": f"{match_leg['corpus_videos']} videos x {match_leg['queries_per_batch']} queries over "
+                                    f"{match_leg['rccl_ranks']} RCCL rank(s)",
+                        "avg_launch_ms": match_leg["ms_per_batch"], "pairs_per_s": match_leg["value"]})
+    out["roofline"]["kernels"] = kernels
     if rank == 0:
         out["h2d"] = h2d_cost(dev)
     if rank == 0 and world == 1 and not args.no_cpu:
@@ -746,6 +963,9 @@ def main():
         # the restatement on ONE core as well as on all of them
         one, _ = cpu_baseline_scene(res["frames"], min(args.cpu_frames, 256), 1, min_seconds=1.0)
         cpu["single_core"] = {"value": one["value"], "unit": "frames/s", "cores": 1, "sample": one["sample"]}
+        m5 = (match_leg or {}).get("config2", {}).get("c5000", {}) if isinstance(match_leg, dict) else {}
+        if "cpu_baseline" in m5:
+            cpu["matcher"] = m5["cpu_baseline"]            # the second half of the metric, timed on the same host cores
         out["cpu_baseline"] = cpu
     else:
         out["cpu_baseline"] = None
@@ -755,38 +975,30 @@ def main():
         out["config0"] = bench_config0(dev, args.cpu_threads)
     if match_leg is not None:
         out["match"] = match_leg
-    printed = threading.Event()
-
-    def emit():
-        if rank == 0 and not printed.is_set():
-            printed.set()
-            sys.stdout.flush()
-            os.write(real_stdout, (json.dumps(out) + "\n").encode())
 
     if not args.no_e2e:                   # every rank: the N-rank leg is collective (the tick exchange)
-        # The leg that has never run on more than one GPU comes LAST and under a watchdog: if it hangs (a
-        # collective that some rank never joins), the line - headline, roofline, match - is printed without
-        # it and every rank leaves, instead of the whole scaling run being lost.
-        def watchdog():
-            if not done.wait(args.e2e_timeout):
-                out["e2e"] = {"error": f"e2e leg did not finish within {args.e2e_timeout:.0f} s on rank {rank} (abandoned)"}
-                print(f"[bench] rank {rank}: e2e leg timed out; leaving", file=sys.stderr)
-                emit()
-                os._exit(0)
-        done = threading.Event()
-        threading.Thread(target=watchdog, daemon=True).start()
-        try:
-            e2e = bench_e2e(dev, rank, world, ranked=args.e2e_ranked)
-        except Exception as e:            # the driver needs SQLAlchemy + a writable temp directory: report, don't die
-            e2e = {"error": repr(e)}
-            if world > 1:
-                print(f"[bench] e2e leg failed on rank {rank}: {e!r}", file=sys.stderr)
+        # The leg that has never run on more than one GPU comes LAST and under a watchdog (run_under_watchdog)
+        shapes = [tuple(int(x) for x in sh.split("x")) for sh in args.e2e_shapes.split(",") if sh]
+        store = dist.distributed_c10d._get_default_store() if dist.is_initialized() else None
+
+        def leg():
+            first = None
+            for j, (nu, nf) in enumerate(shapes):
+                r = bench_e2e(dev, rank, world, n_uploads=nu, n_frames=nf, ranked=args.e2e_ranked)
+                torch.cuda.empty_cache()
+                if first is None:
+                    first = r
+                else:
+                    first.setdefault("other_shapes", []).append(r)
+            return first
+        e2e = run_under_watchdog(leg, args.e2e_timeout, rank, world, out, "e2e", emit, store)
         if rank == 0:
             out["e2e"] = e2e
-        torch.cuda.empty_cache()
-        if dist.is_initialized():
-            dist.barrier()                # (still under the watchdog)
-        done.set()
+            if isinstance(e2e, dict) and "GBps_luma" in e2e and "h2d" in out:
+                # frames that were scored crossed the link: the figure cannot exceed what the link moves
+                e2e["h2d_bound_check"] = {"copies_in_flight": 1, "h2d_GBps": out["h2d"]["GBps"],
+                                          "ok": all(x["GBps_luma"] <= out["h2d"]["GBps"] * 1.02
+                                                    for x in [e2e] + e2e.get("other_shapes", []))}
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()

@@ -67,14 +67,16 @@ try:
     store.clear()
     store.corpus.upload(lib_rows)
     ins.phase_seconds.clear()
+    scored0 = ins.frames_scored
     t0 = time.perf_counter()
     futs = [ins.submit("videos", k) for k in files]
     res = [f.result() for f in futs]
     dt = time.perf_counter() - t0
     assert all(r["status"] == "done" for r in res), [r.get("error") for r in res]
-    frames_done = sum(round(r["scene_cuts"][-1] * 30) if r["duplicates"] else T for r in res)
+    frames_done = ins.frames_scored - scored0   # an upload stops at its duplicate verdict (inspector/app.py:249-255)
     print(json.dumps({"uploads": N, "frames_per_clip": T, "height": H, "width": W, "shards": SHARDS, "workers": WORKERS, "batch": BATCH, "wall_s": round(dt, 3),
-                      "frames_per_s": round(N * T / dt), "GBps_luma": round(N * T * H * W / dt / 1e9, 2),
+                      "frames_per_s": round(frames_done / dt), "GBps_luma": round(frames_done * H * W / dt / 1e9, 2),
+                      "frames_scored": frames_done, "frames_submitted": N * T, "submitted_frames_per_s": round(N * T / dt),
                       "slot_MiB": SLOT_MB, "switch_interval": sys.getswitchinterval(),
                       "cuts_total": sum(r["total_cuts"] for r in res), "dups_total": sum(len(r["duplicates"]) for r in res),
                       "phase_thread_seconds": {k: (round(v, 3) if isinstance(v, float) else v)

@@ -1,4 +1,5 @@
 #!/bin/bash
+export TVZ_ALLOW_DIAGNOSTIC=1   # variants/libtvz_*.so are diagnostic builds (tvz_version() < 0): only these scripts may load them
 # HBM traffic of one matcher workload, two counter passes (FETCH_SIZE, WRITE_SIZE), optionally with a
 # variant library:  [TVZ_LIB=variants/libtvz_x.so] bash profiles/pmc_traffic.sh <workload> <name>
 W=${1:-index}; NAME=${2:-product}

@@ -1,4 +1,5 @@
 #!/bin/bash
+export TVZ_ALLOW_DIAGNOSTIC=1   # variants/libtvz_*.so are diagnostic builds (tvz_version() < 0): only these scripts may load them
 # Everything measured for a round, in one gpurun call (run on the GPU box from the repo root):
 #   bash profiles/variant_build.sh stamp -DTVZ_IX_STAMP      (build container, beforehand)
 #   bash profiles/run_all.sh <tag>

@@ -1,4 +1,5 @@
 #!/bin/bash
+export TVZ_ALLOW_DIAGNOSTIC=1   # variants/libtvz_*.so are diagnostic builds (tvz_version() < 0): only these scripts may load them
 # Experiment harness: time one matcher workload with each prebuilt library variant under variants/
 # (built with TVZ_CXXFLAGS=-D...), plus L2 hit/miss and fabric-read counters of the sweep kernel.
 #   bash profiles/variant_sweep.sh <workload> <variant>...

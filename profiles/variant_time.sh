@@ -1,4 +1,5 @@
 #!/bin/bash
+export TVZ_ALLOW_DIAGNOSTIC=1   # variants/libtvz_*.so are diagnostic builds (tvz_version() < 0): only these scripts may load them
 # Time matcher workloads with prebuilt library variants under variants/ (experiments only).  The
 # variant is selected with TVZ_LIB (tvidz_amd/_lib.py): the product library is never touched.
 #   bash profiles/variant_time.sh "<workload> ..." <variant>...      (variant "product" = tvidz_amd/libtvz.so)

@@ -110,3 +110,29 @@ def test_entry_points_fail_gracefully_without_a_gpu():
     from tvidz_amd import scene
     with pytest.raises(RuntimeError):
         scene.SceneScorer(32, 32, 4, "cpu")
+
+
+def test_diagnostic_builds_are_quarantined(tmp_path):
+    """A library compiled with one of the TVZ_IX_* diagnostic defines (profiles/variant_build.sh: some return WRONG
+    results on purpose) reports a negated version, and the product binding refuses to load it; build.build()
+    ignores TVZ_CXXFLAGS unless TVZ_DIAGNOSTIC=1 says the build is meant to be one."""
+    import subprocess
+    import sys
+    from tvidz_amd import build as b
+    so = str(tmp_path / "libtvz_diag.so")
+    # tvz_api.hip alone carries tvz_version(): compile it with the define the kernels' wrong-result path uses
+    subprocess.check_call([b._hipcc(), f"--offload-arch={b.ARCH}", "-O1", "-std=c++17", "-fPIC", "-shared",
+                           f"-I{b.INCLUDE}", f"-I{b.CSRC}", "-DTVZ_IX_FAKEPOST", "-o", so,
+                           os.path.join(b.CSRC, "tvz_api.hip"), "-ldl"])
+    code = ("import ctypes, os, sys\n"
+            f"sys.path.insert(0, {ROOT!r})\n"
+            "from tvidz_amd import _lib\n"
+            "print(ctypes.CDLL(os.environ['TVZ_LIB']).tvz_version())\n"
+            "try:\n    _lib.load()\n    print('LOADED')\nexcept RuntimeError as e:\n    print('REFUSED', 'DIAGNOSTIC' in str(e))\n")
+    env = dict(os.environ, TVZ_LIB=so)
+    env.pop("TVZ_ALLOW_DIAGNOSTIC", None)
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert out.stdout.split() == ["-400", "REFUSED", "True"], (out.stdout, out.stderr)
+    # the product build does not take flags from a stray environment variable
+    src = open(os.path.join(ROOT, "tvidz_amd", "build.py")).read()
+    assert 'os.environ.get("TVZ_DIAGNOSTIC") == "1"' in src and "TVZ_CXXFLAGS ignored" in src

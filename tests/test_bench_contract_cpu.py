@@ -53,3 +53,53 @@ def test_secondary_objects():
     assert "shard8_roofline" in m and "config2" in m
     assert d["config0"]["gpu"]["cuts_equal_cpu"] is True
     assert d["e2e"]["all_done"] is True and d["h2d"]["GBps"] > 0
+
+
+# ---- the self-launcher and the watchdog's return code (no GPU: `--launch-stub` ranks join a gloo group) ----
+import subprocess
+import sys
+
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _run(*argv, env=None, timeout=240):
+    e = dict(os.environ)
+    e.pop("WORLD_SIZE", None), e.pop("RANK", None)
+    e.update(env or {})
+    return subprocess.run([sys.executable, BENCH, *argv], env=e, capture_output=True, text=True, timeout=timeout)
+
+
+def test_gpus_n_without_a_launcher_starts_n_fresh_rank_processes():
+    """`python bench.py --gpus N` as the driver runs `--gpus 1`: the parent touches no GPU,
+    starts N rank processes of bench.py itself and hands them the rendezvous in the environment."""
+    p = _run("--gpus", "2", "--steps", "3", "--dry-launch")
+    assert p.returncode == 0, p.stderr
+    d = json.loads(p.stdout)
+    assert d["ranks"] == 2 and d["launch"][1] == BENCH and d["launch"][2:] == ["--gpus", "2", "--steps", "3"]
+    assert d["env"]["WORLD_SIZE"] == "2" and d["env"]["MASTER_ADDR"] == "127.0.0.1" and int(d["env"]["MASTER_PORT"]) > 0
+
+
+def test_launcher_relays_rank0_line_and_the_worst_return_code():
+    p = _run("--gpus", "2", "--launch-stub")
+    assert p.returncode == 0, p.stderr
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1 and json.loads(lines[0]) == {"stub": True, "n_gpus": 2, "sum_of_rank_numbers": 3.0}
+    p = _run("--gpus", "2", "--launch-stub", env={"TVZ_BENCH_STUB_FAIL_RANK": "1"})
+    assert p.returncode == 7, (p.returncode, p.stderr)
+    assert p.stdout.strip() == ""                       # no line from a failed run
+
+
+def test_a_mismatched_world_size_is_refused():
+    p = _run("--gpus", "2", "--launch-stub", env={"WORLD_SIZE": "3", "RANK": "0"})
+    assert p.returncode != 0 and "WORLD_SIZE=3" in p.stderr
+
+
+def test_an_abandoned_leg_exits_non_zero_and_names_the_rank():
+    """bench.py:run_under_watchdog: the line is printed with e2e.error and the
+    ranks that never finished; every rank leaves with return code 3."""
+    p = _run("--gpus", "2", "--launch-stub", "--stub-hang-e2e", "--e2e-timeout", "1")
+    assert p.returncode == 3, (p.returncode, p.stderr)
+    d = json.loads(p.stdout)
+    assert "did not finish" in d["e2e"]["error"] and d["e2e"]["ranks_that_never_finished"] == [1]
+    p = _run("--gpus", "1", "--launch-stub", "--stub-hang-e2e", "--e2e-timeout", "0")
+    assert p.returncode == 3 and "error" in json.loads(p.stdout)["e2e"]

@@ -154,3 +154,48 @@ def test_a_dead_rank_is_noticed(svc):
     s.procs[1].terminate()
     s.procs[1].wait(timeout=20)
     assert s.dead() == [1]                           # main()'s monitor thread stops the service on this
+
+
+def test_rank_processes_notice_a_dead_launcher_under_a_subreaper(tmp_path):
+    """the child watchdog compared os.getppid() with 1 - wrong both ways: a launcher that IS pid 1 (the
+    reference's deployment: inspector/entrypoint.sh ends with `exec python app.py`) made every rank leave at once,
+    and under a subreaper an orphan is re-parented to a pid other than 1 and never noticed.  Here the launcher runs
+    under a subreaper (this harness), is killed, and its rank must leave with the watchdog's exit code 4."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    port = PORT + 400
+    harness = f"""
+import ctypes, os, signal, subprocess, sys, time, json, urllib.request
+ctypes.CDLL(None).prctl(36, 1, 0, 0, 0)                       # PR_SET_CHILD_SUBREAPER
+env = dict(os.environ, PYTHONPATH={root!r})
+L = subprocess.Popen([sys.executable, "-m", "tvidz_amd.service", "--ranks", "1", "--port", "{port}", "--db",
+                      "sqlite:///{tmp_path}/t.db", "--parts", "tests.fakes:cpu_rank_parts", "--k", "4", "--cap", "64"], env=env)
+pid, deadline = None, time.time() + 240
+while pid is None and time.time() < deadline:
+    try:
+        pid = json.load(urllib.request.urlopen("http://127.0.0.1:{port + 1}/rank-info", timeout=2))["pid"]
+    except Exception:
+        time.sleep(0.2)
+assert pid, "the rank never came up"
+assert L.poll() is None, "the launcher left although its rank's parent is alive (the pid-1 comparison)"
+os.kill(L.pid, signal.SIGKILL)
+L.wait()
+deadline = time.time() + 20
+while time.time() < deadline:
+    got, status = os.waitpid(pid, os.WNOHANG)                 # re-parented to this subreaper, not to pid 1
+    if got == pid:
+        print("CHILD_EXIT", os.WEXITSTATUS(status) if os.WIFEXITED(status) else -1)
+        break
+    time.sleep(0.1)
+else:
+    os.kill(pid, signal.SIGKILL)
+    print("CHILD_NEVER_LEFT")
+"""
+    out = subprocess.run([sys.executable, "-c", harness], capture_output=True, text=True, timeout=300)
+    assert "CHILD_EXIT 4" in out.stdout, (out.stdout, out.stderr[-2000:])
+
+
+def test_parent_gone_compares_with_the_launchers_pid_not_with_one():
+    assert service.parent_gone(os.getppid()) is False          # also when os.getppid() == 1: a pid-1 launcher is alive
+    assert service.parent_gone(os.getppid() + 1) is True

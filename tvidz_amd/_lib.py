@@ -115,16 +115,21 @@ def load() -> C.CDLL:
                     "fallback. Run `python -m tvidz_amd.build` (needs hipcc).")
             _preload_torch_hip_runtime()
             lib = C.CDLL(SO_PATH)
+            lib.tvz_version.restype, lib.tvz_version.argtypes = C.c_int, []
+            # A stale library behind a newer binding (or the reverse) shifts arguments silently: round
+            # 2's only host crash (SIGSEGV inside tvz_find_duplicates, gpurun_out/r2_t2.log) was a run
+            # of the ABI-v2 binding against a library built from the half-converted sources.  Refuse.
+            if lib.tvz_version() == -VERSION and os.environ.get("TVZ_ALLOW_DIAGNOSTIC") != "1":
+                raise RuntimeError(f"{SO_PATH} is a DIAGNOSTIC build (tvz_version() = {lib.tvz_version()}: compiled with "
+                                   "a TVZ_IX_* / TVZ_DIAGNOSTIC define; some of them return wrong results on purpose). "
+                                   "The product binding refuses it; profile scripts set TVZ_ALLOW_DIAGNOSTIC=1.")
+            if abs(lib.tvz_version()) != VERSION:
+                raise RuntimeError(f"{SO_PATH} is version {lib.tvz_version()}, this binding expects {VERSION}: "
+                                   "rebuild it (python -m tvidz_amd.build --force)")
             for name, (res, args) in SIGNATURES.items():
                 fn = getattr(lib, name)
                 fn.restype = res
                 fn.argtypes = args
-            # A stale library behind a newer binding (or the reverse) shifts arguments silently: round
-            # 2's only host crash (SIGSEGV inside tvz_find_duplicates, gpurun_out/r2_t2.log) was a run
-            # of the ABI-v2 binding against a library built from the half-converted sources.  Refuse.
-            if lib.tvz_version() != VERSION:
-                raise RuntimeError(f"{SO_PATH} is version {lib.tvz_version()}, this binding expects {VERSION}: "
-                                   "rebuild it (python -m tvidz_amd.build --force)")
             _lib = lib
     return _lib
 

@@ -38,10 +38,17 @@ def needs_build() -> bool:
 def build(force: bool = False, verbose: bool = False) -> str:
     if not force and not needs_build():
         return SO
+    # TVZ_CXXFLAGS reaches the product compile only together with TVZ_DIAGNOSTIC=1, and the library it makes then
+    # says so (-DTVZ_DIAGNOSTIC: tvz_version() negated, refused by the binding): a stray environment variable cannot
+    # turn tvidz_amd/libtvz.so into one of the diagnostic builds of profiles/variant_build.sh
+    extra = []
+    if os.environ.get("TVZ_DIAGNOSTIC") == "1":
+        extra = ["-DTVZ_DIAGNOSTIC=1"] + os.environ.get("TVZ_CXXFLAGS", "").split()
+    elif os.environ.get("TVZ_CXXFLAGS"):
+        print("tvidz_amd.build: TVZ_CXXFLAGS ignored (set TVZ_DIAGNOSTIC=1 for a diagnostic build)", file=sys.stderr)
     cmd = [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared",
            "-fvisibility=hidden", "-Wall", "-Wno-unused-function", f"-I{INCLUDE}", f"-I{CSRC}",
-           "-o", SO + ".tmp"] + os.environ.get("TVZ_CXXFLAGS", "").split() + \
-          [os.path.join(CSRC, s) for s in SOURCES] + ["-ldl"]
+           "-o", SO + ".tmp"] + extra + [os.path.join(CSRC, s) for s in SOURCES] + ["-ldl"]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)

@@ -236,6 +236,12 @@ class Comm:
             self.lib.tvz_comm_destroy(self._h)
             self._h = None
 
+    def info(self) -> Tuple[int, int]:
+        """(ranks, rank) as the RCCL communicator inside the library reports them (tvz_comm_info)."""
+        n, r = C.c_int32(0), C.c_int32(0)
+        _lib.check(self.lib.tvz_comm_info(self._h, C.byref(n), C.byref(r)))
+        return int(n.value), int(r.value)
+
     def match_sharded(self, corpus: DeviceCorpus, d_queries: torch.Tensor, d_q_offsets: torch.Tensor,
                       max_query_len: int, min_match: int, cap: int, k: int,
                       d_exclude_ids: Optional[torch.Tensor] = None,

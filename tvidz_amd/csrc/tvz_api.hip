@@ -10,7 +10,7 @@ char *err_buf() {
 }
 }  // namespace tvz
 
-TVZ_EXPORT int tvz_version(void) { return TVZ_VERSION; }
+TVZ_EXPORT int tvz_version(void) { return TVZ_DIAGNOSTIC_BUILD ? -TVZ_VERSION : TVZ_VERSION; }
 TVZ_EXPORT const char *tvz_last_error(void) { return tvz::err_buf(); }
 
 // ------------------------------------------------------------------------------------------------

@@ -13,6 +13,17 @@
 
 #define TVZ_EXPORT extern "C" __attribute__((visibility("default")))
 
+// Diagnostic builds (profiles/variant_build.sh: s_memtime stamps, phases cut short, made-up postings - some of
+// them return WRONG results on purpose) are quarantined: any of these defines makes tvz_version() return the
+// NEGATED version, which every binding refuses (tvidz_amd/_lib.py loads such a library only with
+// TVZ_ALLOW_DIAGNOSTIC=1, the profile scripts' own environment).
+#if defined(TVZ_IX_STOP) || defined(TVZ_IX_FAKEPOST) || defined(TVZ_IX_NOIVID) || defined(TVZ_IX_NOSTORE) || \
+    defined(TVZ_IX_STAMP) || defined(TVZ_DIAGNOSTIC)
+#define TVZ_DIAGNOSTIC_BUILD 1
+#else
+#define TVZ_DIAGNOSTIC_BUILD 0
+#endif
+
 namespace tvz {
 
 char *err_buf();  // thread-local, 512 bytes

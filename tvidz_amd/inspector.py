@@ -107,6 +107,9 @@ class Inspector:
         # optional per-phase wall-clock accounting of the driver loop (profiles/e2e_service.py)
         self.phase_seconds: Optional[Dict[str, float]] = {} if profile else None
         self._phase_lock = threading.Lock()
+        # frames the scene kernels have scored over all uploads (an upload that reaches a duplicate
+        # verdict stops there, app.py:249-255): what a throughput figure must count, not uploads x frames
+        self.frames_scored = 0
 
     def _phase(self, name: str, t0: float) -> float:
         t1 = time.perf_counter()
@@ -259,6 +262,8 @@ class Inspector:
                 self._progress(analysis_key, scene_timestamps, frames_done, total_frames, dups_to_report)
                 t = self._phase("progress", t)
         finally:
+            with self._phase_lock:
+                self.frames_scored += frames_done
             t = time.perf_counter()
             feeder.close()                                 # stops the decoder (app.py:249-252)
             self._scorer_put(skey, scorer)

@@ -578,6 +578,12 @@ def _hip_parts(rank: int, world: int, group, a):
                 inspector=lambda store: Inspector(store, device=f"cuda:{a.device}", max_workers=a.workers))
 
 
+def parent_gone(parent_pid: int) -> bool:
+    """True once this process's parent is no longer the process that started it (it was re-parented: to pid 1,
+    or to a subreaper)."""
+    return os.getppid() != parent_pid
+
+
 def _child_main(a) -> int:
     """One rank: process group, shard, tick exchange, store, driver, routes."""
     from . import db
@@ -605,9 +611,15 @@ def _child_main(a) -> int:
     def rank_info():                                            # what the front's readiness probe and the tests read
         from flask import jsonify
         rows, keys, _ = rc.stats()
-        return jsonify({"rank": a.rank, "ranks": a.ranks, "rows": rows, "keys": keys, "ticks": rc.ticks,
+        return jsonify({"rank": a.rank, "ranks": a.ranks, "pid": os.getpid(), "rows": rows, "keys": keys, "ticks": rc.ticks,
                         "busy_ticks": rc.busy_ticks, "exact_asks": rc.exact_asks,
                         "tick_host_s": rc.tick_host_s, "broken": repr(rc.broken) if rc.broken else None})
+
+    # The launcher's pid as the launcher itself passed it (--parent-pid); a child started by hand takes its parent
+    # at start-up.  NOT `os.getppid() == 1`: the reference runs its app as the container's PID 1
+    # (inspector/entrypoint.sh ends with `exec python app.py`), so a launcher started the same way IS pid 1 and
+    # every rank would leave at once; and under a subreaper an orphan is re-parented to a pid other than 1.
+    parent_pid = a.parent_pid if a.parent_pid > 0 else os.getppid()
 
     def watchdog():
         while True:
@@ -615,7 +627,7 @@ def _child_main(a) -> int:
             if rc.broken is not None:
                 sys.stderr.write(f"[tvidz rank {a.rank}] tick loop broke: {rc.broken!r}\n")
                 os._exit(3)
-            if os.getppid() == 1:                               # the parent is gone: so is the service
+            if parent_gone(parent_pid):                         # the launcher is gone: so is the service
                 os._exit(4)
     threading.Thread(target=watchdog, name="tvz-watchdog", daemon=True).start()
     app.run(host="127.0.0.1", port=a.http_port, threaded=True, use_reloader=False)
@@ -724,7 +736,8 @@ class RankService:
             cmd = [sys.executable, "-m", "tvidz_amd.service", "--child", "--rank", str(r), "--ranks", str(self.ranks),
                    "--master-port", str(master_port), "--http-port", str(base_port + 1 + r), "--db", db_url,
                    "--backend", backend, "--device", str(devices[r]), "--k", str(k), "--cap", str(cap),
-                   "--workers", str(workers), "--tick-s", str(tick_s)] + (["--parts", parts] if parts else [])
+                   "--workers", str(workers), "--tick-s", str(tick_s), "--parent-pid", str(os.getpid())] + \
+                  (["--parts", parts] if parts else [])
             e = dict(os.environ)
             e.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: RCCL between processes needs it here
             e.update(env or {})
@@ -786,6 +799,7 @@ def main(argv=None) -> int:  # pragma: no cover - exercised through subprocesses
     ap.add_argument("--master-port", type=int, default=29500, help=argparse.SUPPRESS)
     ap.add_argument("--http-port", type=int, default=5001, help=argparse.SUPPRESS)
     ap.add_argument("--device", type=int, default=0, help=argparse.SUPPRESS)
+    ap.add_argument("--parent-pid", type=int, default=0, help=argparse.SUPPRESS)
     a = ap.parse_args(argv)
     if a.child:
         return _child_main(a)
