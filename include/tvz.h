@@ -224,6 +224,13 @@ int tvz_corpus_index_stats(tvz_corpus *c, int64_t *n_indexed_rows, int64_t *n_de
  * (where the LDS allows), _NO_PAIR never.  Same results either way. */
 #define TVZ_ALGO_PAIR 0x100
 #define TVZ_ALGO_NO_PAIR 0x200
+/* On a handle of ONE sub-index (up to 16,384 indexed rows: a rank's share of an 8-way sharded 100k-video table) and
+ * queries of up to 512 timestamps the lookup that keeps the top-k gives every query to one WAVE instead of a block
+ * (ts_match_wq_topk_kernel: no barriers, every probe of the query in flight at once, the postings in registers
+ * between the passes).  _NO_WAVE keeps the block kernel, _WAVE asks for the wave kernel (an error where the handle or
+ * the batch does not fit it).  Same results either way. */
+#define TVZ_ALGO_WAVE 0x400
+#define TVZ_ALGO_NO_WAVE 0x800
 
 /* Scratch for the batched calls below.  k = 0 for tvz_match (tables of the hash join only);
  * k > 0 adds the hit lists + per-shard top-k block of tvz_match_topk / tvz_match_sharded

@@ -29,6 +29,9 @@ from tvidz_amd import _lib, corpus as tc, synth  # noqa: E402
 which = sys.argv[1] if len(sys.argv) > 1 else "join"
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 12
 MM = int(sys.argv[3]) if len(sys.argv) > 3 else 2
+# shape of the lookup that keeps the top-k (topk / shard8): 0 = the library's choice, 0x400 = one wave per query
+# (tvz.h TVZ_ALGO_WAVE), 0x800 = never (TVZ_ALGO_NO_WAVE), 0x100 / 0x200 = two queries per block always / never
+SHAPE = int(os.environ.get("TVZ_SHAPE", "0"), 0)
 dev = torch.device("cuda:0")
 C, Q, algo = {"join": (100000, 4096, _lib.ALGO_JOIN), "q1_100k": (100000, 1, _lib.ALGO_Q1),
               "q1_5k": (5000, 1, _lib.ALGO_Q1), "tile": (100000, 64, _lib.ALGO_TILE),
@@ -77,7 +80,7 @@ if which in ("topk", "shard8"):
     out = torch.empty((Q, 17, 3), dtype=torch.int32, device=dev)
     def call():
         b = nxt()
-        blk = dc.match_topk(b[0], b[1], ml, MM, CAP, 16, out=out, workspace=ws, stream=st)
+        blk = dc.match_topk(b[0], b[1], ml, MM, CAP, 16, out=out, workspace=ws, stream=st, algo=SHAPE)
         tc.topk_merge(blk.view(1, Q, 17, 3), 16, stream=st)
 else:
     ws = torch.empty(tc.workspace_bytes(Q, ml), dtype=torch.uint8, device=dev)
@@ -90,7 +93,7 @@ for r in range(reps):
     a.record(st); call(); b.record(st)
     st.synchronize()
     ts.append(a.elapsed_time(b))
-res = {"workload": which, "C": C, "Q": Q, "min_match": MM, "median_ms": round(float(np.median(ts[2:])), 4),
+res = {"workload": which, "shape": hex(SHAPE), "C": C, "Q": Q, "min_match": MM, "median_ms": round(float(np.median(ts[2:])), 4),
        "first_call_ms_cold": round(ts[0], 4), "distinct_batches": NB,
        "hits": int(n.sum().item()) if which not in ("topk", "shard8") else None}
 if which in ("q1_5k", "index1", "index1_5k"):     # find_duplicates takes the index when there is one

@@ -30,6 +30,9 @@ d_q, d_off, max_len = tc.pack_queries(queries, dev)
 rows = []
 comm = sharded.make_comm(0)
 K, CAP = 16, 16384
+# shape of the lookup that keeps the top-k, OR-ed into `algo` (tvz.h): 0 = the library's choice, 0x800 = never one
+# wave per query (TVZ_ALGO_NO_WAVE): an A/B of the two on the one-sub-index shard of N = 8
+SHAPE = int(os.environ.get("TVZ_SHAPE", "0"), 0)
 
 
 def emulated_tail(dc, depth, B, steps=100):
@@ -47,7 +50,7 @@ def emulated_tail(dc, depth, B, steps=100):
     def submit(i):
         st = sts[i]
         _lib.check(lib.tvz_match_topk(dc._h, d_q.data_ptr(), d_off.data_ptr(), Q, max_len, 2, None, CAP, K,
-                                      loc[i].data_ptr(), ws[i].data_ptr(), ws[i].numel(), _lib.ALGO_AUTO, st.cuda_stream))
+                                      loc[i].data_ptr(), ws[i].data_ptr(), ws[i].numel(), _lib.ALGO_AUTO | SHAPE, st.cuda_stream))
         with torch.cuda.stream(st):
             g[i].copy_(src, non_blocking=True)              # B blocks land in the gathered buffer ...
             if B > 1:
@@ -79,7 +82,7 @@ for N in (1, 2, 4, 8):
     dc.upload_csr(s_ids, s_offs, s_keys)
     by_depth = {}
     for depth in ((DEPTH,) if DEPTH else (2, 3)):
-        sm = sharded.RcclShardedMatcher(dc, comm, k=16, cap=16384, n_streams=depth)
+        sm = sharded.RcclShardedMatcher(dc, comm, k=16, cap=16384, n_streams=depth, algo=SHAPE)
         for _ in range(2 * depth):
             sm.match_topk(d_q, d_off, max_len, 2)
         torch.cuda.synchronize()
@@ -136,7 +139,7 @@ for r in rows:
     r["predicted_speedup"] = round(t1 / r["ms_per_batch"], 2)
     r["predicted_speedup_with_N_block_tail"] = round(rows[0]["ms_per_batch_with_N_block_tail"] / r["ms_per_batch_with_N_block_tail"], 2)
     r["allgather_bytes_per_rank"] = Q * 17 * 12
-print(json.dumps({"Q": Q, "C": C, "k": 16, "cap": 16384, "batches_in_flight": DEPTH or "calibrated per N: the faster of 2 and 3", "rows": rows,
+print(json.dumps({"Q": Q, "C": C, "shape": hex(SHAPE), "k": 16, "cap": 16384, "batches_in_flight": DEPTH or "calibrated per N: the faster of 2 and 3", "rows": rows,
                   "note": "rank-0 shard on one MI355X; the collective (204 B per query and rank) is overlapped with the "
                           "next batch's sweep on a second stream, so the prediction is T_shard(1) / T_shard(N); "
                           "merge_of_N_blocks_ms = the merge of N gathered blocks alone on an idle GPU (the timed loop merges "

@@ -13,11 +13,11 @@ import sys
 tag = sys.argv[1] if len(sys.argv) > 1 else "r2"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "gpurun_out", f"pmc_match_{tag}")
-TAGS = {"join": "C100000_Q4096", "q1_100k": "C100000_Q1", "q1_5k": "C5000_Q1", "tile": "C100000_Q64",
+TAGS = {"shard8_wave": "C12500_Q4096_wave", "shard8_block": "C12500_Q4096_block", "join": "C100000_Q4096", "q1_100k": "C100000_Q1", "q1_5k": "C5000_Q1", "tile": "C100000_Q64",
         "topk": "C100000_Q4096", "shard8": "C12500_Q4096", "index": "C100000_Q4096_index",
         "index1": "C100000_Q1_index", "index1_5k": "C5000_Q1_index"}
 OURS = ("ts_match_q1", "ts_match_tile", "ts_match_join", "ts_join_build", "ts_topk_select", "ts_topk_kernel", "ts_topk_wave",
-        "ts_topk_merge_sorted",
+        "ts_topk_merge_sorted", "ts_match_wq_topk", "bk_slice_build",
         "ts_prep", "ts_kth_fixup", "ts_counts_gather", "ts_match_index_topk", "ts_match_index", "ix_count", "ix_fill",
         "ix_offsets")
 

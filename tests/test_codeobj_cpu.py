@@ -13,7 +13,7 @@ from tvidz_amd import build as tbuild
 
 HOT = ("ts_match_index_kernel", "ts_match_index_topk_kernel", "ts_find_fused_kernel", "ts_match_join_kernel",
        "ts_match_q1_kernel", "ts_match_tile_kernel", "luma_sad_flat_kernel", "ts_topk_wave_kernel",
-       "ts_topk_merge_sorted_kernel")
+       "ts_topk_merge_sorted_kernel", "ts_match_wq_topk_kernel", "bk_slice_build_kernel")
 AT_MOST_64_VGPRS = ("ts_match_index_kernel", "ts_match_index_topk_kernel", "ts_find_fused_kernel", "ts_match_join_kernel")
 
 
@@ -84,6 +84,17 @@ def test_eight_waves_per_simd_kernels_fit_64_vgprs(kernels):
             assert k[".vgpr_count"] <= 64, (name, k[".vgpr_count"])
             assert k.get(".vgpr_spill_count", 0) == 0, (name, k)
     assert n >= 10          # index x {host, device} x {M2, Top5, Count}, top-k x 2, fused x 2, join
+
+
+def test_one_wave_lookup_keeps_three_waves_per_simd(kernels):
+    """ts_match_wq_topk_kernel holds a query's postings in registers between its passes; its LDS (~16 KiB per wave) admits
+    ten waves per CU, which needs three per SIMD: at most 168 VGPRs, and no scratch (checked above)."""
+    n = 0
+    for name, k in kernels.items():
+        if "ts_match_wq_topk_kernel" in name:
+            n += 1
+            assert k[".vgpr_count"] <= 168, (name, k[".vgpr_count"])
+    assert n == 2
 
 
 def test_static_lds_of_the_single_query_sweep_is_what_its_launch_guard_assumes(kernels):

@@ -13,6 +13,7 @@ from tvidz_amd import _lib, corpus as tc, synth
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 NEVER = tc.KTH_NEVER
+WAVE_RUNS = []          # (indexed rows, queries) of every comparison that ran the one-wave lookup
 
 
 @pytest.fixture()
@@ -41,8 +42,17 @@ def _check_topk(dc, exp_rows, queries, mm, k, cap, excl=None, algo=_lib.ALGO_AUT
     out = dc.match_topk(d_q, d_off, max_len, mm, cap, k, d_exclude_ids=d_ex, workspace=ws, algo=algo | _lib.ALGO_PAIR)
     torch.cuda.synchronize()
     out = out.cpu().numpy()
-    one = dc.match_topk(d_q, d_off, max_len, mm, cap, k, d_exclude_ids=d_ex, workspace=ws, algo=algo | _lib.ALGO_NO_PAIR)
+    one = dc.match_topk(d_q, d_off, max_len, mm, cap, k, d_exclude_ids=d_ex, workspace=ws,
+                        algo=algo | _lib.ALGO_NO_PAIR | _lib.ALGO_NO_WAVE)
     assert (one.cpu().numpy() == out).all()
+    # ... and, on a handle of one sub-index, the lookup that gives every query to one WAVE (ts_match_wq_topk_kernel)
+    st = dc.index_stats()
+    if 0 < st["indexed_rows"] <= 16384 and max_len <= 512 and 1 <= mm <= 5 and k <= 64 and algo != _lib.ALGO_JOIN:
+        WAVE_RUNS.append((st["indexed_rows"], Q))
+        wv = dc.match_topk(d_q, d_off, max_len, mm, cap, k, d_exclude_ids=d_ex, workspace=ws, algo=algo | _lib.ALGO_WAVE)
+        wv = wv.cpu().numpy()
+        bad = np.flatnonzero((wv != out).reshape(Q, -1).any(axis=1))
+        assert bad.size == 0, (mm, k, cap, bad[:8], wv[bad[0]][:4], out[bad[0]][:4])
     for qi in range(Q):
         rows = exp_rows[qi]
         assert tuple(out[qi, k][[0, 2]]) == (-1, NEVER)
@@ -233,3 +243,57 @@ def test_two_queries_per_block_refusals_odd_batches_and_neighbours(dc):
                 out1 = dc.match_topk(d_q1, d_off1, ml1, mm, 4096, k, algo=_lib.ALGO_PAIR).cpu().numpy()
                 full = dc.match_topk(d_q, d_off, honest, mm, 4096, k, algo=_lib.ALGO_NO_PAIR).cpu().numpy()
                 assert (out1 == full[:Qn]).all(), (mm, k, Qn)
+
+
+def test_one_wave_lookup_on_a_shard_of_configs3(dc):
+    """ts_match_wq_topk_kernel on what a GPU of BASELINE.json configs[3] holds - rank 0's 1/8 of the 100k-video
+    table, one sub-index - against the block kernel (all queries) and the oracle (sampled), min_match 2 and 5,
+    with per-query exclusions; then with indexed rows replaced (dead postings) and a delta table behind it.
+    A handle of more than one sub-index refuses TVZ_ALGO_WAVE by name."""
+    from tvidz_amd import sharded
+    ids, offs, keys = synth.synth_timestamp_corpus(100_000, seed=synth.CORPUS_SEED)
+    s_ids, s_offs, s_keys = sharded.shard_csr(ids, offs, keys, 0, 8)
+    dc.upload_csr(s_ids, s_offs, s_keys)
+    assert dc.index_stats()["indexed_rows"] == len(s_ids) <= 16384
+    Q = 1024
+    queries = synth.synth_queries(ids, offs, keys, Q, seed=synth.CORPUS_SEED + 3)
+    d_q, d_off, max_len = tc.pack_queries(queries, DEV)
+    excl = torch.tensor([int(s_ids[(11 * i) % len(s_ids)]) for i in range(Q)], dtype=torch.int32, device=DEV)
+    rows = None
+    for phase in range(2):
+        if phase == 1:                                  # 300 indexed rows replaced, 100 rows added: a delta table
+            rng = np.random.default_rng(5)
+            for j in range(300):
+                r = int(rng.integers(0, len(s_ids)))
+                dc.upsert(int(s_ids[r]), s_keys[s_offs[r]:s_offs[r + 1]][::2].tolist())
+            for j in range(100):
+                dc.upsert(9_000_000 + j, queries[j][:50].tolist())
+            assert dc.index_stats()["delta_rows"] > 0
+        for mm in (2, 5):
+            for ex in (None, excl):
+                blk = dc.match_topk(d_q, d_off, max_len, mm, 4096, 16, d_exclude_ids=ex,
+                                    algo=_lib.ALGO_NO_WAVE | _lib.ALGO_NO_PAIR).cpu().numpy()
+                wav = dc.match_topk(d_q, d_off, max_len, mm, 4096, 16, d_exclude_ids=ex, algo=_lib.ALGO_WAVE).cpu().numpy()
+                auto = dc.match_topk(d_q, d_off, max_len, mm, 4096, 16, d_exclude_ids=ex).cpu().numpy()
+                assert (wav == blk).all() and (auto == blk).all(), (phase, mm)
+        if phase == 0:
+            rows = [(int(s_ids[r]), s_keys[s_offs[r]:s_offs[r + 1]].tolist()) for r in range(len(s_ids))]
+    # the oracle on the first phase's answer (recomputed: the handle has moved on)
+    dc.upload_csr(s_ids, s_offs, s_keys)
+    wav = dc.match_topk(d_q, d_off, max_len, 2, 4096, 16, algo=_lib.ALGO_WAVE).cpu().numpy()
+    exp = _expected_rows(rows, queries[:24], 2)
+    for qi in range(24):
+        e = sorted(exp[qi], key=lambda h: (h[2], h[0], h[1]))[:16]
+        e += [(-1, 0, NEVER)] * (16 - len(e))
+        assert [tuple(int(x) for x in r) for r in wav[qi, :16]] == e and int(wav[qi, 16, 1]) == len(exp[qi]), qi
+    big = tc.DeviceCorpus(0)
+    try:
+        big.upload_csr(*sharded.shard_csr(ids, offs, keys, 0, 4))          # 25k rows: two sub-indexes
+        with pytest.raises(RuntimeError, match="TVZ_ALGO_WAVE"):
+            big.match_topk(d_q, d_off, max_len, 2, 4096, 16, algo=_lib.ALGO_WAVE)
+    finally:
+        big.close()
+
+
+def test_the_one_wave_lookup_was_compared_in_this_module():
+    assert len(WAVE_RUNS) >= 20, WAVE_RUNS

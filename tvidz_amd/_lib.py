@@ -73,6 +73,7 @@ SIGNATURES = {
 # per-call selectors of include/tvz.h
 ALGO_AUTO, ALGO_Q1, ALGO_TILE, ALGO_JOIN, ALGO_INDEX = 0, 1, 2, 3, 4
 ALGO_PAIR, ALGO_NO_PAIR = 0x100, 0x200      # OR-ed into `algo` of the top-k calls: two queries per lookup block always / never
+ALGO_WAVE, ALGO_NO_WAVE = 0x400, 0x800      # ... one WAVE per query on a handle of one sub-index: required / never
 SHAPE_AUTO = 0
 SHAPE_NO_NT = 1 << 30
 UNIQUE_ID_BYTES = 128

@@ -60,14 +60,26 @@ struct IxBuildInfo {       // device-side build status, read back by the host
     uint32_t n_distinct;   // directory entries in use
     uint32_t failed;       // a probe sequence ran too long: directory too small, rebuild larger
     uint32_t pad;
+    // bucket directory (tvz_bucket_dir.h)
+    uint32_t ext_cursor;   // postings handed out in the external area (uint16 units, whole lines)
+    uint32_t n_spilled;    // keys that do not live in their home bucket
+    uint32_t n_ext;        // keys whose postings are external
+    uint32_t max_spill;
 };
 
 constexpr int kIxMaxProbe = 4096;
+// entries behind the last posting that the lookups may READ (and discard): the lanes of a wave's last step of 64
+// postings (ix_lookup_body), the dead steps of a live group of four (ts_match_wq_topk_kernel)
+constexpr int kIxPostPad = 64 + 256;
 #ifndef TVZ_IX_SUB_LOG2
 #define TVZ_IX_SUB_LOG2 14
 #endif
 constexpr int kSubLog2 = TVZ_IX_SUB_LOG2;            // rows per sub-index (local row numbers are uint16)
 constexpr int kSubRows = 1 << kSubLog2;
+
+}  // namespace
+#include "tvz_bucket_dir.h"
+namespace {
 
 inline int ix_ks(int n_sub) { return n_sub <= 1 ? 0 : (n_sub + 7) & ~7; }   // uint16 counts per entry
 inline int ix_entry_bytes(int ks) { return 16 + 2 * ks; }
@@ -93,7 +105,15 @@ __global__ __launch_bounds__(kBlock) void ix_clear_kernel(uint4 *__restrict__ di
     head.w = 0;
     for (size_t i = i0; i < n16; i += step) dir16[i] = (i % (size_t)es16 == 0) ? head : make_uint4(0, 0, 0, 0);
     for (size_t i = i0; i < nz16; i += step) zero16[i] = make_uint4(0, 0, 0, 0);
-    if (i0 == 0) { info->cursor = 0; info->n_distinct = 0; info->failed = 0; info->pad = 0; }
+    if (i0 == 0) { info->cursor = 0; info->n_distinct = 0; info->failed = 0; info->pad = 0;
+                   info->ext_cursor = 0; info->n_spilled = 0; info->n_ext = 0; info->max_spill = 0; }
+}
+
+// the directory slice of a key: the partition kernels' bin.  dir_bits < 0: the BUCKET directory of a one-sub-index
+// handle (tvz_bucket_dir.h) with -dir_bits buckets, slices of kBkSlice buckets
+__device__ __forceinline__ uint32_t ix_part_of(int64_t k, int dir_bits) {
+    if (dir_bits < 0) return bk_bucket(k, (uint32_t)(-dir_bits)) >> kBkSliceLog2;
+    return ix_slot(k, dir_bits & 0xff) >> (dir_bits >> 8);
 }
 
 // find (or, with INSERT, claim) the directory entry of key k; returns the slot or -1
@@ -232,7 +252,8 @@ constexpr int kIxSliceBlock = 512;
 
 __global__ void ix_part_clear_kernel(uint32_t *__restrict__ hist, int n, IxBuildInfo *info) {
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) hist[i] = 0;
-    if (blockIdx.x == 0 && threadIdx.x == 0) { info->cursor = 0; info->n_distinct = 0; info->failed = 0; info->pad = 0; }
+    if (blockIdx.x == 0 && threadIdx.x == 0) { info->cursor = 0; info->n_distinct = 0; info->failed = 0; info->pad = 0;
+                   info->ext_cursor = 0; info->n_spilled = 0; info->n_ext = 0; info->max_spill = 0; }
 }
 
 // the slices' pair counts and the rows' video ids: a block takes `rpb` consecutive rows (a wave per row,
@@ -242,7 +263,6 @@ __global__ __launch_bounds__(kBlock) void ix_partition_kernel(
     int n_parts, uint32_t *__restrict__ gcnt, int32_t *__restrict__ ivid) {
     extern __shared__ uint32_t ix_part_sh[];
     uint32_t *hist = ix_part_sh;
-    const int dir_log2 = dir_bits & 0xff, slice_log2 = dir_bits >> 8;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int i = threadIdx.x; i < n_parts; i += kBlock) hist[i] = 0;
     __syncthreads();
@@ -252,7 +272,7 @@ __global__ __launch_bounds__(kBlock) void ix_partition_kernel(
         const Row row = load_row(rows + r);
         if (lane == 0) ivid[r] = row.vid;
         for (int i = lane; i < row.len; i += 64)
-            atomicAdd(&hist[ix_slot(keys[row.off + i], dir_log2) >> slice_log2], 1u);
+            atomicAdd(&hist[ix_part_of(keys[row.off + i], dir_bits)], 1u);
     }
     __syncthreads();
     for (int i = threadIdx.x; i < n_parts; i += kBlock)
@@ -280,7 +300,6 @@ __global__ __launch_bounds__(kIxScatterBlock) void ix_scatter_kernel(
     uint32_t *lstart = hist + n_parts;                                             // [n_parts + 1] first staged pair of a slice
     uint32_t *base = lstart + n_parts + 1;                                         // [n_parts] first global pair of the block's run
     __shared__ uint32_t s_w[kIxScatterBlock / 64];
-    const int dir_log2 = dir_bits & 0xff, slice_log2 = dir_bits >> 8;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int i = threadIdx.x; i < n_parts; i += kIxScatterBlock) hist[i] = 0;
     __syncthreads();
@@ -289,7 +308,7 @@ __global__ __launch_bounds__(kIxScatterBlock) void ix_scatter_kernel(
     for (int64_t r = r0 + wave; r < r1; r += kIxScatterBlock / 64) {
         const Row row = load_row(rows + r);
         for (int i = lane; i < row.len; i += 64)
-            atomicAdd(&hist[ix_slot(keys[row.off + i], dir_log2) >> slice_log2], 1u);
+            atomicAdd(&hist[ix_part_of(keys[row.off + i], dir_bits)], 1u);
     }
     __syncthreads();
     // local and global ranges: thread t owns the slices [t * per, (t + 1) * per)
@@ -319,7 +338,7 @@ __global__ __launch_bounds__(kIxScatterBlock) void ix_scatter_kernel(
         const Row row = load_row(rows + r);
         for (int i = lane; i < row.len; i += 64) {
             const int64_t k = keys[row.off + i];
-            const uint32_t p = ix_slot(k, dir_log2) >> slice_log2;
+            const uint32_t p = ix_part_of(k, dir_bits);
             const uint32_t j = atomicAdd(&hist[p], 1u);
             const uint32_t t = lstart[p] + j;
             if (t < (uint32_t)kIxStagePairs) {
@@ -786,7 +805,7 @@ __device__ __forceinline__ void ix_lookup_body(
     uint32_t tk_bmax = 0xffffffffu;                        // TOPK: hits with kth beyond this neither (block-uniform)
 
     // ---- directory: ONE probe per query position; the counts of this block's sub-indexes to LDS ----
-    const uint32_t smask = (1u << (dir_bits >> 8)) - 1u;   // probes wrap inside the directory slice
+    const uint32_t smask = dir_bits < 0 ? 0u : (1u << (dir_bits >> 8)) - 1u;   // probes wrap inside the directory slice
     const int es = 16 + 2 * ks;
     for (int i = threadIdx.x; i < n_all; i += kIxBlock) {
         uint32_t base = 0, total = 0;
@@ -795,6 +814,11 @@ __device__ __forceinline__ void ix_lookup_body(
         // (position i of the block = position i of its first query, or i - n_[0] of its second)
         const int64_t kq = NQ == 1 || i < n_[0] ? qo_[0] + i : qo_[NQ - 1] + (i - n_[0]);
         if (canon_key(byval ? qv->k[i] : queries[kq], k)) {               // NaN never matches
+            if (dir_bits < 0) {                                              // the bucket directory of a one-sub-index handle
+                const BkHit hb = bk_find(dir, (uint32_t)(-dir_bits), k);
+                base = hb.base;
+                total = hb.n;
+            } else {
             uint32_t s = ix_slot(k, dir_log2);
             for (int probes = 0; probes < kIxMaxProbe; ++probes) {
                 const unsigned char *e = dir + (size_t)s * es;
@@ -803,6 +827,7 @@ __device__ __forceinline__ void ix_lookup_body(
                 if (ek == k) { base = (uint32_t)h.z; total = (uint32_t)h.w; ent = e; break; }
                 if (ek == kEmpty) break;
                 s = (s & ~smask) | ((s + 1) & smask);
+            }
             }
         }
         uint16_t *el = e_len_all + (size_t)i * nsb;

@@ -30,6 +30,7 @@
 
 #include "tvz_match_kernels.h"
 #include "tvz_index_kernels.h"
+#include "tvz_index_wave_kernels.h"
 
 namespace {
 
@@ -94,6 +95,10 @@ constexpr int kIxSliceLdsFloor = 40 * 1024;         // LDS asked for per slice b
 // <= 0.5: 60.4, <= 0.25: 57.7, <= 0.12: 57.8 (full corpus 347 -> 341 us).  Memory is not the constraint
 // (64 MB of directory at config 4 on a 288 GB device).
 constexpr int kIxDirLoadPct = 25;
+#ifndef TVZ_BK_FILL_PCT
+#define TVZ_BK_FILL_PCT 35
+#endif
+constexpr int kBkFillPct = TVZ_BK_FILL_PCT;       // bucket directory (one-sub-index handles): payload bytes in use, target
 constexpr int64_t kIndexMinRows = 4096;           // a corpus grown by upserts gets its first index here
 constexpr int64_t kIndexMinDelta = 512;           // rebuilt when the delta exceeds max(this, n_main / 256)
 
@@ -107,11 +112,16 @@ struct IndexBuf {
     DevBuf<Row> drows;                // the delta table that goes with this generation
     int dir_log2 = 0;
     int slice_log2 = 0;               // entries per directory slice (probing wraps inside a slice)
-    int dir_bits() const { return ix_dir_bits(dir_log2, slice_log2); }   // the kernels' argument
+    // A handle of ONE sub-index keeps the BUCKET directory of tvz_bucket_dir.h: nb buckets of 128 bytes - a key's
+    // entry and its postings in one line - + the external lists behind them, all in `dir`; `post` is unused.
+    uint32_t nb = 0;
+    int dir_bits() const { return nb ? -(int)nb : ix_dir_bits(dir_log2, slice_log2); }   // the kernels' argument
+    const uint16_t *post_ptr() const { return nb ? reinterpret_cast<const uint16_t *>(dir.p) : post.p; }
     int n_sub = 0;                    // sub-indexes of kSubRows rows
     int ks = 0;                       // uint16 counts per directory entry
     int64_t n_main = 0;               // rows [0, n_main) are indexed
     int64_t n_post = 0, n_distinct = 0;
+    int64_t n_spilled = 0, n_ext = 0, max_spill = 0;   // bucket directory: keys outside their home bucket / with external lists
 };
 
 struct Index {
@@ -378,8 +388,7 @@ int build_kernels(tvz_corpus *c, IndexBuf &b, const Row *d_rows, int64_t n_rows,
     const int ks = ix_ks(n_sub), es = ix_entry_bytes(ks);
     // (+64: the lookup's last step reads up to 63 postings past the last list and discards them; x2 +
     // a line per size class and slice: the partitioned build pads keys to line-friendly places)
-    const int64_t post_cap = 2 * std::max<int64_t>(keys_cap, live_keys) + (int64_t)kIxMaxParts * kIxClasses * 64 + 64;
-    if (int rc = ensure(b.post, post_cap, 0)) return rc;
+    const int64_t post_cap = 2 * std::max<int64_t>(keys_cap, live_keys) + (int64_t)kIxMaxParts * kIxClasses * 64 + kIxPostPad;
     if (int rc = ensure(b.ivid, std::max<int64_t>(rows_cap, n_rows), 0)) return rc;
     if (int rc = ensure(b.drows, delta_capacity(std::max<int64_t>(rows_cap, n_rows)), 0)) return rc;
     // ONE directory over the distinct keys of all rows, load <= 0.25 (kIxDirLoadPct).  Sized from a guess -
@@ -400,6 +409,87 @@ int build_kernels(tvz_corpus *c, IndexBuf &b, const Row *d_rows, int64_t n_rows,
         if (!partitionable(lg) && partitionable(lg - 1) && (double)((int64_t)1 << (lg - 1)) >= 2.0 * distinct) --lg;
         return lg;
     };
+    b.nb = 0;
+    if (n_sub == 1) {
+        // ---- one sub-index: the bucket directory (tvz_bucket_dir.h) ----
+        // bytes the records need: 8 per distinct key + 2 per posting; buckets for a fill of kBkFillPct % of their
+        // payload.  Fuller: more lists do not fit beside their bucket's other records and move to the external area -
+        // a second line for every lookup that asks for them, and the long lists are the ones asked for most; emptier:
+        // a larger table.  The distinct keys are known from the last build, else guessed and the build repeated once
+        // at the size the count revealed.
+        const int64_t pairs_cap = std::max<int64_t>(keys_cap, live_keys);
+        const int64_t ext_cap16 = 2 * pairs_cap + 64 * 1024;              // external lists: whole lines, lists of > 40 postings only
+        auto buckets_for = [&](double distinct) {
+            const double bytes = 8.0 * distinct + 2.0 * (double)live_keys;
+            const int64_t want = (int64_t)(bytes * 100.0 / ((double)kBkFillPct * kBkPayload)) + 1;
+            return (uint32_t)std::min<int64_t>(tvz::round_up(std::max<int64_t>(want, kBkSlice), kBkSlice), (int64_t)kIxMaxParts * kBkSlice);
+        };
+        double distinct = ix.hint_post > 0 ? (double)ix.hint_distinct * (double)live_keys / (double)ix.hint_post * 1.1
+                                           : (double)live_keys / 4.0;
+        uint32_t nb = buckets_for(distinct);
+        bool resized = false, ok = false;
+        if (int rc = ensure(ix.pkeys, pairs_cap, 0)) return rc;
+        if (int rc = ensure(ix.prows, pairs_cap, 0)) return rc;
+        if (int rc = ensure(ix.pcnt, 6 * (int64_t)kIxMaxParts + 8, 0)) return rc;
+        IxBuildInfo info{};
+        for (int attempt = 0; attempt < 8; ++attempt) {
+            const int64_t n_parts = nb / kBkSlice;
+            const int64_t dir_bytes = (int64_t)nb * kBkBytes + 2 * (ext_cap16 + kIxPostPad);
+            if (int rc = ensure(b.dir, dir_bytes, 0)) return rc;
+            uint32_t *cnt = ix.pcnt.p, *start = cnt + kIxMaxParts, *cur = start + kIxMaxParts + 1;
+            const int bits = -(int)nb;
+            const int64_t mean_len = std::max<int64_t>(1, live_keys / n_rows);
+            const int32_t rpb = (int32_t)std::min<int64_t>(4096, std::max<int64_t>(kBlock / 64 * 2, 16 * n_parts / mean_len));
+            hipLaunchKernelGGL(ix_part_clear_kernel, dim3(4), dim3(kBlock), 0, st, cnt, (int)n_parts, ix.info);
+            hipLaunchKernelGGL(ix_partition_kernel, dim3((unsigned)tvz::ceil_div(n_rows, rpb)), dim3(kBlock), (size_t)n_parts * 4, st,
+                               d_rows, n_rows, rpb, c->keys.p, bits, (int)n_parts, cnt, b.ivid.p);
+            hipLaunchKernelGGL(ix_part_scan_kernel, dim3(1), dim3(1024), 0, st, cnt, (int)n_parts, start, cur, ix.info);
+            const int32_t srpb = (int32_t)std::max<int64_t>(1, kIxStagePairs / mean_len);
+            const size_t sclds = (size_t)kIxStagePairs * 12 + ((size_t)3 * n_parts + 1) * 4;
+            hipLaunchKernelGGL(ix_scatter_kernel, dim3((unsigned)tvz::ceil_div(n_rows, srpb)), dim3(kIxScatterBlock), sclds,
+                               st, d_rows, n_rows, srpb, c->keys.p, bits, (int)n_parts, cur, ix.pkeys.p, ix.prows.p);
+            hipLaunchKernelGGL(bk_slice_build_kernel, dim3((unsigned)n_parts), dim3(kBkBuildBlock), kBkBuildLds, st,
+                               ix.pkeys.p, ix.prows.p, start, b.dir.p, nb, (uint32_t)std::min<int64_t>(ext_cap16, 0x7fffffffLL), ix.info);
+            TVZ_HIP(hipGetLastError());
+            TVZ_HIP(hipMemcpyAsync(ix.h_info, ix.info, sizeof(info), hipMemcpyDeviceToHost, st));
+            if (int rc = wait_stream_polling(st, ix.build_ev)) return rc;
+            info = *ix.h_info;
+            if (!info.failed) {
+                const uint32_t fit = buckets_for((double)info.n_distinct);
+                // (a first build that guessed the distinct keys: once more at the right size if it is off by a quarter)
+                if (!resized && (fit > nb + nb / 4 || fit + fit / 4 < nb)) { nb = fit; resized = true; continue; }
+                ok = true;
+                break;
+            }
+            if (nb >= (uint32_t)kIxMaxParts * kBkSlice) break;            // too many keys for slices of 256 buckets: classic format
+            nb = (uint32_t)std::min<int64_t>(tvz::round_up((int64_t)nb + nb / 2, kBkSlice), (int64_t)kIxMaxParts * kBkSlice);
+        }
+        if (ok) {
+            if ((int64_t)info.cursor != live_keys)
+                return tvz::fail(TVZ_ERR_INVALID, "internal: index holds %u postings for %lld keys", info.cursor,
+                                 (long long)live_keys);
+            b.nb = nb;
+            b.slice_log2 = 0;
+            b.n_sub = 1;
+            b.ks = 0;
+            b.dir_log2 = 0;
+            b.n_main = n_rows;
+            b.n_post = info.cursor;
+            b.n_distinct = info.n_distinct;
+            b.n_spilled = info.n_spilled;
+            b.n_ext = info.n_ext;
+            b.max_spill = info.max_spill;
+            ix.hint_post = (int64_t)info.cursor;
+            ix.hint_distinct = (int64_t)info.n_distinct;
+            if (getenv("TVZ_DEBUG"))
+                fprintf(stderr, "[tvz] bucket directory: %u buckets (%.1f MB) for %u keys / %u postings, fill %.2f, %u keys walked on "
+                        "(max %u buckets), %u external lists (%.1f MB)\n", nb, nb * 128e-6, info.n_distinct, info.cursor,
+                        (8.0 * info.n_distinct + 2.0 * info.cursor) / ((double)nb * kBkPayload), info.n_spilled, info.max_spill,
+                        info.n_ext, info.ext_cursor * 2e-6);
+            return TVZ_OK;
+        }
+    }
+    if (int rc = ensure(b.post, post_cap, 0)) return rc;
     int log2 = 10;
     if (ix.hint_post > 0) {
         // the last build knows how often this corpus repeats its keys: one pass, no retry
@@ -525,7 +615,7 @@ int build_index(tvz_corpus *c) {
     // flight would wait for them)
     IndexBuf &o = ix.buf[ix.cur ^ 1];
     const IndexBuf &n = ix.buf[ix.cur];
-    const int64_t dir_bytes = ((int64_t)1 << n.dir_log2) * ix_entry_bytes(n.ks);
+    const int64_t dir_bytes = n.nb ? n.dir.cap / 2 : ((int64_t)1 << n.dir_log2) * ix_entry_bytes(n.ks);
     (void)ensure(o.dir, 2 * dir_bytes, 0);         // room for the directory to double once
     if (n.slice_log2 == n.dir_log2)                // the unpartitioned build's cursors
         (void)ensure(ix.fillc, 2 * (((int64_t)1 << n.dir_log2) * (n.ks ? n.ks / 2 : 1)), 0);
@@ -1001,7 +1091,7 @@ int launch_index(tvz_corpus *c, const double *d_queries, const int64_t *d_q_offs
     const size_t lds = ix_lds_bytes(max_query_len, spb);
 #define TVZ_IX(MODE)                                                                                        \
     hipLaunchKernelGGL((ts_match_index_kernel<HOSTOUT, MODE>), dim3((unsigned)Q, (unsigned)groups),          \
-                       dim3(kIxBlock), lds, st, ix.dir.p, ix.dir_bits(), ix.ks, ix.post.p, ix.ivid.p, ix.n_main, \
+                       dim3(kIxBlock), lds, st, ix.dir.p, ix.dir_bits(), ix.ks, ix.post_ptr(), ix.ivid.p, ix.n_main, \
                        ix.n_sub, spb, d_queries, d_q_offsets, max_query_len, min_match, d_exclude_ids,        \
                        exclude_one, cap, d_hits, d_hits_n, ns, byval ? *byval : kNoQuery)
     if (min_match <= 2) TVZ_IX(kIxM2);
@@ -1037,6 +1127,24 @@ int launch_index_topk(tvz_corpus *c, const double *d_queries, const int64_t *d_q
                       int32_t max_query_len, int32_t min_match, const int32_t *d_exclude_ids, int32_t cap,
                       int32_t k, int32_t *d_block, int32_t flags, hipStream_t st) {
     const IndexBuf &ix = c->ix.now();
+    // A handle of ONE sub-index (a rank's share of an 8-way sharded 100k-video table) and queries of up to 512
+    // timestamps: one WAVE per query (tvz_index_wave_kernels.h) - no barriers, every probe of the query in flight at
+    // once, the postings in registers between the passes.
+    const bool wave_fits = ix.n_sub == 1 && ix.nb > 0 && max_query_len <= kWqMaxLen;
+    if ((flags & TVZ_ALGO_WAVE) && !wave_fits)
+        return tvz::fail(TVZ_ERR_UNSUPPORTED, "TVZ_ALGO_WAVE: the one-wave lookup takes a handle of one sub-index (this one: %d) "
+                         "and queries of up to %d timestamps (max_query_len %d)", ix.n_sub, kWqMaxLen, max_query_len);
+    if (wave_fits && !(flags & (TVZ_ALGO_NO_WAVE | TVZ_ALGO_PAIR))) {
+        const size_t lds = wq_lds_bytes(max_query_len);
+#define TVZ_WQK(MODE)                                                                                        \
+    hipLaunchKernelGGL((ts_match_wq_topk_kernel<MODE>), dim3((unsigned)Q), dim3(64), lds, st, ix.dir.p,        \
+                       ix.dir_bits(), ix.post_ptr(), ix.ivid.p, ix.n_main, d_queries, d_q_offsets, Q, max_query_len, \
+                       min_match, d_exclude_ids, cap, k, d_block)
+        if (min_match <= 2) TVZ_WQK(kIxM2); else TVZ_WQK(kIxTop5);
+#undef TVZ_WQK
+        TVZ_HIP(hipGetLastError());
+        return TVZ_OK;
+    }
     // Two queries per block - their directory probes share the block's one probe phase (profiles/r4_pair.txt) -
     // when the LDS of both still leaves four blocks on a CU, and when half as many blocks still fill the chip
     // (256 CUs x 4 blocks: below that a batch is one round of blocks, and blocks twice as long would only make it
@@ -1050,7 +1158,7 @@ int launch_index_topk(tvz_corpus *c, const double *d_queries, const int64_t *d_q
     const unsigned grid = pair ? (unsigned)((Q + 1) / 2) : (unsigned)Q;
 #define TVZ_IXK(MODE, NQ)                                                                                   \
     hipLaunchKernelGGL((ts_match_index_topk_kernel<MODE, NQ>), dim3(grid), dim3(kIxBlock), lds, st,           \
-                       ix.dir.p, ix.dir_bits(), ix.ks, ix.post.p, ix.ivid.p, ix.n_main, ix.n_sub, d_queries,   \
+                       ix.dir.p, ix.dir_bits(), ix.ks, ix.post_ptr(), ix.ivid.p, ix.n_main, ix.n_sub, d_queries,   \
                        d_q_offsets, Q, max_query_len, min_match, d_exclude_ids, cap, k, d_block)
     if (pair) { if (min_match <= 2) TVZ_IXK(kIxM2, 2); else TVZ_IXK(kIxTop5, 2); }
     else { if (min_match <= 2) TVZ_IXK(kIxM2, 1); else TVZ_IXK(kIxTop5, 1); }
@@ -1285,8 +1393,9 @@ int tvz_match_topk_local(tvz_corpus *c, const double *d_queries, const int64_t *
                          void *hip_stream, int32_t **gathered_out) {
     if (int rc = check_batch_args(c, d_queries, d_q_offsets, Q, max_query_len, cap)) return rc;
     TVZ_REQUIRE(k >= 1 && k <= kSortCap / 2, "k=%d out of range [1, %d]", k, kSortCap / 2);
-    const int32_t flags = algo & (TVZ_ALGO_PAIR | TVZ_ALGO_NO_PAIR);      // shape of the fused lookup (tvz.h)
-    algo &= ~(TVZ_ALGO_PAIR | TVZ_ALGO_NO_PAIR);
+    constexpr int32_t kShape = TVZ_ALGO_PAIR | TVZ_ALGO_NO_PAIR | TVZ_ALGO_WAVE | TVZ_ALGO_NO_WAVE;
+    const int32_t flags = algo & kShape;                                  // shape of the fused lookup (tvz.h)
+    algo &= ~kShape;
     if (Q == 0) return TVZ_OK;
     TVZ_REQUIRE(d_workspace != nullptr, "d_workspace is NULL");
     const WsLayout w = ws_layout(d_workspace, Q, max_query_len, cap, k, n_ranks);
@@ -1297,6 +1406,14 @@ int tvz_match_topk_local(tvz_corpus *c, const double *d_queries, const int64_t *
     DeviceGuard dg(c->device);
     hipStream_t st = reinterpret_cast<hipStream_t>(hip_stream);
     std::shared_lock<std::shared_mutex> lk(c->mu);
+    if (flags & TVZ_ALGO_WAVE) {          // asked for by name: say why not, instead of quietly taking another path
+        const bool fits = c->ix.valid && c->ix.now().n_sub == 1 && c->ix.now().nb > 0 && max_query_len <= kWqMaxLen && min_match >= 1 &&
+                          min_match <= kTop && k <= kIxTkMaxK && (algo == TVZ_ALGO_AUTO || algo == TVZ_ALGO_INDEX);
+        if (!fits)
+            return tvz::fail(TVZ_ERR_UNSUPPORTED, "TVZ_ALGO_WAVE: the one-wave lookup takes an indexed handle of ONE sub-index "
+                             "(this one: %d), queries of up to %d timestamps (max_query_len %d), min_match 1..5, k <= %d",
+                             c->ix.valid ? c->ix.now().n_sub : 0, kWqMaxLen, max_query_len, kIxTkMaxK);
+    }
     if ((algo == TVZ_ALGO_AUTO || algo == TVZ_ALGO_INDEX) && index_topk_usable(c, Q, max_query_len, min_match, k)) {
         // the lookup keeps the k best itself: no hit list, no top-k launch.  Rows added or replaced since
         // the build are swept as usual; their block and the lookup's are merged (k + 1 rows each).
@@ -1387,6 +1504,12 @@ static int tvz_corpus_create_impl(tvz_corpus **out, int device) {
                                 hipFuncAttributeMaxDynamicSharedMemorySize, kIxMaxLds))
     TVZ_IXK_ATTR(kIxM2, 1); TVZ_IXK_ATTR(kIxTop5, 1); TVZ_IXK_ATTR(kIxM2, 2); TVZ_IXK_ATTR(kIxTop5, 2);
 #undef TVZ_IXK_ATTR
+    TVZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(ts_match_wq_topk_kernel<kIxM2>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)wq_lds_bytes(kWqMaxLen)));
+    TVZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(ts_match_wq_topk_kernel<kIxTop5>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)wq_lds_bytes(kWqMaxLen)));
+    TVZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(bk_slice_build_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBkBuildLds));
     TVZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(ix_slice_count_kernel),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)kIxSliceBytesMax));
     TVZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(ix_slice_fill_kernel),
@@ -1890,7 +2013,7 @@ static int tvz_find_duplicates_impl(tvz_corpus *c, const double *h_query, int64_
                             static const QByVal kNoQuery = {};
 #define TVZ_FUSED(TOP5)                                                                                               \
     hipLaunchKernelGGL((ts_find_fused_kernel<TOP5>), dim3((unsigned)(n_sub + blocks)), dim3(kIxBlock), lds, s->stream, \
-                       ib.dir.p, ib.dir_bits(), ib.ks, ib.post.p, ib.ivid.p, ib.n_main, ib.n_sub, 1, n_sub, dq, dqo,       \
+                       ib.dir.p, ib.dir_bits(), ib.ks, ib.post_ptr(), ib.ivid.p, ib.n_main, ib.n_sub, 1, n_sub, dq, dqo,       \
                        (int32_t)n, min_match, excl, s->dh_ix_hits, s->dh_counts + kQ1MaxBlocks, span.p, span.n,         \
                        c->keys.p, s_log2, ho, by_value ? qv : kNoQuery)
                             if (min_match <= 2) TVZ_FUSED(false); else TVZ_FUSED(true);
