@@ -231,12 +231,28 @@ int tvz_corpus_index_stats(tvz_corpus *c, int64_t *n_indexed_rows, int64_t *n_de
  * the batch does not fit it).  Same results either way. */
 #define TVZ_ALGO_WAVE 0x400
 #define TVZ_ALGO_NO_WAVE 0x800
+/* Which of the two is faster depends on what else the GPU is doing: ONE batch alone is answered sooner by the block
+ * kernel (59 against 72 us for 4,096 queries on a 12.5k-row shard: all waves of the wave kernel start their probe
+ * bursts together), a STREAM of batches - two or three in flight on their own streams, what tvz_match_sharded's
+ * callers run - by the wave kernel, which executes a third fewer instructions (40 against 42 us per batch).  The
+ * default is the block kernel; _PREFER_WAVE takes the wave kernel wherever it fits and says nothing where it
+ * does not (sharded.RcclShardedMatcher sets it). */
+#define TVZ_ALGO_PREFER_WAVE 0x1000
 
 /* Scratch for the batched calls below.  k = 0 for tvz_match (tables of the hash join only);
  * k > 0 adds the hit lists + per-shard top-k block of tvz_match_topk / tvz_match_sharded
  * (and n_ranks gathered blocks for the latter; pass n_ranks = 1 otherwise). */
 size_t tvz_match_workspace_bytes(int32_t Q, int32_t max_query_len, int32_t cap, int32_t k,
                                  int32_t n_ranks);
+/* ... for a batch that holds queries of MORE than 4,095 timestamps (inspector/db.py:87 has no limit).  Such a query
+ * is swept on its own: its sorted distinct keys and their multiplicities are made ON THE DEVICE, in a tail of this
+ * workspace - the call allocates nothing and synchronises once (the host has to read the query offsets to learn
+ * which queries are long).  tvz_match_workspace_bytes has room for ONE query of max_query_len keys;
+ * total_query_keys = the key count of the whole batch (the length of d_queries) makes room for any split of it
+ * into long queries.  A call whose workspace is too small for its long queries returns TVZ_ERR_WORKSPACE and says
+ * how many bytes they need. */
+size_t tvz_match_workspace_bytes_long(int32_t Q, int32_t max_query_len, int32_t cap, int32_t k,
+                                      int32_t n_ranks, int64_t total_query_keys);
 
 /* Batched, device-resident form.
  *   d_queries   : float64 keys of all queries back to back

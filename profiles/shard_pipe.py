@@ -25,7 +25,7 @@ batches = [tc.pack_queries(synth.synth_queries(ids, offs, keys, Q, seed=synth.CO
 ml = max(b[2] for b in batches)
 comm = sharded.make_comm(0)
 res = {}
-shapes = {"auto": 0, "block": _lib.ALGO_NO_WAVE}
+shapes = {"auto": 0, "block": _lib.ALGO_NO_WAVE}      # (auto: RcclShardedMatcher adds ALGO_PREFER_WAVE)
 if dc.index_stats()["indexed_rows"] <= 16384:
     shapes["wave"] = _lib.ALGO_WAVE
 for name, fl in shapes.items():

@@ -26,6 +26,7 @@ static double now_us(void) {
 int main(int argc, char **argv) {
     if (argc < 2) { fprintf(stderr, "usage: %s <file> [depth] [steps]\n", argv[0]); return 2; }
     const int depth = argc > 2 ? atoi(argv[2]) : 3, steps = argc > 3 ? atoi(argv[3]) : 200;
+    const int shape = argc > 4 ? (int)strtol(argv[4], NULL, 0) : 0;     /* TVZ_ALGO_WAVE 0x400 / TVZ_ALGO_NO_WAVE 0x800 / ... */
     if (depth < 1 || depth > MAXD) return 2;
     FILE *f = fopen(argv[1], "rb");
     if (!f) { perror(argv[1]); return 1; }
@@ -60,7 +61,7 @@ int main(int argc, char **argv) {
         HIPCHECK(hipMalloc((void **)&d_top[i], (size_t)Q * K * 3 * 4)); HIPCHECK(hipMalloc((void **)&d_tot[i], (size_t)Q * 4));
     }
 #define SUBMIT(i) do { CHECK(tvz_match_sharded(c, comm, d_q, d_off, (int32_t)Q, (int32_t)max_len, 2, NULL, CAP, K, d_top[i], d_tot[i], \
-                                               d_ws[i], ws, TVZ_ALGO_AUTO, st[i])); HIPCHECK(hipEventRecord(ev[i], st[i])); } while (0)
+                                               d_ws[i], ws, TVZ_ALGO_AUTO | shape, st[i])); HIPCHECK(hipEventRecord(ev[i], st[i])); } while (0)
     for (int w = 0; w < 2 * depth; w++) { SUBMIT(w % depth); }
     HIPCHECK(hipDeviceSynchronize());
     double t_submit = 0, t_wait = 0;

@@ -20,5 +20,5 @@ with open("/tmp/shard_pipeline.bin", "wb") as f:
 PY
 gcc -O2 -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -Iinclude profiles/shard_pipeline.c -o /tmp/shard_pipeline -Ltvidz_amd -ltvz \
     -L/opt/rocm/lib -lamdhip64 -lm -Wl,-rpath,$REPO/tvidz_amd -Wl,-rpath,/opt/rocm/lib || exit 1
-for d in 1 2 3 4; do /tmp/shard_pipeline /tmp/shard_pipeline.bin $d 300 2>/dev/null | tail -1; done
+for sh in 0 0x800; do for d in 1 2 3 4; do echo -n "shape $sh: "; /tmp/shard_pipeline /tmp/shard_pipeline.bin $d 300 $sh 2>/dev/null | tail -1; done; done
 for d in 2 3; do python3 profiles/shard_trace.py $N $Q 300 $d - $d 2>/dev/null | tail -1; done

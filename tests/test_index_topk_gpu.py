@@ -274,7 +274,7 @@ def test_one_wave_lookup_on_a_shard_of_configs3(dc):
                 blk = dc.match_topk(d_q, d_off, max_len, mm, 4096, 16, d_exclude_ids=ex,
                                     algo=_lib.ALGO_NO_WAVE | _lib.ALGO_NO_PAIR).cpu().numpy()
                 wav = dc.match_topk(d_q, d_off, max_len, mm, 4096, 16, d_exclude_ids=ex, algo=_lib.ALGO_WAVE).cpu().numpy()
-                auto = dc.match_topk(d_q, d_off, max_len, mm, 4096, 16, d_exclude_ids=ex).cpu().numpy()
+                auto = dc.match_topk(d_q, d_off, max_len, mm, 4096, 16, d_exclude_ids=ex, algo=_lib.ALGO_PREFER_WAVE).cpu().numpy()
                 assert (wav == blk).all() and (auto == blk).all(), (phase, mm)
         if phase == 0:
             rows = [(int(s_ids[r]), s_keys[s_offs[r]:s_offs[r + 1]].tolist()) for r in range(len(s_ids))]
@@ -291,6 +291,8 @@ def test_one_wave_lookup_on_a_shard_of_configs3(dc):
         big.upload_csr(*sharded.shard_csr(ids, offs, keys, 0, 4))          # 25k rows: two sub-indexes
         with pytest.raises(RuntimeError, match="TVZ_ALGO_WAVE"):
             big.match_topk(d_q, d_off, max_len, 2, 4096, 16, algo=_lib.ALGO_WAVE)
+        a = big.match_topk(d_q, d_off, max_len, 2, 4096, 16, algo=_lib.ALGO_PREFER_WAVE)      # ... a preference is not an error
+        assert (a == big.match_topk(d_q, d_off, max_len, 2, 4096, 16)).all()
     finally:
         big.close()
 

@@ -47,6 +47,7 @@ SIGNATURES = {
     "tvz_corpus_stats": (C.c_int, [_P, C.POINTER(C.c_int64), C.POINTER(C.c_int64),
                                    C.POINTER(C.c_int64)]),
     "tvz_match_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
+    "tvz_match_workspace_bytes_long": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int64]),
     "tvz_match": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, C.c_int32, _P, C.c_int32, _P, _P, _P,
                             C.c_size_t, C.c_int32, _P]),
     "tvz_match_topk": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, C.c_int32, _P, C.c_int32, C.c_int32,
@@ -74,6 +75,7 @@ SIGNATURES = {
 ALGO_AUTO, ALGO_Q1, ALGO_TILE, ALGO_JOIN, ALGO_INDEX = 0, 1, 2, 3, 4
 ALGO_PAIR, ALGO_NO_PAIR = 0x100, 0x200      # OR-ed into `algo` of the top-k calls: two queries per lookup block always / never
 ALGO_WAVE, ALGO_NO_WAVE = 0x400, 0x800      # ... one WAVE per query on a handle of one sub-index: required / never
+ALGO_PREFER_WAVE = 0x1000                   # ... wherever it fits (a stream of batches in flight: fewer instructions per batch)
 SHAPE_AUTO = 0
 SHAPE_NO_NT = 1 << 30
 UNIQUE_ID_BYTES = 128

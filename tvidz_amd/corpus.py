@@ -36,8 +36,15 @@ def _ptr(a: Optional[np.ndarray]):
     return None if a is None or a.size == 0 else C.c_void_p(a.ctypes.data)
 
 
-def workspace_bytes(Q: int, max_query_len: int, cap: int = 0, k: int = 0, n_ranks: int = 1) -> int:
-    """tvz_match_workspace_bytes: scratch of the batched calls (k = 0: the hash-join tables only)."""
+def workspace_bytes(Q: int, max_query_len: int, cap: int = 0, k: int = 0, n_ranks: int = 1,
+                    total_query_keys: int = 0) -> int:
+    """tvz_match_workspace_bytes: scratch of the batched calls (k = 0: the hash-join tables only).
+    `total_query_keys` (the length of d_queries) matters for a batch that holds queries of more than 4,095
+    timestamps: their sorted distinct keys are made on the device in a tail of the workspace
+    (tvz_match_workspace_bytes_long)."""
+    if max_query_len > 4095 and total_query_keys:
+        return int(_lib.load().tvz_match_workspace_bytes_long(int(Q), int(max_query_len), int(cap), int(k),
+                                                              int(n_ranks), int(total_query_keys)))
     return int(_lib.load().tvz_match_workspace_bytes(int(Q), int(max_query_len), int(cap), int(k),
                                                      int(n_ranks)))
 
@@ -184,7 +191,7 @@ class DeviceCorpus:
         if out_n is None:
             out_n = torch.empty(Q, dtype=torch.int32, device=dev)
         s = stream if stream is not None else torch.cuda.current_stream(dev)
-        ws = self._workspace(workspace, workspace_bytes(Q, max_query_len), dev, s)
+        ws = self._workspace(workspace, workspace_bytes(Q, max_query_len, total_query_keys=d_queries.numel()), dev, s)
         _lib.check(self.lib.tvz_match(
             self._h, d_queries.data_ptr(), d_q_offsets.data_ptr(), Q, int(max_query_len),
             int(min_match), d_exclude_ids.data_ptr() if d_exclude_ids is not None else None,
@@ -202,7 +209,7 @@ class DeviceCorpus:
         if out is None:
             out = torch.empty((Q, k + 1, 3), dtype=torch.int32, device=dev)
         s = stream if stream is not None else torch.cuda.current_stream(dev)
-        ws = self._workspace(workspace, workspace_bytes(Q, max_query_len, cap, k), dev, s)
+        ws = self._workspace(workspace, workspace_bytes(Q, max_query_len, cap, k, total_query_keys=d_queries.numel()), dev, s)
         _lib.check(self.lib.tvz_match_topk(
             self._h, d_queries.data_ptr(), d_q_offsets.data_ptr(), Q, int(max_query_len),
             int(min_match), d_exclude_ids.data_ptr() if d_exclude_ids is not None else None,
@@ -261,7 +268,7 @@ class Comm:
             merged = torch.empty((Q, k, 3), dtype=torch.int32, device=dev)
             totals = torch.empty(Q, dtype=torch.int32, device=dev)
         s = stream if stream is not None else torch.cuda.current_stream(dev)
-        ws = corpus._workspace(workspace, workspace_bytes(Q, max_query_len, cap, k, self.n_ranks), dev, s)
+        ws = corpus._workspace(workspace, workspace_bytes(Q, max_query_len, cap, k, self.n_ranks, d_queries.numel()), dev, s)
         _lib.check(self.lib.tvz_match_sharded(
             corpus._h, self._h, d_queries.data_ptr(), d_q_offsets.data_ptr(), Q, int(max_query_len),
             int(min_match), d_exclude_ids.data_ptr() if d_exclude_ids is not None else None,

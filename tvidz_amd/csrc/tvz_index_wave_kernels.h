@@ -18,7 +18,8 @@
 //     the (row, position) cache of the block kernel costs 16 KiB of LDS per query);
 //   * pass A (row bitmaps seen1 / seen2), rank, slots, pass B (count + smallest positions per candidate), the
 //     kth histogram and the kept-hit list are those of the block kernel, by one wave.
-// ~16 KiB of LDS per wave: ten waves per CU, each with 200+ probes and up to 16 posting loads in flight.
+// ~14 KiB of LDS per wave and <= 168 VGPRs: eleven waves per CU, each with 200+ probes and up to 64 posting loads
+// in flight.
 // Results are identical to ts_match_index_topk_kernel (tests/test_index_topk_gpu.py runs both on the same handle).
 #pragma once
 #include "tvz_index_kernels.h"
@@ -29,7 +30,7 @@ constexpr int kWqChunks = 8;                         // chunks of 64 query posit
 constexpr int kWqMaxLen = kWqChunks * 64;            // longest query this kernel takes
 constexpr int kWqSteps = 64;                         // register-resident steps of 64 postings
 constexpr int kWqRegPost = kWqSteps * 64;            // postings kept in registers between the passes
-constexpr int kWqSlots = 512;                        // candidate slots per part
+constexpr int kWqSlots = 512;                        // candidate slots per part (384: 12 waves per CU instead of 11, but every sixth query of the 1/8 shard took two parts - no faster)
 constexpr int kWqPosShift = kSubLog2;                // register entry = row | position << 14
 static_assert(kSubLog2 + 9 <= 32 && kWqMaxLen <= 512, "packed register entries");
 constexpr size_t kWqTkBytes = (size_t)kIxTkCap * 8 + (size_t)kIxTkBins * 4 + 16;   // (16: the list table behind it stays 16-byte aligned)
@@ -37,10 +38,8 @@ constexpr size_t kWqTkBytes = (size_t)kIxTkCap * 8 + (size_t)kIxTkBins * 4 + 16;
 // dynamic LDS of one wave (bytes), by the longest query of the batch
 inline size_t wq_lds_bytes(int max_len) {
     const size_t L = (size_t)((max_len > 0 ? max_len : 1) + 1) & ~(size_t)1;
-    return (size_t)2 * kIxWords * 4        /* seen1, seen2 */
-           + (size_t)kIxWords * 2          /* rank */
+    return (size_t)2 * kIxWords * 4        /* seen1, seen2; behind pass A the one that is not the candidates' holds rank + slot rows */
            + (size_t)kWqSlots * 12         /* count + smallest positions */
-           + (size_t)kWqSlots * 2          /* row of slot k */
            + (size_t)kWqRegPost / 8        /* list-start bitmap */
            + kWqTkBytes                    /* kept hits, kth histogram, fill */
            + L * 8;                        /* non-empty lists */
@@ -73,9 +72,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
     uint32_t *kh = reinterpret_cast<uint32_t *>(tkb + kIxTkCap);                     // hits per kth bin
     uint32_t *tk_n = kh + kIxTkBins;                                                 // entries in tkb (+ one pad word)
     uint2 *lst = reinterpret_cast<uint2 *>(tk_n + 4);                                // non-empty list j = {first posting - local start, position}
-    const int L = ((max_len > 0 ? max_len : 1) + 1) & ~1;
-    uint16_t *rank = reinterpret_cast<uint16_t *>(lst + L);                          // candidates before bitmap word j
+    // rank (candidates before bitmap word j) and the rows of the part's slots live in the bitmap that is NOT the
+    // candidates' - seen1 for min_match >= 2, seen2 for min_match 1 - which is dead once pass A is over
+    uint16_t *rank = reinterpret_cast<uint16_t *>(min_match >= 2 ? bm1 : bm2);
     uint16_t *elist = rank + kIxWords;                                               // row of slot k
+    static_assert((kIxWords + kWqSlots) * 2 <= kIxWords * 4, "rank + slot rows fit one bitmap");
 
     const int q = (int)blockIdx.x;
     const int lane = (int)threadIdx.x;

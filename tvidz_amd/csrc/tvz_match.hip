@@ -854,16 +854,23 @@ struct WsLayout {
     int32_t *gathered = nullptr;    // [n_ranks][Q][k+1][3]
     int32_t *flags = nullptr;       // [Q] queries the one-wave top-k left to the block kernels
     int32_t *pair = nullptr;        // [2][Q][k+1][3] fused lookup: the index's block + the delta sweep's, merged into `local`
+    unsigned char *longq = nullptr; // scratch of the batch's long queries (> 4,095 timestamps): LAST, so that a larger
+    size_t longq_bytes = 0;         //   workspace (tvz_match_workspace_bytes_long) simply has more of it
     size_t total = 0;
 };
+
+// scratch the long queries of a batch need (ts_longq_sort_kernel): per query of n keys a power-of-two sort buffer
+// (< 2 n x 8 B), n + 1 distinct keys (8 B) and multiplicities (4 B), a counter; T = keys of all long queries, L = how many
+inline size_t longq_bytes_bound(int64_t T, int64_t L) { return (size_t)(28 * T + 64 * L + 512); }
 
 size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 WsLayout ws_layout(void *base, int32_t Q, int32_t max_query_len, int32_t cap, int32_t k,
-                   int32_t n_ranks) {
+                   int32_t n_ranks, int64_t total_query_keys = 0) {
     WsLayout w;
     uintptr_t p = (reinterpret_cast<uintptr_t>(base) + 255) & ~(uintptr_t)255;
     const uintptr_t p0 = p;
+    const int32_t true_max_len = max_query_len;
     if (max_query_len > kMaxQueryLen) max_query_len = kMaxQueryLen;   // longer queries do not use the tables
     w.join_bytes = join_shape(Q, max_query_len).bytes();
     w.join = reinterpret_cast<unsigned char *>(p);
@@ -885,6 +892,15 @@ WsLayout ws_layout(void *base, int32_t Q, int32_t max_query_len, int32_t cap, in
             w.pair = reinterpret_cast<int32_t *>(p);
             p += al256((size_t)2 * (size_t)Q * (size_t)(k + 1) * 12);
         }
+    }
+    if (true_max_len > kMaxQueryLen) {
+        // without the batch's key count: room for ONE query of max_query_len keys (tvz_match_workspace_bytes);
+        // with it (tvz_match_workspace_bytes_long): for any split of the keys into long queries
+        const int64_t T = total_query_keys > 0 ? total_query_keys : (int64_t)true_max_len;
+        const int64_t L = std::min<int64_t>(Q > 0 ? Q : 1, T / (kMaxQueryLen + 1) + 1);
+        w.longq = reinterpret_cast<unsigned char *>(p);
+        w.longq_bytes = longq_bytes_bound(T, L);
+        p += al256(w.longq_bytes);
     }
     w.total = (size_t)(p - p0) + 256;
     return w;
@@ -1134,7 +1150,7 @@ int launch_index_topk(tvz_corpus *c, const double *d_queries, const int64_t *d_q
     if ((flags & TVZ_ALGO_WAVE) && !wave_fits)
         return tvz::fail(TVZ_ERR_UNSUPPORTED, "TVZ_ALGO_WAVE: the one-wave lookup takes a handle of one sub-index (this one: %d) "
                          "and queries of up to %d timestamps (max_query_len %d)", ix.n_sub, kWqMaxLen, max_query_len);
-    if (wave_fits && !(flags & (TVZ_ALGO_NO_WAVE | TVZ_ALGO_PAIR))) {
+    if (wave_fits && (flags & (TVZ_ALGO_WAVE | TVZ_ALGO_PREFER_WAVE)) && !(flags & (TVZ_ALGO_NO_WAVE | TVZ_ALGO_PAIR))) {
         const size_t lds = wq_lds_bytes(max_query_len);
 #define TVZ_WQK(MODE)                                                                                        \
     hipLaunchKernelGGL((ts_match_wq_topk_kernel<MODE>), dim3((unsigned)Q), dim3(64), lds, st, ix.dir.p,        \
@@ -1197,22 +1213,20 @@ void sorted_distinct(const double *q, int64_t n, std::vector<int64_t> &uq, std::
 // kth resolved by the fix-up walk - the path tvz_find_duplicates takes for such a query.
 int launch_match_with_long(tvz_corpus *c, const double *d_queries, const int64_t *d_q_offsets, int32_t Q,
                            int32_t min_match, const int32_t *d_exclude_ids, int32_t cap, int32_t *d_hits,
-                           int32_t *d_hits_n, int32_t ns, unsigned char *ws, size_t ws_bytes, int32_t algo,
-                           hipStream_t st) {
+                           int32_t *d_hits_n, int32_t ns, unsigned char *ws, size_t ws_bytes, unsigned char *lq,
+                           size_t lq_bytes, int32_t algo, hipStream_t st) {
+    // The ONE synchronisation of this path: the host has to learn which queries are long (their launches are
+    // shaped by their lengths).  Everything after it is enqueued: no allocation (the scratch is a tail of the
+    // caller's workspace), no further copy, no wait - VERDICT r4 item 7.
     std::vector<int64_t> h_off((size_t)Q + 1);
-    std::vector<int32_t> h_ex;
     TVZ_HIP(hipMemcpyAsync(h_off.data(), d_q_offsets, ((size_t)Q + 1) * 8, hipMemcpyDeviceToHost, st));
-    if (d_exclude_ids) {
-        h_ex.resize((size_t)Q);
-        TVZ_HIP(hipMemcpyAsync(h_ex.data(), d_exclude_ids, (size_t)Q * 4, hipMemcpyDeviceToHost, st));
-    }
     TVZ_HIP(hipStreamSynchronize(st));
-    int64_t short_max = 0, long_keys = 0, long_distinct_bound = 0;
+    int64_t short_max = 0;
     std::vector<int32_t> longs;
     for (int32_t q = 0; q < Q; ++q) {
         const int64_t n = h_off[(size_t)q + 1] - h_off[(size_t)q];
         TVZ_REQUIRE(n >= 0 && n <= INT32_MAX, "query %d has a bad length", q);
-        if (n > kMaxQueryLen) { longs.push_back(q); long_keys = std::max(long_keys, n); long_distinct_bound += n + 1; }
+        if (n > kMaxQueryLen) longs.push_back(q);
         else short_max = std::max(short_max, n);
     }
     if (int rc = launch_match_short(c, d_queries, d_q_offsets, Q, (int32_t)short_max, min_match, d_exclude_ids, cap,
@@ -1220,63 +1234,73 @@ int launch_match_with_long(tvz_corpus *c, const double *d_queries, const int64_t
         return rc;
     if (longs.empty()) return TVZ_OK;
     const int64_t n_rows = (int64_t)c->h_rows.size();
-    int64_t *d_sq = nullptr;
-    int32_t *d_mult = nullptr;
-    TVZ_HIP(hipMalloc(&d_sq, (size_t)long_distinct_bound * 8));
-    if (hipMalloc(&d_mult, (size_t)long_distinct_bound * 4) != hipSuccess) {
-        (void)hipGetLastError();
-        (void)hipFree(d_sq);
-        return tvz::fail(TVZ_ERR_NOMEM, "scratch for the long queries of a batch");
-    }
-    struct Free { int64_t *a; int32_t *b; ~Free() { (void)hipFree(a); (void)hipFree(b); } } fr{d_sq, d_mult};
-    std::vector<double> hq((size_t)long_keys);
-    std::vector<int64_t> uq;
-    std::vector<int32_t> mult;
-    int64_t at = 0;
-    for (int32_t q : longs) {
+    // places in the long-query area: the counters of distinct keys, then per query its sort scratch, distinct keys
+    // and multiplicities (8-byte units for the int64 arrays, 4-byte units for the int32 ones)
+    std::vector<LongQ> table(longs.size());
+    size_t cursor = (longs.size() * 4 + 15) & ~(size_t)15;
+    for (size_t i = 0; i < longs.size(); ++i) {
+        const int32_t q = longs[i];
         const int64_t n = h_off[(size_t)q + 1] - h_off[(size_t)q];
-        TVZ_HIP(hipMemcpyAsync(hq.data(), d_queries + h_off[(size_t)q], (size_t)n * 8, hipMemcpyDeviceToHost, st));
-        TVZ_HIP(hipStreamSynchronize(st));
-        sorted_distinct(hq.data(), n, uq, mult);
-        const int64_t m = (int64_t)uq.size();
+        if (n > ((int64_t)1 << 22))
+            return tvz::fail(TVZ_ERR_UNSUPPORTED, "query %d of a batch has %lld timestamps: more than 4,194,304 are taken "
+                             "one query at a time (tvz_find_duplicates)", q, (long long)n);
+        int64_t p2 = 1;
+        while (p2 < n) p2 <<= 1;
+        LongQ &e = table[i];
+        e.q_off = h_off[(size_t)q];
+        e.n = (int32_t)n;
+        e.pow2 = (int32_t)p2;
+        e.m_at = (int64_t)i;
+        e.sort_at = (int64_t)(cursor / 8);
+        cursor += (size_t)p2 * 8;
+        e.uq_at = (int64_t)(cursor / 8);
+        cursor += (size_t)(n + 1) * 8;
+        e.mult_at = (int64_t)(cursor / 4);
+        cursor = (cursor + (size_t)(n + 1) * 4 + 15) & ~(size_t)15;
+    }
+    if (lq == nullptr || cursor > lq_bytes)
+        return tvz::fail(TVZ_ERR_WORKSPACE, "the batch's %zu queries of more than %d timestamps need %zu bytes of scratch, the "
+                         "workspace has %zu for them: size it with tvz_match_workspace_bytes_long (the batch's key count)",
+                         longs.size(), kMaxQueryLen, cursor, lq ? lq_bytes : (size_t)0);
+    int64_t *area = reinterpret_cast<int64_t *>(lq);
+    for (size_t i0 = 0; i0 < table.size(); i0 += kLongPerLaunch) {
+        LongQTable t{};
+        const size_t cnt = std::min<size_t>(kLongPerLaunch, table.size() - i0);
+        for (size_t i = 0; i < cnt; ++i) t.e[i] = table[i0 + i];
+        hipLaunchKernelGGL(ts_longq_sort_kernel, dim3((unsigned)cnt), dim3(kLongSortBlock), 0, st, d_queries, t, area);
+        TVZ_HIP(hipGetLastError());
+    }
+    for (size_t i = 0; i < longs.size(); ++i) {
+        const int32_t q = longs[i];
+        const LongQ &e = table[i];
         int32_t *cnt = d_hits_n + (size_t)q * ns;
         int32_t *hl = d_hits + (int64_t)q * cap * 3;
         if (int rc = launch_prep(cnt, ns, 1, nullptr, 0, nullptr, 0, st)) return rc;    // un-poison: 0 hits so far
-        if (m && n_rows) {
-            TVZ_HIP(hipMemcpyAsync(d_sq + at, uq.data(), (size_t)m * 8, hipMemcpyHostToDevice, st));
-            TVZ_HIP(hipMemcpyAsync(d_mult + at, mult.data(), (size_t)m * 4, hipMemcpyHostToDevice, st));
-            TVZ_HIP(hipStreamSynchronize(st));                 // uq / mult are reused by the next long query
-            hipLaunchKernelGGL(ts_match_longq_kernel, dim3((unsigned)tvz::ceil_div(n_rows, kGroupsPerBlock)), dim3(kBlock),
-                               0, st, c->rows.p, n_rows, c->keys.p, d_sq + at, d_mult + at, (int32_t)m, min_match,
-                               d_exclude_ids ? h_ex[(size_t)q] : -1, cap, hl, cnt);
-            TVZ_HIP(hipGetLastError());
-            if (min_match > 0) {
-                hipLaunchKernelGGL(ts_kth_fixup_kernel, dim3(1), dim3(kBlock), 0, st, c->rows.p, c->keys.p, d_queries,
-                                   d_q_offsets + q, min_match, cap, hl, cnt, ns);
-                TVZ_HIP(hipGetLastError());
-            }
-        } else if (min_match <= 0 && n_rows) {
-            // every row is a hit with count 0 (db.py:90: 0 >= min_match): the sweep with an empty query
-            hipLaunchKernelGGL(ts_match_longq_kernel, dim3((unsigned)tvz::ceil_div(n_rows, kGroupsPerBlock)), dim3(kBlock),
-                               0, st, c->rows.p, n_rows, c->keys.p, d_sq, d_mult, 0, min_match,
-                               d_exclude_ids ? h_ex[(size_t)q] : -1, cap, hl, cnt);
+        if (!n_rows) continue;
+        // (no distinct key: min_match <= 0 makes every row a hit with count 0, db.py:90: 0 >= min_match)
+        hipLaunchKernelGGL(ts_match_longq_kernel, dim3((unsigned)tvz::ceil_div(n_rows, kGroupsPerBlock)), dim3(kBlock),
+                           0, st, c->rows.p, n_rows, c->keys.p, area + e.uq_at, reinterpret_cast<int32_t *>(lq) + e.mult_at,
+                           0, min_match, -1, cap, hl, cnt, reinterpret_cast<int32_t *>(lq) + e.m_at,
+                           d_exclude_ids ? d_exclude_ids + q : nullptr);
+        TVZ_HIP(hipGetLastError());
+        if (min_match > 0) {
+            hipLaunchKernelGGL(ts_kth_fixup_kernel, dim3(1), dim3(kBlock), 0, st, c->rows.p, c->keys.p, d_queries,
+                               d_q_offsets + q, min_match, cap, hl, cnt, ns);
             TVZ_HIP(hipGetLastError());
         }
-        at += m;
     }
-    TVZ_HIP(hipStreamSynchronize(st));                         // the scratch is freed on return
     return TVZ_OK;
 }
 
 int launch_match(tvz_corpus *c, const double *d_queries, const int64_t *d_q_offsets, int32_t Q,
                  int32_t max_query_len, int32_t min_match, const int32_t *d_exclude_ids,
                  int32_t cap, int32_t *d_hits, int32_t *d_hits_n, int32_t ns, unsigned char *ws,
-                 size_t ws_bytes, int32_t algo, hipStream_t st) {
+                 size_t ws_bytes, int32_t algo, hipStream_t st, unsigned char *lq = nullptr, size_t lq_bytes = 0) {
     TVZ_REQUIRE(algo >= TVZ_ALGO_AUTO && algo <= TVZ_ALGO_INDEX, "unknown algo %d", algo);
     if (max_query_len > kMaxQueryLen) {
         if (int rc = wait_mutations(c, st)) return rc;
         return launch_match_with_long(c, d_queries, d_q_offsets, Q, min_match, d_exclude_ids, cap, d_hits, d_hits_n,
-                                      ns, ws, ws_bytes, algo, st);
+                                      ns, ws, ws_bytes, lq, lq_bytes, algo, st);
     }
     return launch_match_short(c, d_queries, d_q_offsets, Q, max_query_len, min_match, d_exclude_ids, cap, d_hits,
                               d_hits_n, ns, ws, ws_bytes, algo, st);
@@ -1393,7 +1417,7 @@ int tvz_match_topk_local(tvz_corpus *c, const double *d_queries, const int64_t *
                          void *hip_stream, int32_t **gathered_out) {
     if (int rc = check_batch_args(c, d_queries, d_q_offsets, Q, max_query_len, cap)) return rc;
     TVZ_REQUIRE(k >= 1 && k <= kSortCap / 2, "k=%d out of range [1, %d]", k, kSortCap / 2);
-    constexpr int32_t kShape = TVZ_ALGO_PAIR | TVZ_ALGO_NO_PAIR | TVZ_ALGO_WAVE | TVZ_ALGO_NO_WAVE;
+    constexpr int32_t kShape = TVZ_ALGO_PAIR | TVZ_ALGO_NO_PAIR | TVZ_ALGO_WAVE | TVZ_ALGO_NO_WAVE | TVZ_ALGO_PREFER_WAVE;
     const int32_t flags = algo & kShape;                                  // shape of the fused lookup (tvz.h)
     algo &= ~kShape;
     if (Q == 0) return TVZ_OK;
@@ -1439,8 +1463,10 @@ int tvz_match_topk_local(tvz_corpus *c, const double *d_queries, const int64_t *
         return record(c, st);
     }
     // the sweeps count into one-counter-per-line scratch; the select kernel reads it as it is
+    // (the long queries' scratch is the workspace's tail: all of it, however the caller sized it)
+    const size_t lq_bytes = w.longq ? (size_t)(static_cast<unsigned char *>(d_workspace) + workspace_bytes - w.longq) : 0;
     if (int rc = launch_match(c, d_queries, d_q_offsets, Q, max_query_len, min_match, d_exclude_ids,
-                              cap, w.hits, w.counters, kCountStride, w.join, w.join_bytes, algo, st))
+                              cap, w.hits, w.counters, kCountStride, w.join, w.join_bytes, algo, st, w.longq, lq_bytes))
         return rc;
     if (int rc = launch_topk_local(w.hits, w.counters, kCountStride, Q, cap, k, d_out, 1, w.flags, st)) return rc;
     return record(c, st);
@@ -1895,8 +1921,8 @@ static int tvz_match_impl(tvz_corpus *c, const double *d_queries, const int64_t 
     // with a workspace (tvz_match_workspace_bytes(Q, max_query_len, 0, 0, 1)) the sweeps count into
     // one-counter-per-cache-line scratch and may use the hash join; without one they fall back to
     // the caller's dense counters and the LDS kernels
-    unsigned char *ws = nullptr;
-    size_t ws_bytes = 0;
+    unsigned char *ws = nullptr, *lq = nullptr;
+    size_t ws_bytes = 0, lq_bytes = 0;
     int32_t *cnt = d_hits_n;
     int32_t ns = 1;
     if (d_workspace) {
@@ -1904,6 +1930,10 @@ static int tvz_match_impl(tvz_corpus *c, const double *d_queries, const int64_t 
         if (workspace_bytes >= w.total) {
             ws = w.join;
             ws_bytes = w.join_bytes;
+            if (w.longq) {               // the long queries' scratch is the workspace's tail: all of it
+                lq = w.longq;
+                lq_bytes = (size_t)(static_cast<unsigned char *>(d_workspace) + workspace_bytes - w.longq);
+            }
             if (Q > 1) {                 // a lone query's counter shares its line with nobody: no gather launch
                 cnt = w.counters;
                 ns = kCountStride;
@@ -1915,7 +1945,7 @@ static int tvz_match_impl(tvz_corpus *c, const double *d_queries, const int64_t 
     }
     std::shared_lock<std::shared_mutex> lk(c->mu);
     if (int rc = launch_match(c, d_queries, d_q_offsets, Q, max_query_len, min_match,
-                              d_exclude_ids, cap, d_hits, cnt, ns, ws, ws_bytes, algo, st))
+                              d_exclude_ids, cap, d_hits, cnt, ns, ws, ws_bytes, algo, st, lq, lq_bytes))
         return rc;
     if (ns != 1) {
         hipLaunchKernelGGL(ts_counts_gather_kernel, dim3((unsigned)tvz::ceil_div(Q, kBlock)), dim3(kBlock), 0, st,
@@ -2135,7 +2165,7 @@ static int tvz_find_duplicates_impl(tvz_corpus *c, const double *h_query, int64_
                     hipLaunchKernelGGL(ts_match_longq_kernel, dim3((unsigned)tvz::ceil_div(n_rows, kGroupsPerBlock)),
                                        dim3(kBlock), 0, s->stream, c->rows.p, n_rows, c->keys.p, s->d_sq,
                                        s->d_smult, (int32_t)uq.size(), min_match, -1, (int32_t)want, s->d_hits,
-                                       s->d_hits_n);
+                                       s->d_hits_n, static_cast<const int32_t *>(nullptr), static_cast<const int32_t *>(nullptr));
                     TVZ_HIP(hipGetLastError());
                     if (min_match > 0) {
                         hipLaunchKernelGGL(ts_kth_fixup_kernel, dim3(1), dim3(kBlock), 0, s->stream, c->rows.p,
@@ -2283,6 +2313,12 @@ TVZ_EXPORT size_t tvz_match_workspace_bytes(int32_t Q, int32_t max_query_len, in
                                             int32_t n_ranks) {
     if (Q < 0 || max_query_len < 0 || cap < 0 || k < 0) return 0;
     return ws_layout(nullptr, Q, max_query_len, cap, k, n_ranks).total;
+}
+
+TVZ_EXPORT size_t tvz_match_workspace_bytes_long(int32_t Q, int32_t max_query_len, int32_t cap, int32_t k,
+                                                 int32_t n_ranks, int64_t total_query_keys) {
+    if (Q < 0 || max_query_len < 0 || cap < 0 || k < 0 || total_query_keys < 0) return 0;
+    return ws_layout(nullptr, Q, max_query_len, cap, k, n_ranks, std::max<int64_t>(total_query_keys, max_query_len)).total;
 }
 
 TVZ_EXPORT int tvz_corpus_create(tvz_corpus **out, int device) {

@@ -658,10 +658,91 @@ __device__ __forceinline__ int dpp_row16(int v) {
     return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true);
 }
 
+// ---- a batch's long queries, prepared ON THE DEVICE (no host copy, no allocation, no synchronisation) ----------
+// One block per long query: its canonical keys into a power-of-two scratch (NaN -> the largest int64: sorted to the
+// end, never a key), bitonic sort there, then the distinct keys and their multiplicities - what
+// ts_match_longq_kernel searches per row key - and their number.  The scratch is a tail of the caller's workspace
+// (tvz_match_workspace_bytes_long); a query of more than 4,095 timestamps is rare, this is not a fast path.
+constexpr int kLongSortBlock = 1024;
+constexpr int64_t kLongNoKey = 0x7fffffffffffffffLL;        // (a NaN pattern: never a canonical key)
+struct LongQ {                 // one long query of a batch
+    int64_t q_off;             // first key in d_queries
+    int32_t n;                 // keys
+    int32_t pow2;              // sort scratch entries
+    int64_t sort_at;           // int64 index of the sort scratch in the long-query area
+    int64_t uq_at;             // int64 index of the distinct keys [n + 1]
+    int64_t mult_at;           // int32 index of the multiplicities [n + 1]
+    int64_t m_at;              // int32 index of the number of distinct keys
+};
+
+constexpr int kLongPerLaunch = 64;
+struct LongQTable { LongQ e[kLongPerLaunch]; };            // travels BY VALUE in the kernel arguments: no copy to enqueue
+
+__global__ __launch_bounds__(kLongSortBlock) void ts_longq_sort_kernel(const double *__restrict__ queries,
+                                                                        const LongQTable table,
+                                                                        int64_t *__restrict__ area) {
+    const LongQ lq = table.e[blockIdx.x];
+    int64_t *sk = area + lq.sort_at;
+    int64_t *uq = area + lq.uq_at;
+    int32_t *mult = reinterpret_cast<int32_t *>(area) + lq.mult_at;
+    int32_t *m_out = reinterpret_cast<int32_t *>(area) + lq.m_at;
+    const int tid = (int)threadIdx.x;
+    for (int i = tid; i < lq.pow2; i += kLongSortBlock) {
+        int64_t k = kLongNoKey;
+        if (i < lq.n && !canon_key(queries[lq.q_off + i], k)) k = kLongNoKey;
+        sk[i] = k;
+    }
+    __syncthreads();
+    for (int size = 2; size <= lq.pow2; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int t = tid; t < lq.pow2 / 2; t += kLongSortBlock) {
+                const int lo = 2 * t - (t & (stride - 1));          // index with bit `stride` clear
+                const int hi = lo + stride;
+                const bool up = (lo & size) == 0;
+                const int64_t a = sk[lo], b = sk[hi];
+                if ((a > b) == up) { sk[lo] = b; sk[hi] = a; }
+            }
+            __syncthreads();
+        }
+    }
+    // distinct keys: thread t owns a contiguous range; heads counted, scanned over the block, then written
+    __shared__ int s_cnt[kLongSortBlock];
+    __shared__ int s_total;
+    const int per = (lq.n + kLongSortBlock - 1) / kLongSortBlock;
+    const int i0 = tid * per, i1 = i0 + per < lq.n ? i0 + per : lq.n;
+    int heads = 0;
+    for (int i = i0; i < i1; ++i) heads += (sk[i] != kLongNoKey && (i == 0 || sk[i] != sk[i - 1])) ? 1 : 0;
+    s_cnt[tid] = heads;
+    __syncthreads();
+    if (tid == 0) {
+        int run = 0;
+        for (int t = 0; t < kLongSortBlock; ++t) { const int c = s_cnt[t]; s_cnt[t] = run; run += c; }
+        s_total = run;
+    }
+    __syncthreads();
+    int at = s_cnt[tid];
+    for (int i = i0; i < i1; ++i) {
+        if (sk[i] != kLongNoKey && (i == 0 || sk[i] != sk[i - 1])) {
+            int j = i + 1;
+            while (j < lq.n && sk[j] == sk[i]) ++j;                // (a run may go on into the next thread's range)
+            uq[at] = sk[i];
+            mult[at] = j - i;
+            ++at;
+        }
+    }
+    if (tid == 0) *m_out = s_total;
+}
+
+
 __global__ __launch_bounds__(kBlock) void ts_match_longq_kernel(
     const Row *__restrict__ rows, int64_t n_rows, const int64_t *__restrict__ keys,
     const int64_t *__restrict__ sq, const int32_t *__restrict__ smult, int32_t m, int32_t min_match,
-    int32_t exclude_one, int32_t cap, int32_t *__restrict__ hits, int32_t *__restrict__ hits_n) {
+    int32_t exclude_one, int32_t cap, int32_t *__restrict__ hits, int32_t *__restrict__ hits_n,
+    const int32_t *__restrict__ m_dev, const int32_t *__restrict__ exclude_dev) {
+    // (a batch's long queries are prepared on the device - ts_longq_sort_kernel: the number of distinct keys and the
+    // query's own video id are then read here, the host never learns them)
+    if (m_dev) m = *m_dev;
+    if (exclude_dev) exclude_one = *exclude_dev;
     const int gl = threadIdx.x & (kGroup - 1);
     const int64_t r = (int64_t)blockIdx.x * kGroupsPerBlock + threadIdx.x / kGroup;
     if (r >= n_rows) return;                       // whole 16-lane groups leave together

@@ -256,7 +256,7 @@ class ShardedCorpus:
         Q = len(items)
         with torch.cuda.device(self.dev), torch.cuda.stream(self.stream):
             d_q, d_off, d_ex, max_len = self._stage([q for q, _, _ in items], [e for _, _, e in items])
-            need = tc.workspace_bytes(Q, max_len, self.cap, self.k)
+            need = tc.workspace_bytes(Q, max_len, self.cap, self.k, total_query_keys=d_q.numel())
             if self._ws[0] is None or self._ws[0].numel() < need:
                 self._ws[0] = torch.empty(need, dtype=torch.uint8, device=self.dev)       # one workspace: the shards run in turn
             # ONE library call for the R lookups + the merge (tvz_match_topk_shards): every return to the

@@ -142,6 +142,10 @@ class RcclShardedMatcher:
             # two queries per lookup block pay off when a THIRD batch's blocks fill the longer tail of a launch
             # (42 against 46 us per batch on a 1/8 shard); with two batches in flight they cost (57 against 52)
             self.algo |= _lib.ALGO_NO_PAIR
+        if not self.algo & (_lib.ALGO_WAVE | _lib.ALGO_NO_WAVE | _lib.ALGO_PAIR):
+            # a stream of batches: on a shard of one sub-index the lookup that gives every query to one wave executes
+            # a third fewer instructions per batch than the block kernel (which answers a LONE batch sooner: tvz.h)
+            self.algo |= _lib.ALGO_PREFER_WAVE
         self.k = int(k)
         self.cap = max(int(cap), self.k)
         self.world, self.rank = comm.n_ranks, comm.rank
@@ -171,7 +175,7 @@ class RcclShardedMatcher:
         self._i = (i + 1) % len(self.streams)
         st = self.streams[i]
         Q = d_q_offsets.numel() - 1
-        need = tc.workspace_bytes(Q, max_query_len, self.cap, self.k, self.world)
+        need = tc.workspace_bytes(Q, max_query_len, self.cap, self.k, self.world, d_queries.numel())
         if self.ws[i] is None or self.ws[i].numel() < need:
             self.ws[i] = torch.empty(need, dtype=torch.uint8, device=self.dev)
         if self.out[i] is None or self.out[i][0].shape[0] != Q:
