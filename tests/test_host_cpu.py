@@ -533,3 +533,17 @@ def test_native_span_reads_skip_chroma_and_stop_at_partial_records(tmp_path):
     with pytest.raises(RuntimeError, match="expected header"):
         r.read_into(big)
     r.close()
+
+
+def test_a_rank_store_never_audits(tmp_path, monkeypatch):
+    """with census=False (a rank of the N-rank service) the sibling ranks' rows would all look "updated by
+    another writer" to the periodic audit and be upserted into this rank's shard too.  A rank's store ignores
+    TVZ_AUDIT_INTERVAL and an explicit audit_interval."""
+    from tests.fakes import OracleCorpus
+    from tvidz_amd import db
+    monkeypatch.setenv("TVZ_AUDIT_INTERVAL", "0.05")
+    s = db.Store(f"sqlite:///{tmp_path}/r.db", corpus=OracleCorpus(), census=False, audit_interval=0.05)
+    try:
+        assert s.audit_interval == 0.0 and getattr(s, "_audit_thread", None) is None
+    finally:
+        s.close()

@@ -386,6 +386,66 @@ def test_merge_of_gathered_rank_blocks(dc, R, k):
         assert [tuple(int(x) for x in r) for r in merged[q]] == exp, q
 
 
+def test_every_producer_of_rank_blocks_meets_the_sorted_merge_precondition(dc):
+    """tvz_topk_merge (<= 16 ranks, k <= 64) is a k-way merge of SORTED lists: every gathered block must be in
+    ascending (kth, video_id, count) order with its padding last (a block that is not would be
+    mis-merged silently).  Here every producer of such a block in the library is asked for one - the lookup that
+    keeps the top-k (block kernel, two queries per block, one wave per query), with a delta table behind it (the
+    mode-3 pair merge), the sweeps + the select kernels for k <= 16 and k > 16, k beyond the fused lookup's 64, a
+    batch with a refused query - each block is checked for the order, and the blocks of ALL producers, stacked as
+    ranks, are merged and compared with a plain sort."""
+    rng = np.random.default_rng(12)
+    grid = np.arange(1, 3001) / 4.0
+    rows = [(v + 1, rng.choice(grid, size=int(rng.integers(10, 60)), replace=False).tolist()) for v in range(5000)]
+    dc.upload(rows)
+    Q = 33
+    queries = [rng.choice(grid, size=int(rng.integers(20, 120)), replace=False) for _ in range(Q)]
+    queries[4] = np.zeros(0)
+    d_q, d_off, max_len = tc.pack_queries(queries, DEV)
+
+    def sorted_ok(blk, k):
+        for q in range(blk.shape[0]):
+            ent = [tuple(int(x) for x in e) for e in blk[q, :k]]
+            real = [e for e in ent if e[0] >= 0]
+            assert ent[:len(real)] == real, ("padding in the middle", q)
+            assert real == sorted(real, key=lambda h: (h[2], h[0], h[1])), ("not ascending", q)
+
+    for k in (8, 40):
+        blocks = {}
+        for name, algo in (("block", _lib.ALGO_NO_WAVE | _lib.ALGO_NO_PAIR), ("pair", _lib.ALGO_PAIR), ("wave", _lib.ALGO_WAVE),
+                           ("tile+select", _lib.ALGO_TILE), ("join+select", _lib.ALGO_JOIN)):
+            blocks[name] = dc.match_topk(d_q, d_off, max_len, 2, 4096, k, algo=algo).cpu().numpy()
+        # a refused query: max_query_len understated for query 7 -> padding + the poisoned total, still a valid list
+        short = max(len(q) for i, q in enumerate(queries) if i != 7)
+        if len(queries[7]) <= short:
+            queries7 = np.concatenate([queries[7], rng.choice(grid, size=short + 5 - len(queries[7]))])
+            d_q7, d_off7, _ = tc.pack_queries(queries[:7] + [queries7] + queries[8:], DEV)
+        else:
+            d_q7, d_off7 = d_q, d_off
+        blocks["refused"] = dc.match_topk(d_q7, d_off7, short, 2, 4096, k, algo=_lib.ALGO_NO_WAVE).cpu().numpy()
+        assert tuple(blocks["refused"][7, 0]) == (-1, 0, NEVER) and blocks["refused"][7, k, 1] == np.iinfo(np.int32).min
+        for name, b in blocks.items():
+            sorted_ok(b, k)
+            if name != "refused":
+                assert (b == blocks["block"]).all(), name
+        g = np.stack([blocks[n] for n in ("block", "wave", "tile+select", "refused")])
+        merged, totals = tc.topk_merge(torch.from_numpy(g).to(DEV), k)
+        merged = merged.cpu().numpy()
+        for q in range(Q):
+            flat = [tuple(int(x) for x in e) for r in range(g.shape[0]) for e in g[r, q, :k] if e[0] >= 0]
+            exp = sorted(flat, key=lambda h: (h[2], h[0], h[1]))[:k]
+            exp += [(-1, 0, NEVER)] * (k - len(exp))
+            assert [tuple(int(x) for x in r) for r in merged[q]] == exp, (k, q)
+    # with a delta table: the lookup's block and the delta sweep's are merged pairwise (mode 3) - still sorted;
+    # and k beyond the fused lookup's 64 (the unfused pipeline)
+    for j in range(40):
+        dc.upsert(rows[j][0], rows[j][1][::2])
+        dc.upsert(900_000 + j, queries[j % Q][:30].tolist())
+    assert dc.index_stats()["delta_rows"] > 0
+    for k, algo in ((8, 0), (40, 0), (8, _lib.ALGO_WAVE), (100, 0)):
+        sorted_ok(dc.match_topk(d_q, d_off, max_len, 2, 4096, k, algo=algo).cpu().numpy(), k)
+
+
 def test_concurrent_find_duplicates_threads(dc):
     import threading
     ids, offs, keys = synth.synth_timestamp_corpus(1500, seed=8, mean_len=50, dup_frac=0.05)

@@ -129,6 +129,56 @@ def test_rank_service_tick_exchange_world2():
     assert all(p.exitcode == 0 for p in procs)
 
 
+def _failing_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    rc = None
+    try:
+        shard = OracleCorpus()
+        g = dist.new_group(backend="gloo")
+        matcher = sharded.ShardedMatcher(OracleBackend(live=shard), k=4, cap=64, group=g)
+        rc = service.RankCorpus(shard, matcher, group=g, xdev="cpu", tick_s=0.002)
+        rc.upload([(10 + i, [float(i), float(i) + 0.5, 100.25]) for i in range(8)])
+        dist.barrier()
+        assert len(rc.find_duplicates([100.25, 1.0, 1.5], 1)) == 8           # the exchange works (an exact ask: 8 > k rows)
+        dist.barrier()
+        if rank == 1:                                                         # rank 1's own shard breaks
+            def boom(*a, **k):
+                raise ValueError("shard of rank 1 is gone")
+            shard.find_duplicates = boom
+        dist.barrier()
+        # an exact ask from EITHER rank now fails on BOTH, in the same tick, with the failing rank named - nobody
+        # hangs in a collective, nobody is answered from one shard only
+        try:
+            rc.find_duplicates([100.25, 1.0, 1.5], 1)
+            out.put((rank, "answered"))
+        except RuntimeError as e:
+            msg = str(e)
+            out.put((rank, "raised" if ("rank(s) [1]" in msg and "stops" in msg) or "broken" in msg else msg))
+        # ... and so does every later ask, at once
+        try:
+            rc.find_duplicates([1.0], 1, with_kth=True)
+            out.put((rank, "answered-later"))
+        except RuntimeError:
+            out.put((rank, "raised-later"))
+        assert rc.broken is not None
+    finally:
+        dist.destroy_process_group()
+
+
+def test_a_shard_that_fails_on_one_rank_stops_every_rank_in_the_same_tick():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29900 + os.getpid() % 40
+    procs = [ctx.Process(target=_failing_worker, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in procs]
+    [p.join(120) for p in procs]
+    assert all(not p.is_alive() for p in procs), "a rank hung in a collective"
+    res = sorted(q.get(timeout=5) for _ in range(4))
+    assert res == [(0, "raised"), (0, "raised-later"), (1, "raised"), (1, "raised-later")], res
+
+
 def test_hits_from_topk_flags_tie_sets_that_may_continue():
     N = service.KTH_NEVER
     full = np.array([[1, 2, 0], [2, 2, 0], [3, 2, 0], [4, 2, 0]], dtype=np.int32)

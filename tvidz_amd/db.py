@@ -131,6 +131,12 @@ class Store:
         self._sql_digest = {}
         self.audit_interval = float(os.environ.get("TVZ_AUDIT_INTERVAL", "0") if audit_interval is None
                                     else audit_interval)
+        if not self.census:
+            # A rank of the N-rank service: every row a SIBLING rank writes would look like "updated in place by
+            # another writer" to the periodic audit, which would upsert it into THIS rank's shard as well - the video
+            # then lives in two shards (duplicate ids in the merged top-k, totals counted twice).  The ranks are each
+            # other's only writers by construction, so a rank never audits.
+            self.audit_interval = 0.0
         self.audit_repairs = 0           # rows the audits found changed behind this process's back
         self._audit_stop = threading.Event()
         self._audit_thread = None

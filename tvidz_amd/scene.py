@@ -258,7 +258,9 @@ def scene_cuts_chunked(chunks: Sequence[torch.Tensor], threshold: float = DEFAUL
     """ONE long video over several GPUs (scene scoring): `chunks` are consecutive time
     ranges of the video's 8-bit luma, uint8 [T_c,H,W] each on ITS device.  Every device computes the SADs
     of its chunk against a one-frame halo - the last frame of the chunk before it, copied over (2 MB at
-    1080p: the only data that crosses devices) - so each luma byte is still read once; the per-frame SADs
+    1080p: the only data that crosses devices) - so the SAD kernel still reads each luma byte once (this
+    helper, a test vehicle, first copies every chunk behind its halo frame into one buffer: a production feeder
+    would leave a frame of headroom in front of the chunk instead); the per-frame SADs
     (8 B per frame) are concatenated on `gather_device` BEFORE the diff step, where the epilogue of
     get_scene_score (mafd, |mafd - prev_mafd|, clip, threshold: inspector/app.py:206's `select` filter) runs
     once over the whole video.  No collective: a host that owns all chunks drives it (one process per GPU

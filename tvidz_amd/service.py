@@ -298,10 +298,15 @@ class RankCorpus:
     `owner_fn(video_id) -> rank` decides which rank keeps a row of the initial table (default
     video_id mod world; the N-rank service routes by file name and passes its own).
 
-    A failure of the tick thread (a collective that errors, the local matcher, an allocation) cannot be
-    repaired from inside: the other ranks are in the same collective.  It marks the corpus BROKEN - every
-    pending and later ask raises it - and the next meta exchange carries the flag, so the ranks that are
-    still exchanging stop together; the service process then exits non-zero (service main)."""
+    Failures.  What a rank computes ALONE inside a tick - `shard.find_duplicates` for the exact asks - may fail
+    without stranding the others: the failing rank sends a count of -1 into the tick's next collective, every
+    rank reads the same counts and raises in the SAME tick: all pending and later asks fail with the error on
+    every rank, nobody waits in a collective and nobody is answered from an incomplete set of shards
+    (tests/test_service_cpu.py, a shard that raises on one rank).  A failure INSIDE a collective step (the matcher's all-gather, an exchange that errors) cannot be
+    announced - the other ranks are in that collective - and the failing rank's loop ends at once: it marks
+    the corpus BROKEN (`broken`; every pending and later ask raises it) and only the END OF ITS PROCESS frees the
+    others (the service's child watchdog exits with code 3 on `broken`; a host that embeds RankCorpus elsewhere,
+    e.g. bench.py's ranked e2e leg, must do the same)."""
 
     def __init__(self, shard, matcher, group=None, xdev="cpu", tick_s: float = 0.0005, max_batch: int = 1024,
                  owner_fn: Optional[Callable[[int], int]] = None, idle_tick_s: float = 0.005, idle_after: int = 400):
@@ -321,6 +326,7 @@ class RankCorpus:
         self._pending: List[tuple] = []
         self._stop = False
         self.broken: Optional[BaseException] = None
+        self._local_error: Optional[BaseException] = None   # this rank's own work failed inside a tick (announced to the others)
         self.ticks = 0
         self.busy_ticks = 0
         self.exact_asks = 0
@@ -401,12 +407,13 @@ class RankCorpus:
                     self._pending = self._pending[len(take):]
                 # 1) who has how much; does anybody want to stop (all ranks leave together); is anybody broken
                 meta = torch.tensor([len(take), max((len(p[0]) for p in take), default=0), 1 if stop else 0,
-                                     1 if self.broken is not None else 0], dtype=torch.int64, device=self.xdev)
+                                     1 if self._local_error is not None else 0], dtype=torch.int64, device=self.xdev)
                 allmeta = self._gather(meta).cpu().numpy()
                 self.ticks += 1
-                if int(allmeta[:, 3].max()) == 1:
+                if int(allmeta[:, 3].max()) == 1:            # the same tick on every rank: they stop together
                     bad = [int(r) for r in np.flatnonzero(allmeta[:, 3])]
-                    raise RuntimeError(f"the tick loop of rank(s) {bad} failed: the sharded service stops")
+                    raise RuntimeError(f"rank(s) {bad} failed in the last tick: the sharded service stops"
+                                       + (f" ({self._local_error!r})" if self._local_error is not None else ""))
                 if int(allmeta[:, 0].sum()) == 0:
                     if int(allmeta[:, 2].min()) == 1:        # every rank is closing and nothing is pending anywhere
                         return
@@ -479,9 +486,22 @@ class RankCorpus:
             local = []
             for a in sel:
                 q = g_keys[rr[a], ii[a], :int(lens_all[a])]
-                local.append(self.shard.find_duplicates(q, int(mm_all[a]), exclude_id=int(excl_all[a]), with_kth=True))
-            counts = torch.tensor([len(h) for h in local], dtype=torch.int64, device=self.xdev)
+                try:
+                    if self._local_error is not None:
+                        raise self._local_error
+                    local.append(self.shard.find_duplicates(q, int(mm_all[a]), exclude_id=int(excl_all[a]), with_kth=True))
+                except Exception as e:                       # noqa: BLE001 - this rank's own work: finish the tick's collectives
+                    self._local_error = e                    # with a poisoned count (below): every rank stops in this tick
+                    local.append([])
+            # (a rank whose own shard failed sends -1: every rank reads the same counts and stops in THIS tick, before
+            # anybody's ask is answered from an incomplete set of shards)
+            counts = torch.tensor([-1 if self._local_error is not None else len(h) for h in local], dtype=torch.int64,
+                                  device=self.xdev)
             allcounts = self._gather(counts).cpu().numpy()                         # [world, n]
+            if (allcounts < 0).any():
+                bad = [int(r) for r in np.flatnonzero((allcounts < 0).any(axis=1))]
+                raise RuntimeError(f"the shard of rank(s) {bad} failed: the sharded service stops"
+                                   + (f" ({self._local_error!r})" if self._local_error is not None else ""))
             width = int(allcounts.max())
             if width:
                 pad = np.full((len(sel), width, 3), -1, dtype=np.int32)
