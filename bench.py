@@ -358,10 +358,12 @@ def bench_match(args, rank, world, dev):
            "batches_in_flight": DEPTH,
            "batches_in_flight_calibration_ms": {str(d): round(v, 4) for d, v in calib.items()},
            "distinct_query_batches_rotating": NB,
-           "algo": "AUTO = inverted-index lookup, one block per query (two queries per block, probed together, on shards of one or "
-                   "two sub-indexes) walking the query's sub-indexes of 16384 rows "
-                   "and keeping the per-shard top-k in its epilogue (no hit lists, no top-k launch) + sweep of the "
-                   "delta table (empty here); identical rows to the full sweep + top-k (tests/test_index_topk_gpu.py)",
+           "algo": "AUTO = inverted-index lookup, one block per query (two queries per block, probed together, on shards of "
+                   "two sub-indexes) walking the query's sub-indexes of 16384 rows and keeping the per-shard top-k in its "
+                   "epilogue (no hit lists, no top-k launch) + sweep of the delta table (empty here); on a shard of ONE "
+                   "sub-index (N = 8) the bucket directory - a key's entry and its postings in one 128-byte line - and, for "
+                   "a stream of batches, one WAVE per query (TVZ_ALGO_PREFER_WAVE); identical rows to the full sweep + top-k "
+                   "(tests/test_index_topk_gpu.py)",
            "index": ix,
            "collective": (f"tvz_match_sharded (C ABI): one ncclAllGather of [Q,{K_TOP + 1},3] int32 per batch "
                           f"(top-{K_TOP} + hit totals) over {world} rank(s), overlapped with the next batch's match"),
@@ -370,7 +372,7 @@ def bench_match(args, rank, world, dev):
            "scaling": "strong (the same corpus is sharded over the ranks)",
            "match_ms_per_batch_rank0": index_ms, "unfused_lookup_ms_per_batch_rank0": unfused_ms,
            "sweep_ms_per_batch_rank0": sweep_ms,
-           "predicted_scaling": "profiles/r4_predicted_scaling.json (single-GPU shard timings; no multi-GPU box was available)"}
+           "predicted_scaling": "profiles/r5_predicted_scaling.json (single-GPU shard timings; no multi-GPU box was available)"}
     tag = f"C{C}_Q{Q}"
     # ---- roofline of the kernel the batch spends its time in: the index lookup ----
     # algorithmic bytes: every posting of the query's keys once (2 B), ONE directory entry
@@ -390,32 +392,67 @@ def bench_match(args, rank, world, dev):
         "algorithmic_bytes_per_launch": alg_ix, "avg_launch_ms": index_ms,
         "workload": f"rank {rank}'s shard of {C} videos ({shard_rows} rows, {n_sub} sub-index(es)) x {Q} queries",
         "pairs_per_s": Q * shard_rows / (index_ms * 1e-3),
+        **(bound_fields("ts_match_index_topk", "topk") if world == 1 else {}),
         "algorithmic_bytes": f"{postings:.0f} postings x 2 B + one {entry_bytes} B directory entry and one 8 B query key per "
                              f"query element ({n_elems:.0f}) + {Q} x {K_TOP + 1} output rows x 12 B (means over the rotating "
                              f"batches; the {n_hits} hits of a batch are no longer written)",
-        "limiter": "not HBM bandwidth: instruction issue and LDS latency inside a block (one block per query walks "
-                   "its sub-indexes: per sub-index ~300 postings per wave through two LDS passes and five block "
-                   "barriers); s_memtime stamps in profiles/r3_ix_stamps.txt, counters in profiles/r4_match_pmc.txt"}
+        "limiter": "not HBM bandwidth: see frac_bound (the nearest of VALU issue, LDS arrays and the fabric's "
+                   "random-line rate) and wave_cycles_waiting_share - a block is latency-bound (one block per query walks "
+                   "its sub-indexes: per sub-index ~300 postings per wave through two LDS passes and five block barriers)"}
     # ---- the same batch against rank 0's share of an 8-way sharded corpus: what every GPU of configs[3] runs ----
     if world == 1:
         s8 = sharded.shard_csr(ids, offs, keys, 0, 8)
         dc8 = tc.DeviceCorpus(dev.index)
         dc8.upload_csr(*s8)
-        ms8 = kernel_ms(fused_call(dc8), st, reps=28, skip=4)
+        # one sub-index: the bucket directory (a key's entry and its postings in ONE line) and two shapes of the lookup
+        # that keeps the top-k - a block per query (the default: a lone batch is answered soonest) and a wave per query
+        # (what a stream of batches in flight takes, sharded.RcclShardedMatcher: fewer instructions per batch)
+        def shaped_call(handle, shape):
+            def f():
+                b = batches[rot["i"] % NB]
+                rot["i"] += 1
+                handle.match_topk(b[0], b[1], max_len, 2, CAP, K_TOP, out=blk, workspace=ws, stream=st, algo=shape)
+            return f
+        ms8 = kernel_ms(shaped_call(dc8, 0), st, reps=28, skip=4)
+        ms8_wave = kernel_ms(shaped_call(dc8, _lib.ALGO_WAVE), st, reps=28, skip=4) if max_len <= 512 else None
         uk8, uc8 = np.unique(s8[2].view(np.int64), return_counts=True)
         post8 = postings_of(uk8, uc8)
         rows8 = dc8.stats()[0]
         alg8, entry8 = ix_alg_bytes(-(-rows8 // 16384), post8)
         t8, t8_src = pmc_traffic("ts_match_index_topk", tag="shard8")        # (keyed by workload: the r3 line looked up a row count)
+        # the same shard as a STREAM of batches (three in flight on their own streams, one-rank communicator: the whole
+        # tvz_match_sharded call per batch), per shape: what a GPU of configs[3] sustains
+        pipe = {}
+        comm8 = sharded.make_comm(dev.index)
+        for name, fl in (("wave_per_query", _lib.ALGO_PREFER_WAVE), ("block_per_query", _lib.ALGO_NO_WAVE)):
+            try:
+                m8 = sharded.RcclShardedMatcher(dc8, comm8, k=K_TOP, cap=CAP, n_streams=3, algo=fl)
+                for i in range(10):
+                    m8.match_topk(batches[i % NB][0], batches[i % NB][1], max_len, 2)
+                torch.cuda.synchronize()
+                tp = time.perf_counter()
+                run_stream(m8, 3, 120, lambda i: batches[i % NB])
+                torch.cuda.synchronize()
+                pipe[name] = round((time.perf_counter() - tp) * 1e3 / 120, 4)
+            except Exception as e:            # noqa: BLE001 - a secondary figure
+                pipe[name] = repr(e)
+        comm8.close()
         out["shard8_roofline"] = {
-            "bound": "hbm", "kernel": f"ts_match_index_topk_kernel on rank 0's 1/8 shard ({rows8} rows), the same rotating batches of {Q} queries",
+            "bound": "hbm", "kernel": f"ts_match_index_topk_kernel on rank 0's 1/8 shard ({rows8} rows, one sub-index: bucket "
+                                      f"directory), the same rotating batches of {Q} queries",
             "achieved": alg8 / (ms8 * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": alg8 / (ms8 * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": t8, "traffic_source": t8_src,
             "algorithmic_bytes_per_launch": alg8, "avg_launch_ms": ms8,
             "workload": f"rank 0's 1/8 shard of {C} videos ({rows8} rows) x {Q} queries",
             "pairs_per_s": Q * rows8 / (ms8 * 1e-3),
-            "limiter": "instruction issue, as on the full corpus, plus the per-query part that does not shrink with the "
-                       "shard (offsets -> keys -> directory probe: 10.7 us net of the 60 us launch, profiles/r4_probe_prepass.txt)"}
+            **bound_fields("ts_match_index_topk", "shard8"),
+            "wave_per_query_kernel": {"name": "ts_match_wq_topk_kernel (TVZ_ALGO_WAVE)", "avg_launch_ms": ms8_wave,
+                                      "traffic": pmc_traffic("ts_match_wq_topk", tag="shard8_wave")[0],
+                                      **bound_fields("ts_match_wq_topk", "shard8_wave")},
+            "ms_per_batch_as_a_stream_of_batches": dict(pipe, note="tvz_match_sharded, three batches in flight, Python host "
+                                                                    "(~30 us of host time per batch: close to its floor)"),
+            "limiter": "latency, not a throughput ceiling: see frac_bound (the nearest resource is the fabric's random-line "
+                       "rate, one 128-byte bucket line per query timestamp) and wave_cycles_waiting_share"}
         dc8.close()
     # ---- the same batch forced onto the corpus sweep (what AUTO runs without an index) ----
     alg = corpus_bytes * n_tiles + n_hits * 12.0
@@ -834,6 +871,33 @@ def run_under_watchdog(leg, timeout: float, rank: int, world: int, out: dict, ke
     return res
 
 
+def pmc_entry(kernel: str, tag: str):
+    """The committed counter summary's whole entry for (workload tag, kernel) - profiles/summarize_match.py: HBM
+    traffic, and the resource the kernel is closest to (`frac_bound`: VALU issue, the LDS arrays, or the rate the
+    fabric delivers random 128-byte lines) - or None."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_match_pmc_summary.json"))):
+        try:
+            e = json.load(open(f)).get(tag, {}).get(kernel)
+            if e:
+                best = dict(e, source=f"profiles/{os.path.basename(f)}")
+        except Exception:
+            pass
+    return best
+
+
+def bound_fields(kernel: str, tag: str):
+    e = pmc_entry(kernel, tag) or {}
+    fb = e.get("frac_bound")
+    return {"frac_bound": dict(fb, bounds=e.get("bounds"), source=e.get("source"),
+                               note="share of the resource's capacity over the kernel's own duration, committed counter pass "
+                                    "(profiles/summarize_match.py: VALU issue, LDS-array cycles, random 128-byte lines "
+                                    "against 30.3 G lines/s); the largest of the three") if fb else None,
+            "lds_bank_conflict_share": e.get("lds_bank_conflict_share"),
+            "wave_cycles_waiting_share": e.get("wave_cycles_waiting_share")}
+
+
 def main(argv=None):
     argv = list(sys.argv[1:] if argv is None else argv)
     args = parse(argv)
@@ -949,6 +1013,15 @@ def main(argv=None):
                                 "avg_launch_ms": r["avg_launch_ms"], "algorithmic_bytes": r["algorithmic_bytes_per_launch"],
                                 "traffic": r["traffic"], "frac": r["frac"], "pairs_per_s": r.get("pairs_per_s"),
                                 "frac_bound": r.get("frac_bound")})
+        wk = (match_leg.get("shard8_roofline") or {}).get("wave_per_query_kernel")
+        if wk and wk.get("avg_launch_ms"):
+            r8 = match_leg["shard8_roofline"]
+            kernels.append({"name": "ts_match_wq_topk_kernel", "workload": r8.get("workload") + " (one wave per query)",
+                            "avg_launch_ms": wk["avg_launch_ms"], "algorithmic_bytes": r8["algorithmic_bytes_per_launch"],
+                            "traffic": wk.get("traffic"),
+                            "frac": r8["algorithmic_bytes_per_launch"] / (wk["avg_launch_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                            "pairs_per_s": r8["pairs_per_s"] * r8["avg_launch_ms"] / wk["avg_launch_ms"],
+                            "frac_bound": wk.get("frac_bound")})
         kernels.append({"name": "tvz_match_sharded (whole batch: lookup with top-k -> ncclAllGather -> merge, pipelined)",
                         "workload": f"{match_leg['corpus_videos']} videos x {match_leg['queries_per_batch']} queries over "
                                     f"{match_leg['rccl_ranks']} RCCL rank(s)",

@@ -18,13 +18,13 @@ for name, out in (("bench.json", f"{tag}_bench.json"), ("predicted_scaling.json"
                   ("match_ab.txt", f"{tag}_match_ab_raw.txt"), ("rebuild_latency.txt", f"{tag}_rebuild_latency.txt"),
                   ("ix_stamps.txt", f"{tag}_ix_stamps.txt"), ("scale_probe.txt", f"{tag}_scale_probe.txt"),
                   ("fuzz_parity.txt", f"{tag}_fuzz_parity.txt"), ("rebuild_trace.txt", f"{tag}_rebuild_trace.txt"),
-                  ("topk_probe.txt", f"{tag}_topk_probe.txt")):
+                  ("topk_probe.txt", f"{tag}_topk_probe.txt"), ("ab_wave.txt", f"{tag}_shard_shapes.txt")):
     p = os.path.join(src, name)
     if os.path.exists(p) and os.path.getsize(p):
         shutil.copy(p, os.path.join(dst, out))
 # the kernel-trace stats of each matcher workload (rocprofv3 --kernel-trace --stats)
 import glob
-for w in ("topk", "index", "index1", "join", "q1_100k", "q1_5k", "tile", "shard8"):
+for w in ("topk", "index", "index1", "join", "q1_100k", "q1_5k", "tile", "shard8", "shard8_wave", "shard8_block"):
     f = glob.glob(os.path.join(root, "gpurun_out", f"pmc_match_{tag}", w, "trace", "**", "*kernel_stats.csv"), recursive=True)
     if f:
         shutil.copy(f[0], os.path.join(dst, f"{tag}_match_{w}_kernel_stats.csv"))

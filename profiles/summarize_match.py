@@ -81,6 +81,32 @@ for w in sorted(os.listdir(src)):
         if "WRITE_SIZE" in avg:
             e["hbm_write_bytes"] = avg["WRITE_SIZE"] * 1024
             der["hbm_write_MB"] = round(e["hbm_write_bytes"] / 1e6, 2)
+        # Which resource is the kernel closest to?  (a ceiling that means something for a kernel
+        # HBM bandwidth does not bound.)  Per launch, over the kernel's own duration from the trace pass:
+        #   VALU issue : SQ_INSTS_VALU wave-instructions x 2 cycles (a wave64 instruction on a SIMD-32, MI355X_MICROARCH.md)
+        #                / (256 CUs x 4 SIMDs x 2.4 GHz x duration)
+        #   LDS        : SQ_LDS_IDX_ACTIVE (all LDS-array cycles, bank-conflict cycles included) / (256 CUs x 2.4 GHz x duration)
+        #   fabric     : TCC_EA0_RDREQ (128-byte requests that leave the L2s) / duration, against the rate the memory
+        #                system delivers RANDOM 128-byte lines: 818 k lines in 27 us = 30.3 G lines/s (a pure probe pass
+        #                over the directory, profiles/r4_probe_prepass.txt; profiles/r3_calib_fetch.txt: one request per random read)
+        if "duration_ns" in avg and avg["duration_ns"] > 0:
+            dur = avg["duration_ns"] * 1e-9
+            b = {}
+            if "SQ_INSTS_VALU" in avg:
+                b["valu_issue"] = avg["SQ_INSTS_VALU"] * 2.0 / (256 * 4 * 2.4e9 * dur)
+            if "SQ_LDS_IDX_ACTIVE" in avg:
+                b["lds"] = avg["SQ_LDS_IDX_ACTIVE"] / (256 * 2.4e9 * dur)
+            if "TCC_EA0_RDREQ_sum" in avg:
+                b["fabric_random_lines"] = avg["TCC_EA0_RDREQ_sum"] / dur / 30.3e9
+            if b:
+                top = max(b, key=b.get)
+                e["bounds"] = {k: round(v, 3) for k, v in b.items()}
+                e["frac_bound"] = {"resource": top, "frac": round(b[top], 3)}
+                if avg.get("SQ_LDS_IDX_ACTIVE"):
+                    e["lds_bank_conflict_share"] = round(avg.get("SQ_LDS_BANK_CONFLICT", 0) / avg["SQ_LDS_IDX_ACTIVE"], 3)
+                if avg.get("SQ_WAVE_CYCLES"):
+                    e["wave_cycles_waiting_share"] = round(avg.get("SQ_WAIT_ANY", 0) / avg["SQ_WAVE_CYCLES"], 3)
+                der["bounds"] = e["bounds"]
         if "duration_ns" in avg:
             e["avg_duration_ns"] = avg["duration_ns"]
             if "hbm_read_bytes_corrected" in e:
