@@ -156,6 +156,9 @@ class RcclShardedMatcher:
         self.out = [None] * n_streams
         self.events = [torch.cuda.Event() for _ in range(n_streams)]
         self._i = 0
+        self._plans = {}                    # (slot, query tensors, shape) -> the library call's arguments (submit)
+        self._lib = _lib
+        self._call = comm.lib.tvz_match_sharded
 
     def submit(self, d_queries: torch.Tensor, d_q_offsets: torch.Tensor, max_query_len: int,
                min_match: int, d_exclude_ids: Optional[torch.Tensor] = None, inputs_ready: bool = False):
@@ -174,18 +177,37 @@ class RcclShardedMatcher:
         i = self._i
         self._i = (i + 1) % len(self.streams)
         st = self.streams[i]
-        Q = d_q_offsets.numel() - 1
-        need = tc.workspace_bytes(Q, max_query_len, self.cap, self.k, self.world, d_queries.numel())
-        if self.ws[i] is None or self.ws[i].numel() < need:
-            self.ws[i] = torch.empty(need, dtype=torch.uint8, device=self.dev)
-        if self.out[i] is None or self.out[i][0].shape[0] != Q:
-            self.out[i] = (torch.empty((Q, self.k, 3), dtype=torch.int32, device=self.dev),
-                           torch.empty(Q, dtype=torch.int32, device=self.dev))
+        # Steady state: the same query tensors come round again (a service's staging slots, a benchmark's rotating
+        # batches).  Everything that does not change with them - workspace, outputs, the seventeen arguments of the
+        # library call - is kept as a PLAN per (slot, tensors, shape): a batch on a 1/8 shard is ~40 us of GPU time and
+        # the un-planned submit was 30 us of interpreter time, the pipeline's actual bound.
+        key = (i, d_queries.data_ptr(), d_q_offsets.data_ptr(), int(max_query_len), int(min_match),
+               d_exclude_ids.data_ptr() if d_exclude_ids is not None else 0, d_queries.numel(), d_q_offsets.numel())
+        plan = self._plans.get(key)
+        if plan is None:
+            Q = d_q_offsets.numel() - 1
+            self.corpus._check_queries(d_queries, d_q_offsets)
+            need = tc.workspace_bytes(Q, max_query_len, self.cap, self.k, self.world, d_queries.numel())
+            if self.ws[i] is None or self.ws[i].numel() < need:
+                self.ws[i] = torch.empty(need, dtype=torch.uint8, device=self.dev)
+                self._plans = {k_: v for k_, v in self._plans.items() if k_[0] != i}     # (their workspace is gone)
+            if self.out[i] is None or self.out[i][0].shape[0] != Q:
+                self.out[i] = (torch.empty((Q, self.k, 3), dtype=torch.int32, device=self.dev),
+                               torch.empty(Q, dtype=torch.int32, device=self.dev))
+                self._plans = {k_: v for k_, v in self._plans.items() if k_[0] != i}
+            merged, totals = self.out[i]
+            args = (self.corpus._h, self.comm._h, key[1], key[2], Q, key[3], key[4], key[5] or None, self.cap, self.k,
+                    merged.data_ptr(), totals.data_ptr(), self.ws[i].data_ptr(), self.ws[i].numel(), self.algo,
+                    st.cuda_stream)
+            if len(self._plans) > 256:
+                self._plans.clear()
+            plan = self._plans[key] = (args, merged, totals, self.ws[i])
+        args, merged, totals, _ws = plan
         if not inputs_ready:
             st.wait_stream(torch.cuda.current_stream(self.dev))   # the queries are complete before the match reads them
-        merged, totals = self.comm.match_sharded(self.corpus, d_queries, d_q_offsets, max_query_len,
-                                                 min_match, self.cap, self.k, d_exclude_ids,
-                                                 workspace=self.ws[i], stream=st, out=self.out[i], algo=self.algo)
+        rc = self._call(*args)
+        if rc:
+            self._lib.check(rc)
         ev = self.events[i]
         ev.record(st)
         return (merged, totals, ev)
