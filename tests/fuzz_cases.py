@@ -123,7 +123,7 @@ def run(seconds: float = 60.0, seed: int = 12345, max_cases: int = 0, device: st
                 rounds = 0
                 while th.is_alive() or rounds < 2:
                     hits, n = dc.match(d_q, d_off, ml, 2, 4096)
-                    wsz = torch.empty(tc.workspace_bytes(len(cq), ml, 4096, 16), dtype=torch.uint8, device=dev)
+                    wsz = torch.empty(tc.workspace_bytes(len(cq), ml, 4096, 16, total_query_keys=d_q.numel()), dtype=torch.uint8, device=dev)
                     blk = dc.match_topk(d_q, d_off, ml, 2, 4096, 16, workspace=wsz, algo=int(rng.choice([0, _lib.ALGO_PAIR, _lib.ALGO_PREFER_WAVE])))
                     torch.cuda.synchronize()
                     hits, n, blk = hits.cpu().numpy(), n.cpu().numpy(), blk.cpu().numpy()
@@ -204,7 +204,7 @@ def run(seconds: float = 60.0, seed: int = 12345, max_cases: int = 0, device: st
             if mm >= 1 or rng.random() < 0.3:
                 k = int(rng.choice([1, 8, 16, 64, 100]))
                 capk = int(rng.choice([max(C, 1), 40, 2000]))
-                ws = torch.empty(tc.workspace_bytes(Q, ml, capk, k), dtype=torch.uint8, device=dev)
+                ws = torch.empty(tc.workspace_bytes(Q, ml, capk, k, total_query_keys=d_q.numel()), dtype=torch.uint8, device=dev)
                 # the fused lookup's shape - two queries per block, one, or the library's choice - never changes a result
                 # (on a handle of one sub-index PREFER_WAVE takes the one-wave-per-query kernel, the others the block kernel)
                 shape = int(rng.choice([0, _lib.ALGO_PAIR, _lib.ALGO_NO_PAIR, _lib.ALGO_PREFER_WAVE, _lib.ALGO_PREFER_WAVE | _lib.ALGO_NO_PAIR]))

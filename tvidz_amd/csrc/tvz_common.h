@@ -18,7 +18,7 @@
 // NEGATED version, which every binding refuses (tvidz_amd/_lib.py loads such a library only with
 // TVZ_ALLOW_DIAGNOSTIC=1, the profile scripts' own environment).
 #if defined(TVZ_IX_STOP) || defined(TVZ_IX_FAKEPOST) || defined(TVZ_IX_NOIVID) || defined(TVZ_IX_NOSTORE) || \
-    defined(TVZ_IX_STAMP) || defined(TVZ_DIAGNOSTIC)
+    defined(TVZ_IX_STAMP) || defined(TVZ_WQ_NOPOST) || defined(TVZ_DIAGNOSTIC)
 #define TVZ_DIAGNOSTIC_BUILD 1
 #else
 #define TVZ_DIAGNOSTIC_BUILD 0

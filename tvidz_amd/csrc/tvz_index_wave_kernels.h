@@ -279,7 +279,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
                     before += (uint32_t)__popcll(M);
                 }
 #pragma unroll
+#ifdef TVZ_WQ_NOPOST      // diagnostic build only (WRONG results): no posting is fetched, the row is made up from the address
+                for (int u = 0; u < 4; ++u) R[g * 4 + u] = ((e[u].x + (uint32_t)((g * 4 + u) * 64 + lane)) * 2654435761u) >> (32 - kSubLog2);
+#else
                 for (int u = 0; u < 4; ++u) R[g * 4 + u] = (uint32_t)post[e[u].x + (uint32_t)((g * 4 + u) * 64 + lane)];
+#endif
                 P[g * 2] = (e[0].y & 0x1ffu) | ((e[1].y & 0x1ffu) << 16);
                 P[g * 2 + 1] = (e[2].y & 0x1ffu) | ((e[3].y & 0x1ffu) << 16);
             } else {

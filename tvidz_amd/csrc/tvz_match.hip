@@ -1168,7 +1168,10 @@ int launch_index_topk(tvz_corpus *c, const double *d_queries, const int64_t *d_q
     const int one = max_query_len > 0 ? max_query_len : 1;
     const size_t lds2 = ix_lds_bytes(2 * one, ix.n_sub, true);
     const bool no_pair = (flags & TVZ_ALGO_NO_PAIR) != 0, force_pair = (flags & TVZ_ALGO_PAIR) != 0;   // per call, like the algorithm
-    const bool pair = Q >= 2 && (Q >= 2 * kIxResidentBlocks || force_pair) &&
+    // (On a handle of ONE sub-index pairs answered a stream of batches sooner - 42 against 46 us - and a lone batch
+    // later - 66 against 62: streams of batches take the wave kernel there now, so the block kernel's default on such
+    // a handle is the shape that answers a lone batch soonest.)
+    const bool pair = Q >= 2 && ((Q >= 2 * kIxResidentBlocks && ix.nb == 0) || force_pair) &&
                       lds2 + 256 <= (size_t)kLdsPerWorkgroup / 4 && !no_pair;   // (+ the body's static LDS)
     const size_t lds = pair ? lds2 : ix_lds_bytes(max_query_len, ix.n_sub, true);
     const unsigned grid = pair ? (unsigned)((Q + 1) / 2) : (unsigned)Q;
