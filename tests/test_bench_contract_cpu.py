@@ -1,5 +1,5 @@
 """The shape of bench.py's one JSON line, checked on the line the final build printed on the GPU box
-(profiles/r3_bench.json): the driver's contract fields, the roofline and cpu_baseline objects, and
+(profiles/r5_bench.json): the driver's contract fields, the roofline and cpu_baseline objects, and
 the arithmetic that ties them together.  (bench.py itself needs a GPU: tests/test_abi.py checks that
 it refuses to run without one.)"""
 import json
@@ -9,7 +9,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _line():
-    with open(os.path.join(ROOT, "profiles", "r3_bench.json")) as f:
+    with open(os.path.join(ROOT, "profiles", "r5_bench.json")) as f:
         lines = [ln for ln in f.read().splitlines() if ln.strip()]
     assert len(lines) == 1, "bench.py prints ONE line on stdout"
     return json.loads(lines[0])
@@ -42,6 +42,41 @@ def test_roofline_and_cpu_baseline_objects():
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["unit"] == "frames/s" and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
     assert c["agrees_with_gpu"] is True and c["single_core"]["cores"] == 1
+
+
+def test_both_halves_of_the_metric_are_in_the_objects_the_driver_keeps():
+    """roofline.kernels carries the luma-SAD kernel and both lookups (full corpus, 1/8 shard) with what a
+    reader needs to recompute their fractions; cpu_baseline.matcher the two CPU restatements of find_duplicates; the
+    headline fraction uses the same time base as ms_per_step."""
+    d = _line()
+    r = d["roofline"]
+    assert abs(r["avg_launch_ms"] - d["ms_per_step"]) < 1e-12
+    ks = r["kernels"]
+    names = [k["name"] for k in ks]
+    assert names[0] == "luma_sad_flat_kernel" and names.count("ts_match_index_topk_kernel") == 2 and "ts_match_wq_topk_kernel" in names
+    for k in ks:
+        if "algorithmic_bytes" in k:
+            assert abs(k["frac"] - k["algorithmic_bytes"] / (k["avg_launch_ms"] * 1e-3) / 1e9 / 8000.0) < 1e-9, k["name"]
+        if k["name"].startswith("ts_match"):
+            assert k["pairs_per_s"] > 0 and k["frac_bound"]["resource"] in ("valu_issue", "lds", "fabric_random_lines")
+            assert 0 < k["frac_bound"]["frac"] < 1 and set(k["frac_bound"]["bounds"]) == {"valu_issue", "lds", "fabric_random_lines"}
+    m = d["cpu_baseline"]["matcher"]
+    assert m["python_restatement"]["cores"] == 1 and m["c_sorted_binary_search"]["cores"] >= 1
+    assert m["python_restatement"]["unit"] == m["c_sorted_binary_search"]["unit"] == "pairs/s"
+    assert d["match"]["rccl_ranks"] == d["n_gpus"] == 1
+
+
+def test_e2e_counts_scored_frames_and_stays_under_the_link():
+    """e2e.value = frames the scene kernels scored (an upload stops at its duplicate verdict,
+    inspector/app.py:249-255), never uploads x frames; and what was scored crossed the link: GBps_luma <= h2d.GBps x the
+    copies in flight."""
+    d = _line()
+    for e in [d["e2e"]] + d["e2e"].get("other_shapes", []):
+        assert e["frames_scored"] <= e["frames_submitted"] == e["uploads"] * e["frames_per_upload"]
+        assert abs(e["value"] - e["frames_scored"] * e["submitted_frames_per_s"] / e["frames_submitted"]) / e["value"] < 1e-6
+        assert e["GBps_luma"] <= d["h2d"]["GBps"] * d["e2e"]["h2d_bound_check"]["copies_in_flight"] * 1.02
+    assert d["e2e"]["h2d_bound_check"]["ok"] is True
+    assert [e["uploads"] for e in d["e2e"]["other_shapes"]] == [64]                 # configs[4]'s shape
 
 
 def test_secondary_objects():
