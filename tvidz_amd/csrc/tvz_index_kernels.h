@@ -70,7 +70,7 @@ struct IxBuildInfo {       // device-side build status, read back by the host
 constexpr int kIxMaxProbe = 4096;
 // entries behind the last posting that the lookups may READ (and discard): the lanes of a wave's last step of 64
 // postings (ix_lookup_body), the dead steps of a live group of four (ts_match_wq_topk_kernel)
-constexpr int kIxPostPad = 64 + 256;
+constexpr int kIxPostPad = 64 + 512;   // (dead steps of a live group of up to eight)
 #ifndef TVZ_IX_SUB_LOG2
 #define TVZ_IX_SUB_LOG2 14
 #endif

@@ -30,6 +30,10 @@ constexpr int kWqChunks = 8;                         // chunks of 64 query posit
 constexpr int kWqMaxLen = kWqChunks * 64;            // longest query this kernel takes
 constexpr int kWqSteps = 64;                         // register-resident steps of 64 postings
 constexpr int kWqRegPost = kWqSteps * 64;            // postings kept in registers between the passes
+#ifndef TVZ_WQ_GS
+#define TVZ_WQ_GS 4
+#endif
+constexpr int kWqGs = TVZ_WQ_GS;                       // steps per group: their LDS (and global) round trips overlap
 constexpr int kWqSlots = 512;                        // candidate slots per part (384: 12 waves per CU instead of 11, but every sixth query of the 1/8 shard took two parts - no faster)
 constexpr int kWqPosShift = kSubLog2;                // register entry = row | position << 14
 static_assert(kSubLog2 + 9 <= 32 && kWqMaxLen <= 512, "packed register entries");
@@ -263,12 +267,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
         uint32_t P[kWqSteps / 2];                          // positions of the steps' lists, two per register (stage 2 folds them into R)
         uint32_t before = 0;                               // list starts before the current step (wave-uniform)
 #pragma unroll
-        for (int g = 0; g < kWqSteps / 4; ++g) {
-            if (g * 4 < n_steps) {                         // (scalar branch)
-                uint2 e[4];
+        for (int g = 0; g < kWqSteps / kWqGs; ++g) {
+            if (g * kWqGs < n_steps) {                         // (scalar branch)
+                uint2 e[kWqGs];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const unsigned long long Mv = *reinterpret_cast<const unsigned long long *>(lbits + 2 * (g * 4 + u));
+                for (int u = 0; u < kWqGs; ++u) {
+                    const unsigned long long Mv = *reinterpret_cast<const unsigned long long *>(lbits + 2 * (g * kWqGs + u));
                     const uint32_t mlo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)Mv);
                     const uint32_t mhi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(Mv >> 32));
                     const unsigned long long M = ((unsigned long long)mhi << 32) | mlo;      // in SGPRs
@@ -280,38 +284,39 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
                 }
 #pragma unroll
 #ifdef TVZ_WQ_NOPOST      // diagnostic build only (WRONG results): no posting is fetched, the row is made up from the address
-                for (int u = 0; u < 4; ++u) R[g * 4 + u] = ((e[u].x + (uint32_t)((g * 4 + u) * 64 + lane)) * 2654435761u) >> (32 - kSubLog2);
+                for (int u = 0; u < kWqGs; ++u) R[g * kWqGs + u] = ((e[u].x + (uint32_t)((g * kWqGs + u) * 64 + lane)) * 2654435761u) >> (32 - kSubLog2);
 #else
-                for (int u = 0; u < 4; ++u) R[g * 4 + u] = (uint32_t)post[e[u].x + (uint32_t)((g * 4 + u) * 64 + lane)];
+                for (int u = 0; u < kWqGs; ++u) R[g * kWqGs + u] = (uint32_t)post[e[u].x + (uint32_t)((g * kWqGs + u) * 64 + lane)];
 #endif
-                P[g * 2] = (e[0].y & 0x1ffu) | ((e[1].y & 0x1ffu) << 16);
-                P[g * 2 + 1] = (e[2].y & 0x1ffu) | ((e[3].y & 0x1ffu) << 16);
+#pragma unroll
+                for (int u = 0; u < kWqGs; u += 2)
+                    P[(g * kWqGs + u) >> 1] = (e[u].y & 0x1ffu) | ((e[u + 1].y & 0x1ffu) << 16);
             } else {
 #pragma unroll
-                for (int u = 0; u < 4; ++u) R[g * 4 + u] = 0;
-                P[g * 2] = 0;
-                P[g * 2 + 1] = 0;
+                for (int u = 0; u < kWqGs; ++u) R[g * kWqGs + u] = 0;
+#pragma unroll
+                for (int u = 0; u < kWqGs; u += 2) P[(g * kWqGs + u) >> 1] = 0;
             }
         }
         TVZ_WQ_STAMP(2);
         // Stage 2 - pass A proper: every posting sets its row's bit in seen1, or in seen2 if it was set already
 #pragma unroll
-        for (int g = 0; g < kWqSteps / 4; ++g) {
-            if (g * 4 < n_steps) {
-                uint32_t r[4], old[4];
+        for (int g = 0; g < kWqSteps / kWqGs; ++g) {
+            if (g * kWqGs < n_steps) {
+                uint32_t r[kWqGs], old[kWqGs];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const bool live = (uint32_t)((g * 4 + u) * 64 + lane) < c_hi;
-                    r[u] = live ? R[g * 4 + u] : 0u;
+                for (int u = 0; u < kWqGs; ++u) {
+                    const bool live = (uint32_t)((g * kWqGs + u) * 64 + lane) < c_hi;
+                    r[u] = live ? R[g * kWqGs + u] : 0u;
                     // (a posting that does not exist ORs nothing into word 0)
                     old[u] = atomicOr(&bm1[r[u] >> 5], live ? 1u << (r[u] & 31u) : 0u);
-                    R[g * 4 + u] = r[u] | (((P[(g * 4 + u) >> 1] >> ((u & 1) * 16)) & 0x1ffu) << kWqPosShift);
+                    R[g * kWqGs + u] = r[u] | (((P[(g * kWqGs + u) >> 1] >> ((u & 1) * 16)) & 0x1ffu) << kWqPosShift);
                 }
                 if (min_match >= 2) {
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) {
+                    for (int u = 0; u < kWqGs; ++u) {
                         const uint32_t bit = 1u << (r[u] & 31u);
-                        const bool live = (uint32_t)((g * 4 + u) * 64 + lane) < c_hi;
+                        const bool live = (uint32_t)((g * kWqGs + u) * 64 + lane) < c_hi;
                         if (live && (old[u] & bit)) atomicOr(&bm2[r[u] >> 5], bit);
                     }
                 }
@@ -408,24 +413,24 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
             if (idx < (uint32_t)kWqSlots) account_slot(idx, pos);
         };
 #pragma unroll
-        for (int g = 0; g < kWqSteps / 4; ++g) {
-            if (g * 4 < n_steps) {
+        for (int g = 0; g < kWqSteps / kWqGs; ++g) {
+            if (g * kWqGs < n_steps) {
                 // all reads of a stage before the next stage (dead steps hold row 0 / position 0: masked below)
                 // (an opaque copy of the register entry: everything derived from it - word index, bit mask, position -
                 // is otherwise hoisted out of the loop over the parts for all 64 steps at once, and spilled)
-                uint32_t w[4], rkw[4], rr[4];
+                uint32_t w[kWqGs], rkw[kWqGs], rr[kWqGs];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    rr[u] = (uint32_t)ix_opaque((int)R[g * 4 + u]);
+                for (int u = 0; u < kWqGs; ++u) {
+                    rr[u] = (uint32_t)ix_opaque((int)R[g * kWqGs + u]);
                     const uint32_t r = rr[u] & (uint32_t)(kSubRows - 1);
                     w[u] = cand[r >> 5];
                     rkw[u] = rank[r >> 5];
                 }
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
+                for (int u = 0; u < kWqGs; ++u) {
                     const uint32_t r = rr[u] & (uint32_t)(kSubRows - 1);
                     const uint32_t idx = slot_of(r, w[u], rkw[u]);
-                    if ((uint32_t)((g * 4 + u) * 64 + lane) < c_hi && idx < (uint32_t)kWqSlots)
+                    if ((uint32_t)((g * kWqGs + u) * 64 + lane) < c_hi && idx < (uint32_t)kWqSlots)
                         account_slot(idx, rr[u] >> kWqPosShift);
                 }
             }
