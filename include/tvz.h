@@ -184,6 +184,12 @@ int tvz_corpus_build_index(tvz_corpus *c);
  * builds so far (any may be NULL); all 0 while there is no index. */
 int tvz_corpus_index_stats(tvz_corpus *c, int64_t *n_indexed_rows, int64_t *n_delta_rows,
                            int64_t *n_postings, int64_t *n_distinct_keys, int64_t *n_builds);
+/* The directory of a handle of ONE sub-index (up to 16,384 indexed rows) is a table of 128-byte buckets - a key's
+ * entry and its postings in one cache line.  out[0] = buckets (0: the handle has no index, or more than one
+ * sub-index: the open-addressing directory), out[1] = keys that do not live in their home bucket, out[2] = how far
+ * the farthest of them walked (buckets), out[3] = keys whose posting list lives in the external area,
+ * out[4] = external postings (uint16 units, whole lines), out[5] = sub-indexes. */
+int tvz_corpus_bucket_stats(tvz_corpus *c, int64_t out[6]);
 
 /* ------------------------------------------------------------------------
  * Corpus match   — replaces db.find_duplicates (inspector/db.py:76-94) and

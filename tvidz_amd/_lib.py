@@ -44,6 +44,7 @@ SIGNATURES = {
     "tvz_corpus_clear": (C.c_int, [_P]),
     "tvz_corpus_build_index": (C.c_int, [_P]),
     "tvz_corpus_index_stats": (C.c_int, [_P] + [C.POINTER(C.c_int64)] * 5),
+    "tvz_corpus_bucket_stats": (C.c_int, [_P, C.POINTER(C.c_int64)]),
     "tvz_corpus_stats": (C.c_int, [_P, C.POINTER(C.c_int64), C.POINTER(C.c_int64),
                                    C.POINTER(C.c_int64)]),
     "tvz_match_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),

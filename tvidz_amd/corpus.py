@@ -112,6 +112,14 @@ class DeviceCorpus:
         return dict(zip(("indexed_rows", "delta_rows", "postings", "distinct_keys", "builds"),
                         (int(x.value) for x in v)))
 
+    def bucket_stats(self) -> dict:
+        """The bucket directory of a one-sub-index handle (tvz_corpus_bucket_stats): buckets (0: none), keys outside
+        their home bucket, the farthest walk, keys with external lists, external postings, sub-indexes."""
+        v = (C.c_int64 * 6)()
+        _lib.check(self.lib.tvz_corpus_bucket_stats(self._h, v))
+        return dict(zip(("buckets", "keys_walked_on", "max_walk", "external_lists", "external_postings", "sub_indexes"),
+                        (int(x) for x in v)))
+
     def stats(self) -> Tuple[int, int, int]:
         a, b, c = C.c_int64(), C.c_int64(), C.c_int64()
         _lib.check(self.lib.tvz_corpus_stats(self._h, C.byref(a), C.byref(b), C.byref(c)))

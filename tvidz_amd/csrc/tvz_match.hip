@@ -121,7 +121,7 @@ struct IndexBuf {
     int ks = 0;                       // uint16 counts per directory entry
     int64_t n_main = 0;               // rows [0, n_main) are indexed
     int64_t n_post = 0, n_distinct = 0;
-    int64_t n_spilled = 0, n_ext = 0, max_spill = 0;   // bucket directory: keys outside their home bucket / with external lists
+    int64_t n_spilled = 0, n_ext = 0, max_spill = 0, ext_used = 0;   // bucket directory: keys outside their home bucket / with external lists
 };
 
 struct Index {
@@ -479,6 +479,7 @@ int build_kernels(tvz_corpus *c, IndexBuf &b, const Row *d_rows, int64_t n_rows,
             b.n_spilled = info.n_spilled;
             b.n_ext = info.n_ext;
             b.max_spill = info.max_spill;
+            b.ext_used = info.ext_cursor;
             ix.hint_post = (int64_t)info.cursor;
             ix.hint_distinct = (int64_t)info.n_distinct;
             if (getenv("TVZ_DEBUG"))
@@ -2344,6 +2345,26 @@ TVZ_EXPORT int tvz_corpus_upload(tvz_corpus *c, const int32_t *h_video_ids,
 
 TVZ_EXPORT int tvz_corpus_build_index(tvz_corpus *c) {
     TVZ_GUARDED(tvz_corpus_build_index_impl(c));
+}
+
+static int tvz_corpus_bucket_stats_impl(tvz_corpus *c, int64_t *out) {
+    TVZ_REQUIRE(c != nullptr && out != nullptr, "NULL argument");
+    std::shared_lock<std::shared_mutex> lk(c->mu);
+    const Index &ix = c->ix;
+    for (int i = 0; i < 6; ++i) out[i] = 0;
+    if (!ix.valid) return TVZ_OK;
+    const IndexBuf &b = ix.now();
+    out[0] = b.nb;
+    out[1] = b.nb ? b.n_spilled : 0;
+    out[2] = b.nb ? b.max_spill : 0;
+    out[3] = b.nb ? b.n_ext : 0;
+    out[4] = b.nb ? b.ext_used : 0;
+    out[5] = b.n_sub;
+    return TVZ_OK;
+}
+
+TVZ_EXPORT int tvz_corpus_bucket_stats(tvz_corpus *c, int64_t out[6]) {
+    TVZ_GUARDED(tvz_corpus_bucket_stats_impl(c, out));
 }
 
 TVZ_EXPORT int tvz_corpus_index_stats(tvz_corpus *c, int64_t *n_indexed_rows, int64_t *n_delta_rows,
