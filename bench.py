@@ -777,7 +777,8 @@ def launch_ranks(args, argv) -> int:
     """--gpus N without a launcher around it (WORLD_SIZE unset): THIS process has not touched a GPU and never
     will - it starts N FRESH rank processes (one per GPU; nothing is exec'ed over a process that has initialised
     the GPU), relays rank 0's one JSON line and returns the WORST return code of the ranks.  When a rank fails the
-    others get 10 s to leave by themselves (a watchdog's return code 3 is worth more than a SIGTERM's), then are ended."""
+    others get 10 s to leave by themselves (a watchdog's return code 3 is worth more than a SIGTERM's), then are ended
+    (SIGTERM, and SIGKILL 10 s later for a rank that does not react)."""
     cmd, port, n = launcher_cmd(argv), free_port(), args.gpus
     if args.dry_launch:
         print(json.dumps({"launch": cmd, "ranks": n,
@@ -801,17 +802,22 @@ def launch_ranks(args, argv) -> int:
                 sys.stderr.write(txt)
     th = threading.Thread(target=relay, daemon=True)
     th.start()
-    first_fail = None
+    first_fail = term_at = None
     while any(p.poll() is None for p in procs):
         time.sleep(0.05)
         bad = [p for p in procs if p.poll() not in (None, 0)]
         if bad and first_fail is None:
             first_fail = time.monotonic()
-        if first_fail is not None and time.monotonic() - first_fail > 10.0:
+        if first_fail is not None and term_at is None and time.monotonic() - first_fail > 10.0:
             for p in procs:
                 if p.poll() is None:
                     p.terminate()                             # the exact processes this launcher started
-            first_fail = time.monotonic() + 1e9
+            term_at = time.monotonic()
+        if term_at is not None and time.monotonic() - term_at > 10.0:
+            for p in procs:                                   # a rank stuck in the driver does not see SIGTERM
+                if p.poll() is None:
+                    p.kill()
+            term_at = time.monotonic() + 1e9
     th.join(5.0)
     rcs = [p.returncode if p.returncode >= 0 else 128 - p.returncode for p in procs]
     rc = max(rcs)
