@@ -35,14 +35,20 @@ constexpr int kWqRegPost = kWqSteps * 64;            // postings kept in registe
 #endif
 constexpr int kWqGs = TVZ_WQ_GS;                       // steps per group: their LDS (and global) round trips overlap
 constexpr int kWqSlots = 512;                        // candidate slots per part (384: 12 waves per CU instead of 11, but every sixth query of the 1/8 shard took two parts - no faster)
-constexpr int kWqPosShift = kSubLog2;                // register entry = row | position << 14
-static_assert(kSubLog2 + 9 <= 32 && kWqMaxLen <= 512, "packed register entries");
+// This kernel's own row range: handles of up to 2^14 indexed rows, whatever a sub-index of the block kernel holds
+// (TVZ_IX_SUB_LOG2) - eight bitmap words per lane, rank and slot rows in one bitmap, row | position << 14 in a register.
+constexpr int kWqRowsLog2 = 14;
+constexpr int kWqRows = 1 << kWqRowsLog2;
+constexpr int kWqWords = kWqRows / 32;               // words per bitmap
+constexpr bool kWqUsable = kWqRowsLog2 <= kSubLog2;  // (a handle this kernel takes is ONE sub-index of the build)
+constexpr int kWqPosShift = kWqRowsLog2;             // register entry = row | position << 14
+static_assert(kWqRowsLog2 + 9 <= 32 && kWqMaxLen <= 512, "packed register entries");
 constexpr size_t kWqTkBytes = (size_t)kIxTkCap * 8 + (size_t)kIxTkBins * 4 + 16;   // (16: the list table behind it stays 16-byte aligned)
 
 // dynamic LDS of one wave (bytes), by the longest query of the batch
 inline size_t wq_lds_bytes(int max_len) {
     const size_t L = (size_t)((max_len > 0 ? max_len : 1) + 1) & ~(size_t)1;
-    return (size_t)2 * kIxWords * 4        /* seen1, seen2; behind pass A the one that is not the candidates' holds rank + slot rows */
+    return (size_t)2 * kWqWords * 4        /* seen1, seen2; behind pass A the one that is not the candidates' holds rank + slot rows */
            + (size_t)kWqSlots * 12         /* count + smallest positions */
            + (size_t)kWqRegPost / 8        /* list-start bitmap */
            + kWqTkBytes                    /* kept hits, kth histogram, fill */
@@ -67,8 +73,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
     constexpr bool TOP5 = MODE == kIxTop5;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t *bm1 = reinterpret_cast<uint32_t *>(smem);
-    uint32_t *bm2 = bm1 + kIxWords;
-    uint32_t *tcnt = bm2 + kIxWords;
+    uint32_t *bm2 = bm1 + kWqWords;
+    uint32_t *tcnt = bm2 + kWqWords;
     unsigned long long *ttop = reinterpret_cast<unsigned long long *>(tcnt + kWqSlots);
     uint32_t *m12 = reinterpret_cast<uint32_t *>(ttop);   // kIxM2: the same 8 B per slot = {smallest, second smallest} position
     uint32_t *lbits = reinterpret_cast<uint32_t *>(ttop + kWqSlots);                 // bit t: a list starts at local posting t
@@ -79,8 +85,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
     // rank (candidates before bitmap word j) and the rows of the part's slots live in the bitmap that is NOT the
     // candidates' - seen1 for min_match >= 2, seen2 for min_match 1 - which is dead once pass A is over
     uint16_t *rank = reinterpret_cast<uint16_t *>(min_match >= 2 ? bm1 : bm2);
-    uint16_t *elist = rank + kIxWords;                                               // row of slot k
-    static_assert((kIxWords + kWqSlots) * 2 <= kIxWords * 4, "rank + slot rows fit one bitmap");
+    uint16_t *elist = rank + kWqWords;                                               // row of slot k
+    static_assert((kWqWords + kWqSlots) * 2 <= kWqWords * 4, "rank + slot rows fit one bitmap");
 
     const int q = (int)blockIdx.x;
     const int lane = (int)threadIdx.x;
@@ -284,7 +290,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
                 }
 #pragma unroll
 #ifdef TVZ_WQ_NOPOST      // diagnostic build only (WRONG results): no posting is fetched, the row is made up from the address
-                for (int u = 0; u < kWqGs; ++u) R[g * kWqGs + u] = ((e[u].x + (uint32_t)((g * kWqGs + u) * 64 + lane)) * 2654435761u) >> (32 - kSubLog2);
+                for (int u = 0; u < kWqGs; ++u) R[g * kWqGs + u] = ((e[u].x + (uint32_t)((g * kWqGs + u) * 64 + lane)) * 2654435761u) >> (32 - kWqRowsLog2);
 #else
                 for (int u = 0; u < kWqGs; ++u) R[g * kWqGs + u] = (uint32_t)post[e[u].x + (uint32_t)((g * kWqGs + u) * 64 + lane)];
 #endif
@@ -329,7 +335,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
 
     // ---- rank: candidates before every bitmap word (lane l owns words 8 l .. 8 l + 7) ----
     const uint32_t *cand = min_match >= 2 ? bm2 : bm1;
-    constexpr int kWpl = kIxWords / 64;                    // bitmap words per lane
+    constexpr int kWpl = kWqWords / 64;                    // bitmap words per lane
     uint32_t cw[kWpl], rk0, n_cand;
     {
         const uint4 a = *reinterpret_cast<const uint4 *>(cand + lane * kWpl);
@@ -422,13 +428,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
 #pragma unroll
                 for (int u = 0; u < kWqGs; ++u) {
                     rr[u] = (uint32_t)ix_opaque((int)R[g * kWqGs + u]);
-                    const uint32_t r = rr[u] & (uint32_t)(kSubRows - 1);
+                    const uint32_t r = rr[u] & (uint32_t)(kWqRows - 1);
                     w[u] = cand[r >> 5];
                     rkw[u] = rank[r >> 5];
                 }
 #pragma unroll
                 for (int u = 0; u < kWqGs; ++u) {
-                    const uint32_t r = rr[u] & (uint32_t)(kSubRows - 1);
+                    const uint32_t r = rr[u] & (uint32_t)(kWqRows - 1);
                     const uint32_t idx = slot_of(r, w[u], rkw[u]);
                     if ((uint32_t)((g * kWqGs + u) * 64 + lane) < c_hi && idx < (uint32_t)kWqSlots)
                         account_slot(idx, rr[u] >> kWqPosShift);

@@ -1147,10 +1147,10 @@ int launch_index_topk(tvz_corpus *c, const double *d_queries, const int64_t *d_q
     // A handle of ONE sub-index (a rank's share of an 8-way sharded 100k-video table) and queries of up to 512
     // timestamps: one WAVE per query (tvz_index_wave_kernels.h) - no barriers, every probe of the query in flight at
     // once, the postings in registers between the passes.
-    const bool wave_fits = ix.n_sub == 1 && ix.nb > 0 && max_query_len <= kWqMaxLen;
+    const bool wave_fits = kWqUsable && ix.n_sub == 1 && ix.nb > 0 && ix.n_main <= kWqRows && max_query_len <= kWqMaxLen;
     if ((flags & TVZ_ALGO_WAVE) && !wave_fits)
-        return tvz::fail(TVZ_ERR_UNSUPPORTED, "TVZ_ALGO_WAVE: the one-wave lookup takes a handle of one sub-index (this one: %d) "
-                         "and queries of up to %d timestamps (max_query_len %d)", ix.n_sub, kWqMaxLen, max_query_len);
+        return tvz::fail(TVZ_ERR_UNSUPPORTED, "TVZ_ALGO_WAVE: the one-wave lookup takes a handle of one sub-index (this one: %d) of up to %d rows "
+                         "and queries of up to %d timestamps (max_query_len %d)", ix.n_sub, kWqRows, kWqMaxLen, max_query_len);
     if (wave_fits && (flags & (TVZ_ALGO_WAVE | TVZ_ALGO_PREFER_WAVE)) && !(flags & (TVZ_ALGO_NO_WAVE | TVZ_ALGO_PAIR))) {
         const size_t lds = wq_lds_bytes(max_query_len);
 #define TVZ_WQK(MODE)                                                                                        \
