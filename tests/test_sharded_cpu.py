@@ -74,7 +74,9 @@ def _worker(rank, world, port, C, Q, mm, k, cap, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,C,Q,mm,k,cap", [(2, 300, 6, 2, 8, 64), (2, 120, 4, 1, 16, 16), (3, 90, 3, 2, 4, 8)])
+# (world 8: the rank count of BASELINE.json configs[3] - eight blocks gathered and merged on every rank)
+@pytest.mark.parametrize("world,C,Q,mm,k,cap", [(2, 300, 6, 2, 8, 64), (2, 120, 4, 1, 16, 16), (3, 90, 3, 2, 4, 8),
+                                                (8, 240, 4, 2, 8, 32)])
 def test_sharded_match_equals_whole_corpus(world, C, Q, mm, k, cap):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
